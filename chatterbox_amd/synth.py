@@ -1,0 +1,248 @@
+"""Seeded synthetic checkpoints and inputs (there is no network: no pretrained weights).
+
+`t3_state_dict()` / `s3gen_state_dict()` emit tensors under the *reference's own
+state-dict key layout* (verified against the reference
+constructors by tests/golden/make_golden.py), so the very same dict loads into
+the unmodified reference modules (`load_state_dict(strict=True)` modulo the
+out-of-scope `tokenizer.*` / `speaker_encoder.*` prefixes) and into our loader.
+
+Every tensor is drawn from its own CPU generator seeded by crc32(key) ^ seed, so
+a 2-layer model is a strict prefix of the 30-layer one and generation order
+does not matter.  The synthetic-input recipe follows SURVEY.md section 8(d).
+"""
+import math
+import zlib
+
+import torch
+
+# ----------------------------------------------------------------------------- primitives
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def _normal(key, shape, std, seed, mean=0.0):
+    return torch.randn(shape, generator=_gen(key, seed), dtype=torch.float32) * std + mean
+
+
+def _uniform(key, shape, bound, seed):
+    return (torch.rand(shape, generator=_gen(key, seed), dtype=torch.float32) * 2 - 1) * bound
+
+
+def _linear(sd, name, out_f, in_f, seed, bias=True, gain=1.0):
+    b = gain / math.sqrt(in_f)
+    sd[name + ".weight"] = _uniform(name + ".weight", (out_f, in_f), b * math.sqrt(3.0), seed)
+    if bias:
+        sd[name + ".bias"] = _uniform(name + ".bias", (out_f,), 0.1, seed)
+
+
+def _norm(sd, name, dim, seed, bias=True):
+    sd[name + ".weight"] = 1.0 + _normal(name + ".weight", (dim,), 0.1, seed)
+    if bias:
+        sd[name + ".bias"] = _normal(name + ".bias", (dim,), 0.1, seed)
+
+
+def _conv(sd, name, out_c, in_c, k, seed, gain=1.0):
+    b = gain / math.sqrt(in_c * k)
+    sd[name + ".weight"] = _uniform(name + ".weight", (out_c, in_c, k), b * math.sqrt(3.0), seed)
+    sd[name + ".bias"] = _uniform(name + ".bias", (out_c,), 0.1, seed)
+
+
+def _wn_conv(sd, name, dim0, dim1, k, seed, gain=1.0, fan_in=None):
+    """weight_norm parametrization keys: original0 = g (dim0,1,1), original1 = v (dim0,dim1,k)."""
+    fan_in = fan_in or dim1 * k
+    b = gain / math.sqrt(fan_in)
+    v = _uniform(name + ".v", (dim0, dim1, k), b * math.sqrt(3.0), seed)
+    g = v.flatten(1).norm(dim=1).view(dim0, 1, 1) * (1.0 + _normal(name + ".g", (dim0, 1, 1), 0.1, seed))
+    sd[name + ".parametrizations.weight.original0"] = g
+    sd[name + ".parametrizations.weight.original1"] = v
+
+
+# ----------------------------------------------------------------------------- T3 (Llama backbone)
+
+T3_MTL = dict(dim=1024, inter=4096, n_layers=30, n_heads=16, head_dim=64, text_vocab=2454,
+              speech_vocab=8194, max_text_pos=2048 + 2, max_speech_pos=4096 + 4, spk_dim=256,
+              n_query=32, perceiver_heads=4)
+
+
+def t3_state_dict(n_layers=30, seed=0, text_vocab=2454):
+    """Keys of `T3(T3Config.multilingual())` (reference src/chatterbox/models/t3/t3.py:49-86)."""
+    c = dict(T3_MTL, n_layers=n_layers, text_vocab=text_vocab)
+    d, f = c["dim"], c["inter"]
+    sd = {}
+    sd["tfmr.embed_tokens.weight"] = _normal("tfmr.embed_tokens.weight", (8, d), 0.02, seed)
+    for i in range(n_layers):
+        p = f"tfmr.layers.{i}."
+        for nm, (o, k) in dict(q_proj=(d, d), k_proj=(d, d), v_proj=(d, d), o_proj=(d, d)).items():
+            sd[p + f"self_attn.{nm}.weight"] = _normal(p + f"self_attn.{nm}.weight", (o, k), 0.03, seed)
+        for nm, (o, k) in dict(gate_proj=(f, d), up_proj=(f, d), down_proj=(d, f)).items():
+            sd[p + f"mlp.{nm}.weight"] = _normal(p + f"mlp.{nm}.weight", (o, k), 0.03, seed)
+        _norm(sd, p + "input_layernorm", d, seed, bias=False)
+        _norm(sd, p + "post_attention_layernorm", d, seed, bias=False)
+    _norm(sd, "tfmr.norm", d, seed, bias=False)
+    _linear(sd, "cond_enc.spkr_enc", d, c["spk_dim"], seed)
+    sd["cond_enc.emotion_adv_fc.weight"] = _normal("cond_enc.emotion_adv_fc.weight", (d, 1), 1.0, seed)
+    sd["cond_enc.perceiver.pre_attention_query"] = _uniform("cond_enc.perceiver.pre_attention_query",
+                                                            (1, c["n_query"], d), 0.3, seed)
+    _norm(sd, "cond_enc.perceiver.attn.norm", d, seed)
+    for nm in ("to_q", "to_k", "to_v", "proj_out"):
+        _linear(sd, f"cond_enc.perceiver.attn.{nm}", d, d, seed)
+    sd["text_emb.weight"] = _normal("text_emb.weight", (c["text_vocab"], d), 1.0, seed)
+    sd["speech_emb.weight"] = _normal("speech_emb.weight", (c["speech_vocab"], d), 1.0, seed)
+    sd["text_pos_emb.emb.weight"] = _normal("text_pos_emb.emb.weight", (c["max_text_pos"], d), 0.02, seed)
+    sd["speech_pos_emb.emb.weight"] = _normal("speech_pos_emb.emb.weight", (c["max_speech_pos"], d), 0.02, seed)
+    sd["text_head.weight"] = _normal("text_head.weight", (c["text_vocab"], d), 0.05, seed)
+    # a sharper-than-default head so that sampling is not uniform over 8194 ids
+    sd["speech_head.weight"] = _normal("speech_head.weight", (c["speech_vocab"], d), 0.08, seed)
+    return sd
+
+
+# ----------------------------------------------------------------------------- S3Gen (flow + HiFT)
+
+
+def _conformer_layer(sd, p, seed):
+    for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
+        _linear(sd, p + "self_attn." + nm, 512, 512, seed)
+    _linear(sd, p + "self_attn.linear_pos", 512, 512, seed, bias=False)
+    sd[p + "self_attn.pos_bias_u"] = _uniform(p + "self_attn.pos_bias_u", (8, 64), 0.3, seed)
+    sd[p + "self_attn.pos_bias_v"] = _uniform(p + "self_attn.pos_bias_v", (8, 64), 0.3, seed)
+    _linear(sd, p + "feed_forward.w_1", 2048, 512, seed)
+    _linear(sd, p + "feed_forward.w_2", 512, 2048, seed)
+    _norm(sd, p + "norm_ff", 512, seed)
+    _norm(sd, p + "norm_mha", 512, seed)
+
+
+def _cfm_stage(sd, p, cin, seed, tail):
+    _linear(sd, p + "0.mlp.1", 256, 1024, seed)
+    _conv(sd, p + "0.block1.block.0", 256, cin, 3, seed)
+    _norm(sd, p + "0.block1.block.2", 256, seed)
+    _conv(sd, p + "0.block2.block.0", 256, 256, 3, seed)
+    _norm(sd, p + "0.block2.block.2", 256, seed)
+    _conv(sd, p + "0.res_conv", 256, cin, 1, seed)
+    for j in range(4):
+        q = p + f"1.{j}."
+        _norm(sd, q + "norm1", 256, seed)
+        for nm in ("to_q", "to_k", "to_v"):
+            _linear(sd, q + "attn1." + nm, 512, 256, seed, bias=False)
+        _linear(sd, q + "attn1.to_out.0", 256, 512, seed)
+        _norm(sd, q + "norm3", 256, seed)
+        _linear(sd, q + "ff.net.0.proj", 1024, 256, seed)
+        _linear(sd, q + "ff.net.2", 256, 1024, seed)
+    if tail:
+        _conv(sd, p + "2", 256, 256, 3, seed)
+
+
+def _hift_resblock(sd, p, ch, k, seed):
+    for j in range(3):
+        _wn_conv(sd, p + f"convs1.{j}", ch, ch, k, seed)
+        sd[p + f"convs1.{j}.bias"] = _uniform(p + f"convs1.{j}.bias", (ch,), 0.05, seed)
+        _wn_conv(sd, p + f"convs2.{j}", ch, ch, k, seed)
+        sd[p + f"convs2.{j}.bias"] = _uniform(p + f"convs2.{j}.bias", (ch,), 0.05, seed)
+        sd[p + f"activations1.{j}.alpha"] = 1.0 + _normal(p + f"activations1.{j}.alpha", (ch,), 0.2, seed)
+        sd[p + f"activations2.{j}.alpha"] = 1.0 + _normal(p + f"activations2.{j}.alpha", (ch,), 0.2, seed)
+
+
+def s3gen_state_dict(seed=0, meanflow=False, n_mid=12, n_enc=6, n_up_enc=4):
+    """Keys of `S3Token2Wav()` minus tokenizer.* / speaker_encoder.* (reference s3gen.py:53-258)."""
+    sd = {}
+    sd["flow.input_embedding.weight"] = _normal("flow.input_embedding.weight", (6561, 512), 1.0, seed)
+    _linear(sd, "flow.spk_embed_affine_layer", 80, 192, seed)
+    e = "flow.encoder."
+    _linear(sd, e + "embed.out.0", 512, 512, seed)
+    _norm(sd, e + "embed.out.1", 512, seed)
+    _norm(sd, e + "after_norm", 512, seed)
+    _conv(sd, e + "pre_lookahead_layer.conv1", 512, 512, 4, seed)
+    _conv(sd, e + "pre_lookahead_layer.conv2", 512, 512, 3, seed)
+    for i in range(n_enc):
+        _conformer_layer(sd, e + f"encoders.{i}.", seed)
+    _conv(sd, e + "up_layer.conv", 512, 512, 5, seed)
+    _linear(sd, e + "up_embed.out.0", 512, 512, seed)
+    _norm(sd, e + "up_embed.out.1", 512, seed)
+    for i in range(n_up_enc):
+        _conformer_layer(sd, e + f"up_encoders.{i}.", seed)
+    _linear(sd, "flow.encoder_proj", 80, 512, seed)
+    d = "flow.decoder.estimator."
+    _linear(sd, d + "time_mlp.linear_1", 1024, 320, seed)
+    _linear(sd, d + "time_mlp.linear_2", 1024, 1024, seed)
+    if meanflow:
+        w = torch.zeros(1024, 2048)
+        w[:, :1024] = torch.eye(1024)
+        sd[d + "time_embed_mixer.weight"] = w + _normal(d + "time_embed_mixer.weight", (1024, 2048), 0.01, seed)
+    _cfm_stage(sd, d + "down_blocks.0.", 320, seed, tail=True)
+    for i in range(n_mid):
+        _cfm_stage(sd, d + f"mid_blocks.{i}.", 256, seed, tail=False)
+    _cfm_stage(sd, d + "up_blocks.0.", 512, seed, tail=True)
+    _conv(sd, d + "final_block.block.0", 256, 256, 3, seed)
+    _norm(sd, d + "final_block.block.2", 256, seed)
+    _conv(sd, d + "final_proj", 80, 256, 1, seed)
+
+    h = "mel2wav."
+    sd[h + "m_source.l_linear.weight"] = _uniform(h + "m_source.l_linear.weight", (1, 9), 1.5, seed)
+    sd[h + "m_source.l_linear.bias"] = _uniform(h + "m_source.l_linear.bias", (1,), 0.1, seed)
+    _wn_conv(sd, h + "conv_pre", 512, 80, 7, seed)
+    sd[h + "conv_pre.bias"] = _uniform(h + "conv_pre.bias", (512,), 0.05, seed)
+    for i, (cin, cout, k) in enumerate(((512, 256, 16), (256, 128, 11), (128, 64, 7))):
+        # ConvTranspose1d weight is (Cin, Cout, k); weight_norm(dim=0) -> g per *input* channel
+        _wn_conv(sd, h + f"ups.{i}", cin, cout, k, seed, fan_in=cin * k // (8, 5, 3)[i])
+        sd[h + f"ups.{i}.bias"] = _uniform(h + f"ups.{i}.bias", (cout,), 0.05, seed)
+    for i, (cout, k) in enumerate(((256, 30), (128, 6), (64, 1))):
+        _conv(sd, h + f"source_downs.{i}", cout, 18, k, seed)
+    for i, (ch, k) in enumerate(((256, 7), (128, 7), (64, 11))):
+        _hift_resblock(sd, h + f"source_resblocks.{i}.", ch, k, seed)
+    for i in range(9):
+        _hift_resblock(sd, h + f"resblocks.{i}.", (256, 128, 64)[i // 3], (3, 7, 11)[i % 3], seed)
+    # small conv_post so exp(.) stays far from the 1e2 clip and the +-0.99 clamp rarely fires
+    _wn_conv(sd, h + "conv_post", 18, 64, 7, seed, gain=0.15)
+    sd[h + "conv_post.bias"] = _uniform(h + "conv_post.bias", (18,), 0.05, seed) - 2.5
+    f = h + "f0_predictor."
+    for j, cin in zip((0, 2, 4, 6, 8), (80, 512, 512, 512, 512)):
+        _wn_conv(sd, f + f"condnet.{j}", 512, cin, 3, seed)
+        sd[f + f"condnet.{j}.bias"] = _uniform(f + f"condnet.{j}.bias", (512,), 0.05, seed)
+    # scaled so that |f0| straddles the 10 Hz voiced threshold (both SineGen branches exercised)
+    sd[f + "classifier.weight"] = _uniform(f + "classifier.weight", (1, 512), 12.0, seed)
+    sd[f + "classifier.bias"] = torch.tensor([60.0])
+    return sd
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+
+
+def text_tokens(n=64, seed=1, vocab=2454):
+    """`n` ids uniform in [1, vocab) excluding SOT 255 / EOT 0, then SOT/EOT padded (mtl_tts.py:319-322)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    t = torch.randint(1, vocab - 1, (n,), generator=g)
+    t = torch.where(t >= 255, t + 1, t)
+    return torch.cat([torch.tensor([255]), t, torch.tensor([0])]).long()
+
+
+def t3_cond(seed=2, prompt_len=150, emotion=0.5):
+    g = torch.Generator().manual_seed(2000 + seed)
+    spk = torch.randn(1, 256, generator=g)
+    spk = spk / spk.norm()
+    toks = torch.randint(0, 6561, (1, prompt_len), generator=g)
+    return dict(speaker_emb=spk, cond_prompt_speech_tokens=toks, emotion_adv=emotion * torch.ones(1, 1, 1))
+
+
+def s3gen_ref(seed=4, n_prompt_tokens=250):
+    g = torch.Generator().manual_seed(4000 + seed)
+    tok = torch.randint(0, 6561, (1, n_prompt_tokens), generator=g)
+    feat = (torch.randn(1, 2 * n_prompt_tokens, 80, generator=g) * 2 - 5).clamp(-11.5, 2.0)
+    emb = torch.randn(1, 192, generator=g)
+    return dict(prompt_token=tok, prompt_token_len=torch.tensor([n_prompt_tokens]), prompt_feat=feat,
+                prompt_feat_len=None, embedding=emb)
+
+
+def speech_tokens(n=250, seed=1):
+    g = torch.Generator().manual_seed(5000 + seed)
+    return torch.randint(0, 6561, (n,), generator=g)
+
+
+def randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(6000 + seed))
+
+
+def rand(shape, seed):
+    return torch.rand(shape, generator=torch.Generator().manual_seed(7000 + seed))

@@ -1,0 +1,94 @@
+"""ctypes binding of libcbx_hip.so (the C ABI declared in include/cbx.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point is absent, importing this
+module raises.  torch is imported first so that the already-loaded ROCm runtime (libamdhip64.so.7) is the one
+our library binds to -- pointers and streams are then interchangeable with torch's.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcbx_hip.so")
+
+c_f = ctypes.c_void_p
+c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+
+class GemmParams(ctypes.Structure):
+    _fields_ = [
+        ("A", c_f), ("W", c_f), ("C", c_f), ("bias", c_f), ("R", c_f), ("C2", c_f),
+        ("act1_param", c_f), ("act2_param", c_f), ("lens", c_f),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("Cin", c_int), ("taps", c_int), ("dil", c_int), ("stride", c_int), ("pad_left", c_int), ("up", c_int),
+        ("Tin", c_int), ("nz1", c_int), ("nz2", c_int), ("w_kn", c_int), ("swiglu", c_int),
+        ("act1", c_int), ("act2", c_int),
+        ("act1_slope", c_float), ("act2_slope", c_float), ("alpha", c_float), ("beta", c_float),
+        ("lda", c_long), ("a_s1", c_long), ("a_s2", c_long),
+        ("ldw", c_long), ("w_s1", c_long), ("w_s2", c_long),
+        ("ldc", c_long), ("c_s1", c_long), ("c_s2", c_long),
+        ("ldr", c_long), ("r_s1", c_long), ("r_s2", c_long),
+        ("ldc2", c_long), ("c2_s1", c_long), ("c2_s2", c_long),
+    ]
+
+
+class SamplerParams(ctypes.Structure):
+    _fields_ = [
+        ("logits", c_f), ("ld", c_long), ("V", c_int), ("B", c_int), ("cfg", c_int),
+        ("cfg_weight", c_float), ("temperature", c_float), ("min_p", c_float), ("top_p", c_float),
+        ("rep_penalty", c_float), ("top_k", c_int), ("order", c_int), ("ban_token", c_int), ("eos_token", c_int),
+        ("seen", c_f), ("uniforms", c_f), ("max_steps", c_int), ("step", c_f), ("out_tokens", c_f),
+        ("done", c_f), ("n_generated", c_f), ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f),
+        ("ctx_lens", c_f),
+    ]
+
+
+_SIGS = {
+    "cbx_abi_version": ([], c_int),
+    "cbx_last_error": ([], ctypes.c_char_p),
+    "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
+    "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
+    "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),
+    "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
+    "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
+    "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
+    "cbx_axpby_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_float, c_f], c_int),
+    "cbx_embed_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_float, c_int, c_f], c_int),
+    "cbx_rope_kv_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_f], c_int),
+    "cbx_cfm_euler_f32": ([c_f, c_f, c_int, c_long, c_int, c_long, c_long, c_long, c_long, c_float, c_float, c_int, c_f], c_int),
+    "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
+    "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
+    "cbx_hift_stft_f32": ([c_f, c_f, c_int, c_long, c_long, c_f], c_int),
+    "cbx_hift_istft_f32": ([c_f, c_f, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
+}
+
+
+class CbxError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m chatterbox_amd.build` (hipcc --offload-arch=gfx950). "
+            "chatterbox_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"libcbx_hip.so does not export {name} (stale build?)") from e
+        fn.argtypes = args
+        fn.restype = res
+    if lib.cbx_abi_version() != 1:
+        raise ImportError("libcbx_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise CbxError(f"{what}: rc={rc}: {lib.cbx_last_error().decode(errors='replace')}")

@@ -1,0 +1,309 @@
+// Attention kernels (fp32 exact): flash-style tiled attention on v_mfma_f32_32x32x2_f32, single-query decode
+// attention streaming the KV cache, and the materialised rel-pos softmax of the conformer encoder.
+#include "cbx_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// Flash attention, head_dim 64.  Workgroup = 4 waves x 32 queries; KV walked in 64-key tiles staged in LDS.
+//
+// "Swapped" formulation so that softmax statistics are lane-local: the wave computes S^T = K Q^T, whose MFMA
+// C/D map puts query (lane&31) in the column and 16 keys in the lane's registers; the row max / sum of a query
+// is then 16 in-register ops + ONE cross-half shuffle.  O^T = V^T P^T uses the same column = query map, so the
+// exponentiated P registers feed the second MFMA directly as its B operand (no LDS round trip for P) and the
+// online-softmax rescale is a per-lane scalar.  The d (resp. key) contraction order is permuted so that the two
+// half-waves own d in [0,32) / [32,64) (resp. keys r and r+4) -- legal because MFMA sums both halves' k.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int KT = 64;        // keys per LDS tile
+constexpr int K_LD = 65;      // K tile row stride (floats): b32 reads by 32 consecutive keys are conflict-free
+constexpr int V_LD = 64;
+
+struct FlashArgs {
+    const float* q; const float* k; const float* v; float* o; const int* key_lens;
+    int Tq, Tk;
+    long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
+    float scale;
+    int causal;  // 0 = none; else key j allowed iff j <= i + (Tk - Tq)
+};
+
+__global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, z = blockIdx.z;
+    const int q0 = blockIdx.x * 128;
+    const int qi = q0 + wid * 32 + lr;  // this lane's query
+    const float* qb = a.q + (long)z * a.q_sb + head * 64;
+    const float* kb = a.k + (long)z * a.k_sb + head * 64;
+    const float* vb = a.v + (long)z * a.v_sb + head * 64;
+    const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
+    const int coff = a.Tk - a.Tq;
+
+    // Q fragment: d = s + 32*lh, pre-scaled
+    float qreg[32];
+    {
+        const bool ok = qi < a.Tq;
+        const float* qp = qb + (long)(ok ? qi : 0) * a.q_st + 32 * lh;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(qp + s4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qreg[s4 * 4 + e] = ok ? t[e] * a.scale : 0.f;
+        }
+    }
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kend = klen;
+    if (a.causal) kend = min(kend, q0 + 128 + coff);  // keys beyond the block's last query are never visible
+    const int ld_row = tid >> 2, ld_c = (tid & 3) * 16;
+
+    for (int j0 = 0; j0 < kend; j0 += KT) {
+        // ---- stage K/V tile (64 keys x 64 d each)
+        {
+            const int j = j0 + ld_row;
+            const bool ok = j < klen;
+            const float* kp = kb + (long)(ok ? j : 0) * a.k_st + ld_c;
+            const float* vp = vb + (long)(ok ? j : 0) * a.v_st + ld_c;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
+                    vv = *reinterpret_cast<const f32x4*>(vp + c * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ks[ld_row * K_LD + ld_c + c * 4 + e] = kv[e];
+                *reinterpret_cast<f32x4*>(&Vs[ld_row * V_LD + ld_c + c * 4]) = vv;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T  (2 sub-tiles of 32 keys)
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+            const float* kr = &Ks[(t * 32 + lr) * K_LD + 32 * lh];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[s], qreg[s], st[t], 0, 0, 0);
+        }
+
+        // ---- mask + online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int j = j0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bool vis = j < klen && (!a.causal || j <= qi + coff);
+                float sv = vis ? st[t][r] : -INFINITY;
+                st[t][r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        float alpha = 1.f;
+        if (m_new > -INFINITY) alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = (m_new > -INFINITY) ? __expf(st[t][r] - m_new) : 0.f;
+                st[t][r] = pv;
+                ls += pv;
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T : MFMA step (t,r) contracts keys t*32 + row(r) (+4 for the upper half-wave)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float* vr = &Vs[key * V_LD + lr];
+                ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[t][r], ot[0], 0, 0, 0);
+                ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[t][r], ot[1], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+
+    // ---- finalise: both half-waves hold partial sums of the same query
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Tq) {
+        float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t = {ot[d][g * 4 + 0] * inv, ot[d][g * 4 + 1] * inv, ot[d][g * 4 + 2] * inv, ot[d][g * 4 + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * lh) = t;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Decode attention: one query row per (row, head), KV cache [row][head][pos][64] streamed once.
+// 4 waves split the context; inside a wave 16 lanes x float4 cover one key row (4 keys per wave-iteration,
+// 1 KiB contiguous per load instruction).  Scores go through LDS (two-pass softmax), then V is streamed.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DEC_MAX_CTX = 8192;
+
+__global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                              const float* __restrict__ vc, float* __restrict__ o,
+                                                              const int* __restrict__ ctx_lens, long q_ld, long o_ld,
+                                                              long row_stride, long head_stride, float scale) {
+    __shared__ float sc[DEC_MAX_CTX];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float oacc[4][64];
+    const int row = blockIdx.y, head = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = lane >> 4, l16 = lane & 15;  // key-in-group, float4 index within the 64-d row
+    const int ctx = min(ctx_lens[row], DEC_MAX_CTX);
+    const float* kb = kc + (long)row * row_stride + (long)head * head_stride;
+    const float* vb = vc + (long)row * row_stride + (long)head * head_stride;
+    f32x4 qv = *reinterpret_cast<const f32x4*>(q + (long)row * q_ld + head * 64 + l16 * 4);
+    qv *= scale;
+
+    // pass 1: scores
+    float mx = -INFINITY;
+    for (int p0 = wid * 4; p0 < ctx; p0 += 16) {
+        int pos = p0 + sub;
+        float d = 0.f;
+        if (pos < ctx) {
+            f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)pos * 64 + l16 * 4);
+            d = kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+        }
+        d += __shfl_xor(d, 8);
+        d += __shfl_xor(d, 4);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 1);
+        if (pos < ctx) {
+            if (l16 == 0) sc[pos] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int p = tid; p < ctx; p += 256) {
+        float e = __expf(sc[p] - mx);
+        sc[p] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wid] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+
+    // pass 2: weighted V
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = wid * 4; p0 < ctx; p0 += 16) {
+        int pos = p0 + sub;
+        if (pos < ctx) {
+            f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long)pos * 64 + l16 * 4);
+            float pw = sc[pos];
+            acc += vv * pw;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (sub == 0) *reinterpret_cast<f32x4*>(&oacc[wid][l16 * 4]) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float t = (oacc[0][tid] + oacc[1][tid] + oacc[2][tid] + oacc[3][tid]) * inv;
+        o[(long)row * o_ld + head * 64 + tid] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Conformer rel-pos softmax over materialised scores: one wave per query row.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_relpos_kernel(const float* __restrict__ ac, const float* __restrict__ bd,
+                                                             float* __restrict__ p, const int* __restrict__ key_lens,
+                                                             int nz2, int Tq, int Tk, long ld_ac, long ld_bd, long ld_p,
+                                                             long zs_ac, long zs_bd, long zs_p, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.y;
+    if (i >= Tq) return;
+    const int klen = key_lens ? min(Tk, key_lens[z / nz2]) : Tk;
+    const float* ar = ac + (long)z * zs_ac + (long)i * ld_ac;
+    const float* br = bd ? bd + (long)z * zs_bd + (long)i * ld_bd + (Tk - 1 - i) : nullptr;
+    float* pr = p + (long)z * zs_p + (long)i * ld_p;
+    float mx = -INFINITY;
+    for (int j = lane; j < klen; j += 64) {
+        float s = ar[j] + (br ? br[j] : 0.f);
+        mx = fmaxf(mx, s * scale);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < klen; j += 64) {
+        float s = (ar[j] + (br ? br[j] : 0.f)) * scale;
+        sum += __expf(s - mx);
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    for (int j = lane; j < ld_p; j += 64) {
+        float v = 0.f;
+        if (j < klen) {
+            float s = (ar[j] + (br ? br[j] : 0.f)) * scale;
+            v = __expf(s - mx) * inv;
+        }
+        pr[j] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
+                                  int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                                  long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, void* stream) {
+    CBX_REQUIRE(q && k && v && o, "flash_attn: null operand");
+    CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn: bad shape");
+    CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb) % 4 == 0, "flash_attn: strides must be multiples of 4");
+    CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn: 16-byte alignment");
+    FlashArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
+    dim3 grid((Tq + 127) / 128, n_heads, nz1);
+    hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return cbx_check_launch("flash_attn");
+}
+
+extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float* o, const int* ctx_lens,
+                                   int rows, int n_heads, long q_ld, long o_ld, long cache_row_stride,
+                                   long cache_head_stride, float scale, void* stream) {
+    CBX_REQUIRE(q && kc && vc && o && ctx_lens, "decode_attn: null operand");
+    CBX_REQUIRE(q_ld % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn: alignment");
+    hipLaunchKernelGGL(decode_attn_f32_kernel, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, q, kc, vc, o,
+                       ctx_lens, q_ld, o_ld, cache_row_stride, cache_head_stride, scale);
+    return cbx_check_launch("decode_attn");
+}
+
+extern "C" int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int* key_lens, int nz1, int nz2,
+                                      int Tq, int Tk, long ld_ac, long ld_bd, long ld_p, long zs_ac, long zs_bd,
+                                      long zs_p, float scale, void* stream) {
+    CBX_REQUIRE(ac && p && Tq > 0 && Tk > 0, "softmax_relpos: bad args");
+    hipLaunchKernelGGL(softmax_relpos_kernel, dim3((Tq + 3) / 4, nz1 * nz2), dim3(256), 0, (hipStream_t)stream, ac, bd, p,
+                       key_lens, nz2, Tq, Tk, ld_ac, ld_bd, ld_p, zs_ac, zs_bd, zs_p, scale);
+    return cbx_check_launch("softmax_relpos");
+}

@@ -1,0 +1,54 @@
+// Shared device/host helpers for libcbx_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/cbx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern thread_local char cbx_err_buf[512];
+int cbx_set_error(int code, const char* fmt, ...);
+int cbx_check_launch(const char* what);
+
+#define CBX_REQUIRE(cond, ...)                                     \
+    do {                                                           \
+        if (!(cond)) return cbx_set_error(CBX_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+__device__ __forceinline__ float cbx_act(float v, int act, float slope, float param) {
+    switch (act) {
+        case CBX_ACT_SILU: return v / (1.0f + __expf(-v));
+        case CBX_ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        case CBX_ACT_GELU_TANH: {
+            float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+            return 0.5f * v * (1.0f + tanhf(u));
+        }
+        case CBX_ACT_MISH: {
+            // x * tanh(softplus(x)); torch softplus threshold 20
+            float sp = v > 20.0f ? v : log1pf(expf(v));
+            return v * tanhf(sp);
+        }
+        case CBX_ACT_LRELU: return v > 0.0f ? v : v * slope;
+        case CBX_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+        case CBX_ACT_TANH: return tanhf(v);
+        case CBX_ACT_SNAKE: {
+            float s = sinf(v * param);
+            return v + (1.0f / (param + 1e-9f)) * s * s;
+        }
+        case CBX_ACT_ABS: return fabsf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,267 @@
+// Implicit-GEMM linear / conv1d / batched matmul on the fp32 matrix cores of gfx950.
+//
+//   v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD = 157 TF chip peak.
+//
+// One 256-thread workgroup (4 waves, one per SIMD) owns a BM x BN output tile; K is walked in 16-float
+// tiles that are register-prefetched from HBM while the previous tile is consumed from a double-buffered
+// LDS image (one s_barrier per K tile).  A wave's MFMA operand for k-step s is one float per lane; the two
+// half-waves take k = 4h+s of each 8-deep k-block (h = lane>>5), so every lane fetches its four operands with
+// ONE ds_read_b128 from a row of stride 20 floats (conflict-free for the b128 lane groups).
+//
+// The A operand is generated on the fly from a channel-last activation tensor: K = taps*Cin and the row of tap j
+// for output row m is (m*stride + j*dil - pad_left)/up, zero outside [0, min(Tin, lens[z1])) -- that single
+// address generator gives Linear, Conv1d (any stride/dilation/padding, causal or not), nearest-upsample+conv,
+// phase-packed ConvTranspose1d and ragged-batch masking without ever materialising im2col.
+#include "cbx_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDS_LD = BK + 4;  // 20 floats = 80 B row stride: 16-B aligned, b128 reads conflict-free
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const cbx_gemm_t p) {
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_IT = (BM + 63) / 64;  // float4 loads per thread per K tile (A)
+    constexpr int B_IT = BN / 64;
+    constexpr bool A_PART = (BM % 64) != 0;  // BM = 32: only threads 0..127 carry A rows
+    static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WARPS_N, wn = wid % WARPS_N;
+    const int z = blockIdx.z, z1 = z / p.nz2, z2 = z - z1 * p.nz2;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+
+    const float* __restrict__ Ab = p.A + (long)z1 * p.a_s1 + (long)z2 * p.a_s2;
+    const float* __restrict__ Wb = p.W + (long)z1 * p.w_s1 + (long)z2 * p.w_s2;
+    const int lim = p.lens ? min(p.Tin, p.lens[z1]) : p.Tin;
+    const int K = p.K;
+
+    // ---- per-thread loader state
+    const int a_c4 = (tid & 3) * 4;
+    int a_base[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + (tid >> 2) + 64 * i;
+        a_ok[i] = m < p.M && (!A_PART || (tid >> 2) + 64 * i < BM);
+        a_base[i] = m * p.stride - p.pad_left;
+    }
+    f32x4 ra[A_IT], rb[B_IT];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        int tap = 0, c0 = k0;
+        if (p.taps > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
+        const int kk = k0 + a_c4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int rr = a_base[i] + tap * p.dil;
+            bool ok = a_ok[i] && rr >= 0;
+            int row = (p.up > 1) ? (rr / p.up) : rr;
+            ok = ok && row < lim;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = Ab + (long)row * p.lda + c0 + a_c4;
+                if (kk + 3 < K) {
+                    v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kk + e < K) v[e] = src[e];
+                }
+            }
+            ra[i] = v;
+        }
+        if constexpr (!W_KN) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                int n = n0 + (tid >> 2) + 64 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.N) {
+                    const float* src = Wb + (long)n * p.ldw + kk;
+                    if (kk + 3 < K) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (kk + e < K) v[e] = src[e];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {
+            constexpr int PER = BN / 4;  // float4 per k row
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                int idx = tid + 256 * i;
+                int kr = idx / PER, c4 = (idx - kr * PER) * 4;
+                int k = k0 + kr, n = n0 + c4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    const float* src = Wb + (long)k * p.ldw + n;
+                    if (n + 3 < p.N) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) v[e] = src[e];
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (!A_PART || (tid >> 2) + 64 * i < BM)
+                *reinterpret_cast<f32x4*>(&As[buf][((tid >> 2) + 64 * i) * LDS_LD + a_c4]) = ra[i];
+        if constexpr (!W_KN) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 2) + 64 * i) * LDS_LD + a_c4]) = rb[i];
+        } else {
+            constexpr int PER = BN / 4;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                int idx = tid + 256 * i;
+                int kr = idx / PER, c4 = (idx - kr * PER) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[buf][(c4 + e) * LDS_LD + kr] = rb[i][e];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* as = &As[cur][(wm * WM + lr) * LDS_LD + 4 * lh];
+        const float* bs = &Bs[cur][(wn * WN + lr) * LDS_LD + 4 * lh];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + kb * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cb = p.C + (long)z1 * p.c_s1 + (long)z2 * p.c_s2;
+    const float* Rb = p.R ? p.R + (long)z1 * p.r_s1 + (long)z2 * p.r_s2 : nullptr;
+    float* C2b = p.C2 ? p.C2 + (long)z1 * p.c2_s1 + (long)z2 * p.c2_s2 : nullptr;
+
+    if (p.swiglu) {
+        if constexpr (TN == 2) {
+            const int oc = (n0 + wn * WN) / 2 + lr;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M && oc < p.N / 2) {
+                        float g = acc[i][0][r], u = acc[i][1][r];
+                        Cb[(long)m * p.ldc + oc] = (g / (1.0f + __expf(-g))) * u;
+                    }
+                }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        if (n >= p.N) continue;
+        const float bia = p.bias ? p.bias[n] : 0.f;
+        const float a1 = p.act1_param ? p.act1_param[n] : 0.f;
+        const float a2 = p.act2_param ? p.act2_param[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bia;
+                v = cbx_act(v, p.act1, p.act1_slope, a1);
+                if (Rb) v += Rb[(long)m * p.ldr + n];
+                v *= p.alpha;
+                float* dst = Cb + (long)m * p.ldc + n;
+                if (p.beta != 0.f) v += p.beta * *dst;
+                *dst = v;
+                if (C2b) C2b[(long)m * p.ldc2 + n] = cbx_act(v, p.act2, p.act2_slope, a2);
+            }
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN>
+int launch(const cbx_gemm_t& p, hipStream_t st) {
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WARPS_M, WARPS_N, W_KN>), grid, dim3(256), 0, st, p);
+    return cbx_check_launch("gemm_f32");
+}
+
+}  // namespace
+
+extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
+    cbx_gemm_t p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.nz1 < 1) p.nz1 = 1;
+    if (p.nz2 < 1) p.nz2 = 1;
+    if (p.taps < 1) p.taps = 1;
+    if (p.stride < 1) p.stride = 1;
+    if (p.up < 1) p.up = 1;
+    if (p.taps == 1 && p.Cin == 0) p.Cin = p.K;
+    if (p.Tin == 0) p.Tin = p.M;
+    CBX_REQUIRE(p.A && p.W && p.C, "gemm: null operand");
+    CBX_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+    CBX_REQUIRE(p.K == p.taps * p.Cin, "gemm: K=%d != taps*Cin=%d*%d", p.K, p.taps, p.Cin);
+    CBX_REQUIRE(p.taps == 1 || p.Cin % BK == 0, "gemm: conv needs Cin %% 16 == 0 (Cin=%d)", p.Cin);
+    CBX_REQUIRE(p.lda % 4 == 0 && p.a_s1 % 4 == 0 && p.a_s2 % 4 == 0 && ((uintptr_t)p.A & 15) == 0,
+                "gemm: A must be 16-byte aligned (lda=%ld)", p.lda);
+    CBX_REQUIRE(p.ldw % 4 == 0 && p.w_s1 % 4 == 0 && p.w_s2 % 4 == 0 && ((uintptr_t)p.W & 15) == 0,
+                "gemm: W must be 16-byte aligned (ldw=%ld)", p.ldw);
+    CBX_REQUIRE((long)p.nz1 * p.nz2 <= 65535, "gemm: too many batches");
+    CBX_REQUIRE(!p.swiglu || (p.N % 64 == 0 && !p.bias && !p.R && !p.C2 && !p.w_kn), "gemm: bad swiglu config");
+    if (p.w_kn) {
+        if (p.N <= 64) return launch<128, 64, 2, 2, true>(p, st);
+        return launch<128, 128, 2, 2, true>(p, st);
+    }
+    if (p.swiglu) {
+        if (p.M <= 32) return launch<32, 256, 1, 4, false>(p, st);
+        return launch<128, 128, 2, 2, false>(p, st);
+    }
+    if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
+    if (p.N <= 64) return launch<128, 64, 2, 2, false>(p, st);
+    return launch<128, 128, 2, 2, false>(p, st);
+}

@@ -1,0 +1,236 @@
+// Device-side T3 sampler: CFG combine + repetition penalty + temperature + min-p / top-k / top-p + softmax +
+// inverse-CDF sampling, one 1024-thread workgroup per utterance, the whole vocabulary row resident in LDS.
+// Nothing returns to the host: the kernel appends the token, updates the repetition bitmap, the EOS flag and
+// the per-row position / context-length scalars that the next decode step (same hipGraph) reads.
+//
+// Semantics follow the reference loop body (models/t3/t3.py:339-368) and the HF logits processors it calls
+// (transformers/generation/logits_process.py: RepetitionPenalty, Temperature, MinP, TopK, TopP); torch.multinomial
+// is replaced by inverse-CDF sampling on a caller-provided uniform, which is how the oracle injects its RNG.
+#include "cbx_common.h"
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int MAXV = 8448;  // >= 8194, multiple of 64
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += red[i];
+    return r;
+}
+
+// HF RepetitionPenaltyLogitsProcessor on the ids seen so far
+__device__ __forceinline__ void rep_penalty(float* l, const unsigned char* seen, int V, float pen) {
+    for (int i = threadIdx.x; i < V; i += NT)
+        if (seen[i]) l[i] = l[i] < 0.f ? l[i] * pen : l[i] / pen;
+}
+
+// HF TopPLogitsWarper: drop the ascending-sorted prefix whose cumulative probability is <= 1 - top_p.
+// Sort-free: token i is dropped iff mass{p_j <= p_i} <= 1 - top_p; the cut value is found by bisection on the
+// (monotone) bit pattern of the un-normalised probabilities.
+__device__ void top_p_filter(float* l, int V, float top_p, float* red) {
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += NT) m = fmaxf(m, l[i]);
+    m = block_max(m, red);
+    float z = 0.f;
+    for (int i = threadIdx.x; i < V; i += NT) z += __expf(l[i] - m);
+    z = block_sum(z, red);
+    const float budget = (1.0f - top_p) * z;
+    unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget
+    while (lo + 1 < hi) {
+        unsigned mid = lo + (hi - lo) / 2;
+        float thr = __uint_as_float(mid);
+        float s = 0.f;
+        for (int i = threadIdx.x; i < V; i += NT) {
+            float e = __expf(l[i] - m);
+            if (e <= thr) s += e;
+        }
+        s = block_sum(s, red);
+        if (s <= budget) lo = mid; else hi = mid;
+    }
+    const float cut = __uint_as_float(lo);
+    __syncthreads();
+    for (int i = threadIdx.x; i < V; i += NT) {
+        float e = __expf(l[i] - m);
+        if (e <= cut && e < 1.0f) l[i] = -INFINITY;  // the arg-max is always kept (min_tokens_to_keep = 1)
+    }
+    __syncthreads();
+}
+
+// HF TopKLogitsWarper: scores < k-th largest -> -inf (bisection on the order-preserving integer image).
+__device__ void top_k_filter(float* l, int V, int k, float* red) {
+    if (k <= 0 || k >= V) return;
+    auto key = [](float f) -> unsigned {
+        unsigned u = __float_as_uint(f);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    };
+    unsigned lo = 0u, hi = 0xFFFFFFFFu;  // largest key with count{key(l) >= key} >= k
+    while (lo < hi) {
+        unsigned mid = lo + (hi - lo) / 2 + 1;
+        float c = 0.f;
+        for (int i = threadIdx.x; i < V; i += NT) c += key(l[i]) >= mid ? 1.f : 0.f;
+        c = block_sum(c, red);
+        if (c >= (float)k) lo = mid; else hi = mid - 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V; i += NT)
+        if (key(l[i]) < lo) l[i] = -INFINITY;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
+    __shared__ float l[MAXV];
+    __shared__ float red[NT / 64];
+    __shared__ double redd[NT / 64];
+    __shared__ double wave_base[NT / 64];
+    __shared__ int chosen;
+
+    const int b = blockIdx.x, tid = threadIdx.x, V = p.V;
+    if (p.done[b]) return;
+    const int step = p.step[b];
+    if (step >= p.max_steps) return;
+    unsigned char* seen = p.seen + (long)b * V;
+    const float* lc = p.logits + (long)b * p.ld;
+    const float* lu = p.logits + (long)(p.B + b) * p.ld;
+
+    for (int i = tid; i < V; i += NT) {
+        float c = lc[i];
+        l[i] = p.cfg ? c + p.cfg_weight * (c - lu[i]) : c;
+    }
+    __syncthreads();
+
+    if (p.order == 0) {  // T3.inference: penalty -> temperature -> min-p -> top-p
+        if (p.rep_penalty != 1.0f) rep_penalty(l, seen, V, p.rep_penalty);
+        __syncthreads();
+        if (p.temperature != 1.0f)
+            for (int i = tid; i < V; i += NT) l[i] = l[i] / p.temperature;
+        __syncthreads();
+        if (p.min_p > 0.f) {
+            float m = -INFINITY;
+            for (int i = tid; i < V; i += NT) m = fmaxf(m, l[i]);
+            m = block_max(m, red);
+            float z = 0.f;
+            for (int i = tid; i < V; i += NT) z += __expf(l[i] - m);
+            z = block_sum(z, red);
+            const float top = 1.0f / z;
+            for (int i = tid; i < V; i += NT) {
+                float pr = __expf(l[i] - m) / z;
+                if (pr < p.min_p * top && l[i] < m) l[i] = -INFINITY;
+            }
+            __syncthreads();
+        }
+        if (p.top_p < 1.0f) top_p_filter(l, V, p.top_p, red);
+    } else {  // T3.inference_turbo: temperature -> top-k -> top-p -> penalty
+        if (p.temperature > 0.f && p.temperature != 1.0f)
+            for (int i = tid; i < V; i += NT) l[i] = l[i] / p.temperature;
+        __syncthreads();
+        top_k_filter(l, V, p.top_k, red);
+        if (p.top_p < 1.0f) top_p_filter(l, V, p.top_p, red);
+        if (p.rep_penalty != 1.0f) rep_penalty(l, seen, V, p.rep_penalty);
+        __syncthreads();
+    }
+
+    // ---- softmax + inverse CDF.  Thread t owns the contiguous ids [t*per, (t+1)*per); prefix sums in fp64.
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += NT) m = fmaxf(m, l[i]);
+    m = block_max(m, red);
+    const int per = (V + NT - 1) / NT;
+    const int i0 = tid * per, i1 = min(V, i0 + per);
+    double loc = 0.0;
+    for (int i = i0; i < i1; ++i) {
+        float e = (i == p.ban_token) ? 0.f : __expf(l[i] - m);
+        loc += (double)e;
+    }
+    // exclusive scan of `loc` over threads: inclusive wave scan + wave bases
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(inc, o);
+        if ((tid & 63) >= o) inc += t;
+    }
+    if ((tid & 63) == 63) redd[tid >> 6] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int w = 0; w < NT / 64; ++w) {
+            wave_base[w] = run;
+            run += redd[w];
+        }
+        redd[0] = run;  // total
+        chosen = -1;
+    }
+    __syncthreads();
+    const double total = redd[0];
+    const double excl = wave_base[tid >> 6] + inc - loc;
+    const double target = (double)p.uniforms[(long)b * p.max_steps + step] * total;
+    if (loc > 0.0 && target >= excl && target < excl + loc) {
+        double run = excl;
+        int pick = -1;
+        for (int i = i0; i < i1; ++i) {
+            float e = (i == p.ban_token) ? 0.f : __expf(l[i] - m);
+            if (e > 0.f) {
+                pick = i;
+                run += (double)e;
+                if (run > target) break;
+            }
+        }
+        chosen = pick;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tok = chosen;
+        if (tok < 0) {  // numerical corner (target == total): last id with non-zero probability
+            for (int i = V - 1; i >= 0; --i)
+                if (i != p.ban_token && l[i] > -INFINITY) { tok = i; break; }
+        }
+        p.out_tokens[(long)b * p.max_steps + step] = tok;
+        seen[tok] = 1;
+        p.step[b] = step + 1;
+        p.n_generated[b] = step + 1;
+        if (tok == p.eos_token) p.done[b] = 1;
+        const int nrep = p.cfg ? 2 : 1;
+        for (int r = 0; r < nrep; ++r) {
+            const int row = b + r * p.B;
+            if (p.next_ids) p.next_ids[row] = tok;
+            if (p.next_pos_ids) p.next_pos_ids[row] = step + 1;
+            if (p.positions) p.positions[row] += 1;
+            if (p.ctx_lens) p.ctx_lens[row] += 1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cbx_t3_sample(const cbx_sampler_t* p, void* stream) {
+    CBX_REQUIRE(p && p->logits && p->seen && p->uniforms && p->step && p->out_tokens && p->done && p->n_generated,
+                "t3_sample: null operand");
+    CBX_REQUIRE(p->V > 0 && p->V <= MAXV, "t3_sample: V=%d exceeds %d", p->V, MAXV);
+    hipLaunchKernelGGL(t3_sample_kernel, dim3(p->B), dim3(NT), 0, (hipStream_t)stream, *p);
+    return cbx_check_launch("t3_sample");
+}

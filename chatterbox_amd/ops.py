@@ -1,0 +1,199 @@
+"""Thin Python wrappers that hand raw device pointers of torch tensors + the current HIP stream to the C ABI.
+
+torch is used only as the allocator / stream provider; every function below launches hand-written gfx950 kernels
+from libcbx_hip.so and raises if the library is unavailable (no eager fallback).
+"""
+import ctypes
+
+import torch
+
+from ._lib import GemmParams, SamplerParams, check, lib
+
+NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    assert t.dtype == torch.float32 and t.is_cuda, f"{name}: expected a CUDA fp32 tensor, got {t.dtype} on {t.device}"
+    return t
+
+
+def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, ldc2=0, act1=NONE, act2=NONE,
+         act1_param=None, act2_param=None, act1_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, lens=None, Cin=0, taps=1,
+         dil=1, stride=1, pad_left=0, up=1, Tin=0, nz1=1, nz2=1, a_s=(0, 0), w_s=(0, 0), c_s=(0, 0), r_s=(0, 0),
+         c2_s=(0, 0), w_kn=False, swiglu=False):
+    """Raw access to cbx_gemm_f32 (see include/cbx.h).  A/W/C... are tensors (their data_ptr() is the base)."""
+    p = GemmParams()
+    p.A, p.W, p.C = _p(_f32(A, "A")), _p(_f32(W, "W")), _p(_f32(C, "C"))
+    p.bias, p.R, p.C2 = _p(bias), _p(R), _p(C2)
+    p.act1_param, p.act2_param, p.lens = _p(act1_param), _p(act2_param), _p(lens)
+    if lens is not None:
+        assert lens.dtype == torch.int32
+    p.M, p.N, p.K = M, N, K
+    p.Cin, p.taps, p.dil, p.stride, p.pad_left, p.up, p.Tin = Cin or (K // taps), taps, dil, stride, pad_left, up, Tin
+    p.nz1, p.nz2, p.w_kn, p.swiglu = nz1, nz2, int(w_kn), int(swiglu)
+    p.act1, p.act2, p.act1_slope, p.act2_slope, p.alpha, p.beta = act1, act2, act1_slope, act2_slope, alpha, beta
+    p.lda, p.a_s1, p.a_s2 = lda, a_s[0], a_s[1]
+    p.ldw, p.w_s1, p.w_s2 = ldw, w_s[0], w_s[1]
+    p.ldc, p.c_s1, p.c_s2 = ldc, c_s[0], c_s[1]
+    p.ldr, p.r_s1, p.r_s2 = ldr, r_s[0], r_s[1]
+    p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
+    check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32")
+    return C
+
+
+def linear(x, w, out, bias=None, act=NONE, residual=None, out2=None, act2=NONE, act_param=None, act2_param=None,
+           act_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, swiglu=False):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T).  x/out/residual are 2-D views with unit inner stride."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.stride(1) == 1 and out.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    return gemm(x, w, out, M=M, N=N, K=K, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias, R=residual,
+                ldr=0 if residual is None else residual.stride(0), C2=out2, ldc2=0 if out2 is None else out2.stride(0),
+                act1=act, act2=act2, act1_param=act_param, act2_param=act2_param, act1_slope=act_slope,
+                act2_slope=act2_slope, alpha=alpha, beta=beta, swiglu=swiglu)
+
+
+def conv1d(x, w, out, *, taps, cin, bias=None, dil=1, stride=1, pad_left=0, up=1, lens=None, act=NONE, residual=None,
+           out2=None, act2=NONE, act_param=None, act2_param=None, act_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0,
+           t_in=None):
+    """Channel-last conv1d as implicit GEMM.  x (B,Tin,>=cin), w packed (N, taps*cin), out (B,Tout,N)."""
+    B, Tin = x.shape[0], (t_in if t_in is not None else x.shape[1])
+    Tout, N = out.shape[1], w.shape[0]
+    assert x.stride(2) == 1 and out.stride(2) == 1 and w.shape[1] == taps * cin
+    return gemm(x, w, out, M=Tout, N=N, K=taps * cin, Cin=cin, taps=taps, dil=dil, stride=stride, pad_left=pad_left, up=up,
+                Tin=Tin, lens=lens, lda=x.stride(1), ldw=w.stride(0), ldc=out.stride(1), nz1=B, a_s=(x.stride(0), 0),
+                c_s=(out.stride(0), 0), bias=bias, R=residual, ldr=0 if residual is None else residual.stride(1),
+                r_s=(0 if residual is None else residual.stride(0), 0), C2=out2,
+                ldc2=0 if out2 is None else out2.stride(1), c2_s=(0 if out2 is None else out2.stride(0), 0), act1=act,
+                act2=act2, act1_param=act_param, act2_param=act2_param, act1_slope=act_slope, act2_slope=act2_slope,
+                alpha=alpha, beta=beta)
+
+
+def bmm(a, b, out, *, nn=False, alpha=1.0):
+    """Two-level batched matmul on 4-D strided views (Z1, Z2, M, K):  out = a @ b^T (b: Z1,Z2,N,K) or, with nn=True,
+    out = a @ b (b: Z1,Z2,K,N)."""
+    Z1, Z2, M, K = a.shape
+    N = b.shape[3] if nn else b.shape[2]
+    assert a.stride(3) == 1 and b.stride(3) == 1 and out.stride(3) == 1
+    return gemm(a, b, out, M=M, N=N, K=K, lda=a.stride(2), ldw=b.stride(2), ldc=out.stride(2), nz1=Z1, nz2=Z2,
+                a_s=(a.stride(0), a.stride(1)), w_s=(b.stride(0), b.stride(1)), c_s=(out.stride(0), out.stride(1)),
+                w_kn=nn, alpha=alpha)
+
+
+def layernorm(x, w, b, out, eps=1e-5, rms=False, act=NONE, post_add=None, scale=1.0):
+    rows, C = x.shape
+    assert x.stride(1) == 1 and out.stride(1) == 1
+    check(lib.cbx_layernorm_f32(_p(x), _p(out), _p(w), _p(b), _p(post_add), rows, C, x.stride(0), out.stride(0), eps,
+                                int(rms), act, scale, _stream()), "cbx_layernorm_f32")
+    return out
+
+
+def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
+    """q (Z,Tq,H,64), k/v (Z,Tk,H,64), out (Z,Tq,H,64): strided views with head stride 64, unit inner stride."""
+    Z, Tq, H, D = q.shape
+    Tk = k.shape[1]
+    assert D == 64
+    for t in (q, k, v, out):
+        assert t.stride(3) == 1 and t.stride(2) == 64
+    check(lib.cbx_flash_attn_f32(_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1),
+                                 k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale,
+                                 int(causal), _stream()), "cbx_flash_attn_f32")
+    return out
+
+
+def decode_attn(q, kc, vc, out, ctx_lens, scale):
+    """q/out (rows, H*64) views; kc/vc (rows, H, max_pos, 64) contiguous caches; ctx_lens int32 (rows,)."""
+    rows, H = kc.shape[0], kc.shape[1]
+    check(lib.cbx_decode_attn_f32(_p(q), _p(kc), _p(vc), _p(out), _p(ctx_lens), rows, H, q.stride(0), out.stride(0),
+                                  kc.stride(0), kc.stride(1), scale, _stream()), "cbx_decode_attn_f32")
+    return out
+
+
+def softmax_relpos(ac, bd, p, scale, key_lens=None):
+    """ac (Z1,Z2,Tq,>=Tk), bd (Z1,Z2,Tq,>=2Tk-1) or None, p (Z1,Z2,Tq,ld_p) (pad columns written as 0)."""
+    Z1, Z2, Tq = ac.shape[:3]
+    Tk = Tq
+    assert ac.is_contiguous() or ac.stride(3) == 1
+    check(lib.cbx_softmax_relpos_f32(_p(ac), _p(bd), _p(p), _p(key_lens), Z1, Z2, Tq, Tk, ac.stride(2),
+                                     0 if bd is None else bd.stride(2), p.stride(2), ac.stride(1),
+                                     0 if bd is None else bd.stride(1), p.stride(1), scale, _stream()),
+          "cbx_softmax_relpos_f32")
+    return p
+
+
+def softmax_rows(s, p, scale, n_keys, key_lens=None):
+    """Plain row softmax of s (Z1,Z2,Tq,>=n_keys) into p (pad columns zeroed): perceiver attention."""
+    Z1, Z2, Tq = s.shape[:3]
+    check(lib.cbx_softmax_relpos_f32(_p(s), None, _p(p), _p(key_lens), Z1, Z2, Tq, n_keys, s.stride(2), 0, p.stride(2),
+                                     s.stride(1), 0, p.stride(1), scale, _stream()), "cbx_softmax_relpos_f32")
+    return p
+
+
+def act(x, out, kind, param=None, slope=0.0):
+    rows, C = x.shape
+    check(lib.cbx_act_f32(_p(x), _p(out), _p(param), rows, C, x.stride(0), out.stride(0), kind, slope, _stream()), "cbx_act_f32")
+    return out
+
+
+def axpby(x, y, a=1.0, b=0.0):
+    """y = a*x + b*y on 2-D strided views."""
+    rows, C = x.shape
+    assert x.stride(1) == 1 and y.stride(1) == 1
+    check(lib.cbx_axpby_f32(_p(x), _p(y), rows, C, x.stride(0), y.stride(0), a, b, _stream()), "cbx_axpby_f32")
+    return y
+
+
+def embed(ids, table, out, table2=None, ids2=None, scale=1.0):
+    rows, C = out.shape
+    assert ids.dtype == torch.int64 and (ids2 is None or ids2.dtype == torch.int32)
+    check(lib.cbx_embed_f32(_p(ids), _p(table), _p(table2), _p(ids2), _p(out), rows, C, out.stride(0), scale, 1, _stream()),
+          "cbx_embed_f32")
+    return out
+
+
+def rope_kv(qkv, positions, cos_t, sin_t, kc, vc, n_heads, cache_rows=None):
+    """In-place RoPE on the q,k parts of qkv (rows, 3*H*64) + append k,v at `positions` into caches (rows,H,max,64)."""
+    n_rows = qkv.shape[0]
+    check(lib.cbx_rope_kv_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(cache_rows), n_rows, n_heads,
+                              qkv.stride(0), 0 if kc is None else kc.stride(0), 0 if kc is None else kc.stride(1),
+                              _stream()), "cbx_rope_kv_f32")
+
+
+def cfm_euler(xin, v, B, T, C, dt, w, cfg=True):
+    """xin (rows,T,ld) packed estimator input whose first C columns are x; v (rows,T,C)."""
+    check(lib.cbx_cfm_euler_f32(_p(xin), _p(v), B, T, C, xin.stride(1), v.stride(1), xin.stride(0), v.stride(0), dt, w,
+                                int(cfg), _stream()), "cbx_cfm_euler_f32")
+
+
+def t3_sample(**kw):
+    p = SamplerParams()
+    for k, val in kw.items():
+        setattr(p, k, _p(val) if torch.is_tensor(val) else val)
+    check(lib.cbx_t3_sample(ctypes.byref(p), _stream()), "cbx_t3_sample")
+
+
+def hift_source(f0, phase, noise, lin_w, lin_b, s, frame_cum, up=480, sr=24000.0):
+    B, T = f0.shape
+    check(lib.cbx_hift_source_f32(_p(f0), _p(phase), _p(noise), _p(lin_w), float(lin_b), _p(s), _p(frame_cum), B, T, up, sr,
+                                  _stream()), "cbx_hift_source_f32")
+    return s
+
+
+def hift_stft(s, spec):
+    B, L = s.shape
+    check(lib.cbx_hift_stft_f32(_p(s), _p(spec), B, L, spec.stride(1), _stream()), "cbx_hift_stft_f32")
+    return spec
+
+
+def hift_istft(x, wav, clamp=0.99, fade_n=0):
+    B, frames = x.shape[0], x.shape[1]
+    check(lib.cbx_hift_istft_f32(_p(x), _p(wav), B, frames, x.stride(1), clamp, fade_n, _stream()), "cbx_hift_istft_f32")
+    return wav

@@ -1,0 +1,143 @@
+/* cbx.h -- C ABI of libcbx_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the Chatterbox hot path
+ * generate() = T3.inference -> S3Gen.flow_inference -> HiFT.inference.
+ *
+ * The reference (resemble-ai/chatterbox) has no FFI: its numerical layer is PyTorch ATen + HF transformers +
+ * diffusers called from Python.  Each entry point below replaces the ATen/HF op group that the cited reference
+ * lines dispatch; INTEGRATION.md shows the ctypes binding.  Conventions:
+ *   - plain C types only; every pointer is a DEVICE pointer valid on `stream` (a hipStream_t passed as void*);
+ *   - all tensors fp32 row-major "channel-last" (rows = time/tokens, columns = channels) unless stated;
+ *   - the callee never allocates, never synchronises, and is hipGraph-capturable;
+ *   - return 0 on success, else a negative CBX_E* / positive hipError_t; cbx_last_error() gives text.
+ */
+#ifndef CBX_H
+#define CBX_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBX_ABI_VERSION 1
+#define CBX_EINVAL (-22)
+
+/* activations usable in GEMM / elementwise epilogues */
+enum { CBX_ACT_NONE = 0, CBX_ACT_SILU = 1, CBX_ACT_GELU_ERF = 2, CBX_ACT_GELU_TANH = 3, CBX_ACT_MISH = 4,
+       CBX_ACT_LRELU = 5, CBX_ACT_ELU = 6, CBX_ACT_TANH = 7, CBX_ACT_SNAKE = 8, CBX_ACT_ABS = 9 };
+
+int cbx_abi_version(void);
+const char* cbx_last_error(void);
+
+/* ---- implicit-GEMM linear / conv1d / batched matmul on fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32) ----
+ * C[z][m][n] = beta*C + alpha*( act1( sum_{tap,c} A[z][ (m*stride + tap*dil - pad_left)/up ][c] * W[z][n][tap*Cin+c]
+ *                                      + bias[n] ) + R[z][m][n] ),      C2 = act2(C)   (optional)
+ * Replaces F.linear / F.conv1d / F.conv_transpose1d (phase-packed weights) / torch.matmul on:
+ *   HF LlamaAttention/LlamaMLP projections (models/t3/t3.py:326-333,378-384), CFM estimator convs and
+ *   transformer-block linears (models/s3gen/decoder.py:243-333, matcha/transformer.py:243-316), conformer
+ *   encoder linears/convs (transformer/upsample_encoder.py:237-304), HiFT convs (hifigan.py:412-444).
+ * z = z1*nz2 + z2 (two-level batch: e.g. utterance row, attention head).
+ */
+typedef struct cbx_gemm_t {
+    const float* A; const float* W; float* C;
+    const float* bias;        /* [N] or NULL */
+    const float* R;           /* residual, or NULL */
+    float* C2;                /* second output act2(C), or NULL */
+    const float* act1_param;  /* per-column parameter of act1 (snake alpha) or NULL */
+    const float* act2_param;
+    const int* lens;          /* per-z1 number of valid INPUT rows (rows >= lens read as 0), or NULL */
+    int M, N, K;              /* output rows per batch, output columns, K = taps*Cin */
+    int Cin, taps, dil, stride, pad_left, up, Tin;
+    int nz1, nz2;
+    int w_kn;                 /* 0: W is [N][K] (torch Linear layout); 1: W is [K][N] (e.g. P @ V) */
+    int swiglu;               /* 1: packed [32 gate | 32 up] column groups -> C[m][N/2] = silu(gate)*up */
+    int act1, act2;
+    float act1_slope, act2_slope, alpha, beta;
+    long lda, a_s1, a_s2;     /* strides in floats */
+    long ldw, w_s1, w_s2;
+    long ldc, c_s1, c_s2;
+    long ldr, r_s1, r_s2;
+    long ldc2, c2_s1, c2_s2;
+} cbx_gemm_t;
+int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
+
+/* ---- normalisation (wavefront reductions, one wave per row) ----
+ * LayerNorm / RMSNorm over the last dim (C <= 4096, C % 4 == 0):
+ *   y = act( (x-mean)*rstd*w + b ) [+ post_add[c]] [* rowmask]            (nn.LayerNorm, HF LlamaRMSNorm)
+ * Replaces F.layer_norm (+Mish of CausalBlock1D, decoder.py:49-63) and LlamaRMSNorm. */
+int cbx_layernorm_f32(const float* x, float* y, const float* w, const float* b, const float* post_add,
+                      long rows, int C, long ldx, long ldy, float eps, int rms, int act, float out_scale,
+                      void* stream);
+
+/* ---- attention ----
+ * Flash-style fp32 attention, head_dim 64: O = softmax(scale*Q K^T + mask) V, one (z1,head) per grid.y slice.
+ * q/k/v/o are addressed as base + z1*s_b + t*s_t + head*64 (+ kv: s_kb/s_kt). key_lens[z1] masks keys >= len
+ * (diffusers additive -1e10 bias, decoder.py:26-34,285-286); causal!=0 adds j<=i+causal_off (HF sdpa is_causal).
+ * Replaces F.scaled_dot_product_attention in diffusers AttnProcessor2_0 and HF sdpa_attention_forward. */
+int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
+                       int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                       long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, void* stream);
+
+/* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).
+ * cache layout [row][head][pos][64]; ctx_lens[row] = number of valid positions (including the new token). */
+int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float* o, const int* ctx_lens,
+                        int rows, int n_heads, long q_ld, long o_ld, long cache_row_stride, long cache_head_stride,
+                        float scale, void* stream);
+
+/* Row softmax over materialised scores with optional relative-position term and key mask
+ * (RelPositionMultiHeadedAttention.forward, transformer/attention.py:249-330):
+ *   p[z][i][j] = softmax_j( scale*(ac[z][i][j] + bd[z][i][T-1-i+j]) ), keys j >= key_lens[z1] -> 0. */
+int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int* key_lens, int nz1, int nz2,
+                           int Tq, int Tk, long ld_ac, long ld_bd, long ld_p, long zs_ac, long zs_bd, long zs_p,
+                           float scale, void* stream);
+
+/* ---- elementwise / glue ---- */
+/* y[r][c] = act(x[r][c]) (per-column param for snake), 2-D strided. */
+int cbx_act_f32(const float* x, float* y, const float* param, long rows, int C, long ldx, long ldy, int act,
+                float slope, void* stream);
+/* generic 2-D strided copy / scale-add: y = a*x + b*y */
+int cbx_axpby_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, float a, float b, void* stream);
+/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2 ? ids2[r] : pos0+r%period][:]]   (nn.Embedding gathers) */
+int cbx_embed_f32(const long long* ids, const float* table, const float* table2, const int* ids2, float* out,
+                  long rows, int C, long ld_out, float scale, int zero_if_neg, void* stream);
+/* RoPE (HF apply_rotary_pos_emb, rotate_half form) on q,k rows of a fused qkv buffer + KV-cache append.
+ * positions[r] gives the absolute position of row r; cos/sin tables are [max_pos][64] (cat(freqs,freqs)). */
+int cbx_rope_kv_f32(float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc, float* vc,
+                    const int* cache_rows, long n_rows, int n_heads, long ld_qkv, long cache_row_stride,
+                    long cache_head_stride, void* stream);
+/* CFM Euler + CFG update (flow_matching.py:125-141): x += dt*((1+w)*v[b] - w*v[B+b]) written to both row sets. */
+int cbx_cfm_euler_f32(float* xin, const float* v, int B, long T, int C, long ld_x, long ld_v, long xs_b, long vs_b,
+                      float dt, float w, int cfg, void* stream);
+
+/* ---- T3 sampler (t3.py:339-368 + HF logits processors): one workgroup per utterance ---- */
+typedef struct cbx_sampler_t {
+    const float* logits;       /* [2*B][ld] rows b (cond) and B+b (uncond) when cfg, else [B][ld] */
+    long ld; int V; int B; int cfg;
+    float cfg_weight, temperature, min_p, top_p, rep_penalty;
+    int top_k;                 /* 0 = off */
+    int order;                 /* 0: T3.inference (penalty,temperature,min-p,top-p); 1: inference_turbo
+                                  (temperature,top-k,top-p,penalty)  (t3.py:339-356 vs 396-404) */
+    int ban_token;             /* probability forced to 0 (EOS ban for fixed-length runs) or -1 */
+    int eos_token;
+    unsigned char* seen;       /* [B][V] 0/1 map of generated ids (repetition penalty) */
+    const float* uniforms;     /* [B][max_steps] U[0,1): the injected RNG of torch.multinomial */
+    int max_steps;
+    int* step;                 /* [B] step index, incremented */
+    long long* out_tokens;     /* [B][max_steps] */
+    int* done;                 /* [B] set when EOS sampled; finished utterances are skipped */
+    int* n_generated;          /* [B] */
+    long long* next_ids;       /* [rows] id to embed at the next decode step (both CFG rows), or NULL */
+    int* next_pos_ids;         /* [rows] learned speech-position index of the next input (= step+1), or NULL */
+    int* positions;            /* [rows] RoPE / cache position of the next input, incremented, or NULL */
+    int* ctx_lens;             /* [rows] context length of the next decode step, incremented, or NULL */
+} cbx_sampler_t;
+int cbx_t3_sample(const cbx_sampler_t* p, void* stream);
+
+/* ---- HiFT source + (i)STFT (hifigan.py:201-231,267-283,396-410) ---- */
+int cbx_hift_source_f32(const float* f0, const float* phase, const float* noise, const float* lin_w, float lin_b,
+                        float* s, double* frame_cum, int B, int T, int up, float sr, void* stream);
+int cbx_hift_stft_f32(const float* s, float* spec, int B, long L, long ld_spec, void* stream);
+/* x[b][frame][0..8] log-magnitude, [9..17] phase pre-sin (conv_post output); fade_n>0 applies S3Gen trim_fade. */
+int cbx_hift_istft_f32(const float* x, float* wav, int B, long frames, long ldx, float clamp, int fade_n,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+"""Kernel-level parity (-m gpu): every C-ABI op against the CPU oracle / plain torch fp32 on the same seeded inputs.
+
+Tolerances: fp32-exact mode.  GEMM-class ops: |err| <= 2e-5 * (1 + |ref|) * sqrt(K/256) (fp32 accumulation-order
+noise between an fmaf chain and MKL's blocked sgemm); softmax/attention: 2e-5 abs on O(1) outputs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    lim = tol * (1.0 + ref.abs())
+    bad = err > lim
+    assert not bad.any(), f"{what}: max err {err.max():.3e} (ref max {ref.abs().max():.3e}), {int(bad.sum())} / {bad.numel()} over tol {tol}"
+
+
+def _r(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 8, 16), (16, 1024, 1024), (37, 80, 192), (300, 1536, 256), (129, 257, 320), (1000, 64, 1024)])
+def test_linear(dev, M, N, K):
+    from chatterbox_amd import ops
+    x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+    for act, fn in ((ops.NONE, lambda t: t), (ops.SILU, F.silu), (ops.GELU_ERF, F.gelu), (ops.MISH, F.mish),
+                    (ops.GELU_TANH, lambda t: F.gelu(t, approximate="tanh")), (ops.ELU, F.elu)):
+        out = torch.empty(M, N, device=dev)
+        ops.linear(x.to(dev), w.to(dev), out, bias=b.to(dev), act=act, residual=r.to(dev))
+        _close(out, fn(F.linear(x, w, b)) + r, 3e-5 * max(1.0, math.sqrt(K / 256)), f"linear act={act}")
+
+
+def test_linear_strided_accumulate_and_second_output(dev):
+    from chatterbox_amd import ops
+    M, N, K = 200, 96, 64
+    xb, w = _r((M, K + 8), 1), _r((N, K), 2, 0.1)
+    alpha_p = 1.0 + 0.2 * _r((N,), 5)
+    cb = _r((M, N + 4), 6)
+    out, out2 = cb.clone().to(dev), torch.empty(M, N, device=dev)
+    ops.linear(xb.to(dev)[:, :K], w.to(dev), out[:, :N], alpha=1.0 / 3, beta=1.0, out2=out2, act2=ops.SNAKE,
+               act2_param=alpha_p.to(dev))
+    ref = cb[:, :N] + F.linear(xb[:, :K], w) / 3
+    _close(out[:, :N], ref, 3e-5, "accumulate")
+    _close(out[:, N:], cb[:, N:], 0.0, "untouched pad")
+    a = alpha_p[None]
+    _close(out2, ref + (1.0 / (a + 1e-9)) * torch.sin(ref * a) ** 2, 5e-5, "snake second output")
+
+
+def test_swiglu(dev):
+    from chatterbox_amd import ops, weights
+    for M in (16, 200):
+        D, Fh = 256, 512
+        x, g, u = _r((M, D), 1), _r((Fh, D), 2, 0.06), _r((Fh, D), 3, 0.06)
+        out = torch.empty(M, Fh, device=dev)
+        ops.linear(x.to(dev), weights.pack_swiglu(g, u).to(dev), out, swiglu=True)
+        _close(out, F.silu(F.linear(x, g)) * F.linear(x, u), 3e-5, "swiglu")
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,stride,pad,T", [(32, 48, 3, 1, 1, 1, 77), (80, 512, 7, 1, 1, 3, 60), (64, 64, 11, 5, 1, 25, 300),
+                                                         (32, 256, 30, 1, 15, 7, 1201), (32, 128, 6, 1, 3, 1, 241), (320, 256, 3, 1, 1, 2, 100)])
+def test_conv1d(dev, cin, cout, k, dil, stride, pad, T):
+    from chatterbox_amd import ops, weights
+    B = 3
+    x, w, b = _r((B, cin, T), 1), _r((cout, cin, k), 2, 1 / math.sqrt(cin * k)), _r((cout,), 3)
+    causal = (pad == k - 1 and dil == 1 and cin == 320)
+    ref = F.conv1d(F.pad(x, (pad, 0)) if causal else x, w, b, stride=stride, dilation=dil, padding=0 if causal else pad)
+    Tout = ref.shape[2]
+    out = torch.empty(B, Tout, cout, device=dev)
+    ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w).to(dev), out, taps=k, cin=cin, bias=b.to(dev),
+               dil=dil, stride=stride, pad_left=pad)
+    _close(out.transpose(1, 2), ref, 4e-5, "conv1d")
+
+
+def test_conv1d_ragged_and_upsample(dev):
+    from chatterbox_amd import ops, weights
+    B, C, T = 3, 32, 50
+    lens = torch.tensor([50, 31, 7], dtype=torch.int32)
+    x, w, b = _r((B, C, T), 1), _r((C, C, 4), 2, 0.1), _r((C,), 3)
+    out = torch.empty(B, T, C, device=dev)
+    # look-ahead conv (right pad 3) must see zeros beyond each row's own length
+    ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w).to(dev), out, taps=4, cin=C, bias=b.to(dev),
+               pad_left=0, lens=lens.to(dev))
+    for i in range(B):
+        n = int(lens[i])
+        ref = F.conv1d(F.pad(x[i:i + 1, :, :n], (0, 3)), w, b)
+        _close(out[i, :n].t(), ref[0], 3e-5, f"ragged row {i}")
+    # nearest x2 upsample + left pad 4 + k5 (Upsample1D of the conformer encoder)
+    w5 = _r((C, C, 5), 4, 0.1)
+    ref = F.conv1d(F.pad(x.repeat_interleave(2, dim=2), (4, 0)), w5, b)
+    out = torch.empty(B, 2 * T, C, device=dev)
+    ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w5).to(dev), out, taps=5, cin=C, bias=b.to(dev),
+               pad_left=4, up=2)
+    _close(out.transpose(1, 2), ref, 3e-5, "upsample conv")
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p", [(64, 32, 16, 8, 4), (32, 16, 11, 5, 3), (32, 64, 7, 3, 2)])
+def test_conv_transpose(dev, cin, cout, k, s, p):
+    from chatterbox_amd import ops, weights
+    B, T = 2, 41
+    x, w, b = _r((B, cin, T), 1), _r((cin, cout, k), 2, 0.1), _r((cout,), 3)
+    ref = F.conv_transpose1d(x, w, b, stride=s, padding=p)
+    wp, bp = weights.pack_conv_transpose(w, b, s, p)
+    out = torch.empty(B, T, s * cout, device=dev)
+    ops.conv1d(x.transpose(1, 2).contiguous().to(dev), wp.to(dev), out, taps=3, cin=cin, bias=bp.to(dev), pad_left=1)
+    _close(out.view(B, T * s, cout).transpose(1, 2), ref, 3e-5, "conv_transpose")
+
+
+def test_bmm(dev):
+    from chatterbox_amd import ops
+    Z1, Z2, M, K, N = 2, 3, 150, 64, 149
+    a, b = _r((Z1, M, Z2, K), 1), _r((Z1, N, Z2, K), 2)
+    out = torch.empty(Z1, Z2, M, 152, device=dev)
+    ops.bmm(a.to(dev).permute(0, 2, 1, 3), b.to(dev).permute(0, 2, 1, 3), out[..., :N])
+    _close(out[..., :N], torch.einsum("zmhk,znhk->zhmn", a, b), 3e-5, "bmm nt")
+    # nn: P (Z1,Z2,M,Kp) @ V (Z1,Z2,Kp,64) with Kp = 150 (not a multiple of 16), V strided
+    pr, v = _r((Z1, Z2, M, 152), 3), _r((Z1, 150, Z2, 64), 4)
+    pr[..., 150:] = 0
+    o = torch.empty(Z1, M, Z2, 64, device=dev)
+    ops.bmm(pr.to(dev)[..., :150], v.to(dev).permute(0, 2, 1, 3), o.permute(0, 2, 1, 3), nn=True)
+    _close(o, torch.einsum("zhmk,zkhd->zmhd", pr[..., :150], v), 3e-5, "bmm nn")
+
+
+def test_layernorm_rmsnorm(dev):
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    for C, eps in ((256, 1e-5), (512, 1e-12), (1024, 1e-5), (80, 1e-5)):
+        x, w, b, pa = _r((333, C), 1, 3.0) + 0.5, 1 + 0.1 * _r((C,), 2), 0.1 * _r((C,), 3), _r((C,), 4)
+        out = torch.empty(333, C, device=dev)
+        ops.layernorm(x.to(dev), w.to(dev), b.to(dev), out, eps)
+        _close(out, F.layer_norm(x, (C,), w, b, eps), 2e-5, "layernorm")
+        ops.layernorm(x.to(dev), w.to(dev), b.to(dev), out, eps, act=ops.MISH, post_add=pa.to(dev))
+        _close(out, F.mish(F.layer_norm(x, (C,), w, b, eps)) + pa, 2e-5, "layernorm+mish+add")
+        ops.layernorm(x.to(dev), w.to(dev), None, out, 1e-5, rms=True)
+        _close(out, O.rms_norm(x, w), 2e-5, "rmsnorm")
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(200, 200, False), (1000, 1000, False), (103, 103, True), (64, 64, True), (130, 130, False)])
+def test_flash_attn(dev, Tq, Tk, causal):
+    from chatterbox_amd import ops
+    Z, H = 3, 4
+    qkv = _r((Z, Tq, 3, H, 64), 1)
+    lens = torch.tensor([Tk, max(1, Tk - 37), max(1, Tk // 3)], dtype=torch.int32)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    if causal:
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        kl = None
+    else:
+        bias = torch.zeros(Z, 1, 1, Tk)
+        for z in range(Z):
+            bias[z, ..., int(lens[z]):] = -1e10
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
+        kl = lens.to(dev)
+    d = qkv.to(dev)
+    out = torch.empty(Z, Tq, H, 64, device=dev)
+    ops.flash_attn(d[:, :, 0], d[:, :, 1], d[:, :, 2], out, 0.125, key_lens=kl, causal=causal)
+    _close(out, ref.transpose(1, 2), 2e-5, "flash_attn")
+
+
+def test_decode_attn(dev):
+    from chatterbox_amd import ops
+    rows, H, maxp = 6, 16, 700
+    kc, vc, q = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2), _r((rows, H * 64), 3)
+    ctx = torch.tensor([1, 5, 64, 129, 333, 700], dtype=torch.int32)
+    out = torch.empty(rows, H * 64, device=dev)
+    ops.decode_attn(q.to(dev), kc.to(dev), vc.to(dev), out, ctx.to(dev), 0.125)
+    for r in range(rows):
+        n = int(ctx[r])
+        ref = F.scaled_dot_product_attention(q[r].view(H, 1, 64), kc[r, :, :n], vc[r, :, :n])
+        _close(out[r].view(H, 64), ref[:, 0], 2e-5, f"decode_attn row {r}")
+
+
+def test_softmax_relpos(dev):
+    from chatterbox_amd import ops
+    Z1, Z2, T = 2, 8, 75
+    ac, bd = _r((Z1, Z2, T, T), 1, 3.0), _r((Z1, Z2, T, 2 * T - 1), 2, 3.0)
+    lens = torch.tensor([T, 40], dtype=torch.int32)
+    p = torch.full((Z1, Z2, T, 76), 7.0, device=dev)
+    ops.softmax_relpos(ac.to(dev), bd.to(dev), p, 0.125, key_lens=lens.to(dev))
+    idx = T - 1 - torch.arange(T)[:, None] + torch.arange(T)[None]
+    sc = (ac + torch.gather(bd, 3, idx.expand(Z1, Z2, T, T))) / 8
+    m = torch.arange(T)[None, :] >= lens[:, None]
+    ref = torch.softmax(sc.masked_fill(m[:, None, None], float("-inf")), -1).masked_fill(m[:, None, None], 0)
+    _close(p[..., :T], ref, 1e-5, "softmax_relpos")
+    assert float(p[..., T:].abs().max()) == 0.0
+
+
+def test_rope_and_kv_append(dev):
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    rows, H, maxp = 5, 16, 64
+    qkv = _r((rows, 3 * H * 64), 1)
+    pos = torch.tensor([0, 3, 17, 40, 63], dtype=torch.int32)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    kc, vc = torch.zeros(rows, H, maxp, 64, device=dev), torch.zeros(rows, H, maxp, 64, device=dev)
+    d = qkv.clone().to(dev)
+    ops.rope_kv(d, pos.to(dev), cos.to(dev), sin.to(dev), kc, vc, H)
+    q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
+    c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
+    qr, kr = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
+    _close(d.view(rows, 3, H, 64)[:, 0], qr, 1e-6, "rope q")
+    _close(d.view(rows, 3, H, 64)[:, 1], kr, 1e-6, "rope k")
+    for r in range(rows):
+        _close(kc[r, :, int(pos[r])], kr[r], 1e-6, "k cache")
+        _close(vc[r, :, int(pos[r])], v[r], 0.0, "v cache")
+
+
+def test_elementwise(dev):
+    from chatterbox_amd import ops
+    x, a = _r((100, 64), 1, 2.0), 1 + 0.2 * _r((64,), 2)
+    out = torch.empty(100, 64, device=dev)
+    ops.act(x.to(dev), out, ops.SNAKE, param=a.to(dev))
+    _close(out, x + (1 / (a + 1e-9)) * torch.sin(x * a) ** 2, 3e-6, "snake")
+    ops.act(x.to(dev), out, ops.LRELU, slope=0.1)
+    _close(out, F.leaky_relu(x, 0.1), 0.0, "lrelu")
+    tab, tab2 = _r((50, 64), 3), _r((20, 64), 4)
+    ids, ids2 = torch.tensor([3, 49, 0, 7], dtype=torch.int64), torch.tensor([0, 1, 19, 5], dtype=torch.int32)
+    o = torch.empty(4, 64, device=dev)
+    ops.embed(ids.to(dev), tab.to(dev), o, table2=tab2.to(dev), ids2=ids2.to(dev))
+    _close(o, tab[ids] + tab2[ids2.long()], 0.0, "embed")
+    # CFM Euler + CFG on the packed estimator input
+    B, T = 2, 33
+    xin, v = _r((2 * B, T, 320), 5), _r((2 * B, T, 80), 6)
+    dx = xin.clone().to(dev)
+    ops.cfm_euler(dx, v.to(dev), B, T, 80, 0.07, 0.7)
+    xn = xin[:B, :, :80] + 0.07 * (1.7 * v[:B] - 0.7 * v[B:])
+    _close(dx[:B, :, :80], xn, 2e-6, "euler cond rows")
+    _close(dx[B:, :, :80], xn, 2e-6, "euler uncond rows")
+    _close(dx[:, :, 80:], xin[:, :, 80:], 0.0, "euler leaves mu/spk/cond")
+
+
+@pytest.mark.parametrize("top_p,min_p", [(1.0, 0.05), (0.9, 0.0), (0.8, 0.05)])
+def test_sampler(dev, top_p, min_p):
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    B, V, steps = 3, 8194, 6
+    logits = _r((steps, 2 * B, V), 1, 2.0)
+    u = torch.rand(B, steps, generator=torch.Generator().manual_seed(5))
+    d = dict(seen=torch.zeros(B, V, dtype=torch.uint8, device=dev), step=torch.zeros(B, dtype=torch.int32, device=dev),
+             out_tokens=torch.zeros(B, steps, dtype=torch.int64, device=dev), done=torch.zeros(B, dtype=torch.int32, device=dev),
+             n_generated=torch.zeros(B, dtype=torch.int32, device=dev), next_ids=torch.zeros(2 * B, dtype=torch.int64, device=dev),
+             next_pos_ids=torch.zeros(2 * B, dtype=torch.int32, device=dev), positions=torch.full((2 * B,), 9, dtype=torch.int32, device=dev),
+             ctx_lens=torch.full((2 * B,), 10, dtype=torch.int32, device=dev))
+    d["seen"][:, O.START_SPEECH] = 1
+    ud = u.to(dev)
+    gen = [[O.START_SPEECH] for _ in range(B)]
+    for s in range(steps):
+        ld = logits[s].to(dev)
+        ops.t3_sample(logits=ld, ld=V, V=V, B=B, cfg=1, cfg_weight=0.5, temperature=0.8, min_p=min_p, top_p=top_p,
+                      rep_penalty=1.2, top_k=0, order=0, ban_token=O.STOP_SPEECH, eos_token=O.STOP_SPEECH, uniforms=ud,
+                      max_steps=steps, **d)
+        toks = d["out_tokens"][:, s].cpu()
+        for b in range(B):
+            l = O.process_logits(logits[s, b], logits[s, B + b], torch.tensor(gen[b]), 0.5, 0.8, min_p, top_p, 1.2)
+            pr = torch.softmax(l, -1)
+            pr[O.STOP_SPEECH] = 0
+            ref = O.sample_inverse_cdf(pr, u[b, s])
+            assert int(toks[b]) == ref, f"step {s} utt {b}: got {int(toks[b])} want {ref}"
+            gen[b].append(ref)
+    assert d["positions"].tolist() == [9 + steps] * (2 * B) and d["ctx_lens"].tolist() == [10 + steps] * (2 * B)
+    assert d["next_pos_ids"].tolist() == [steps] * (2 * B) and d["step"].tolist() == [steps] * B
+
+
+def test_hift_source_stft_istft(dev):
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    B, T = 2, 40
+    f0 = torch.rand(B, T, generator=torch.Generator().manual_seed(1)) * 300
+    f0[:, 5:9] = 3.0  # unvoiced stretch
+    phase = (torch.rand(B, 9, 1, generator=torch.Generator().manual_seed(2)) * 2 - 1) * math.pi
+    phase[:, 0] = 0
+    noise = _r((B, 9, 480 * T), 3)
+    sd = {"mel2wav.m_source.l_linear.weight": _r((1, 9), 4, 0.5), "mel2wav.m_source.l_linear.bias": torch.tensor([0.05])}
+    ref = O.source_module(sd, f0, phase, noise)[:, 0]
+    s = torch.empty(B, 480 * T, device=dev)
+    cum = torch.empty(B, 9, T, dtype=torch.float64, device=dev)
+    ops.hift_source(f0.to(dev), phase.to(dev), noise.to(dev), sd["mel2wav.m_source.l_linear.weight"].to(dev), 0.05, s, cum)
+    _close(s, ref, 2e-5, "hift source")
+    # STFT
+    win = torch.hann_window(16, periodic=True)
+    sp = torch.stft(ref, 16, 4, 16, window=win, return_complex=True)
+    spec = torch.empty(B, 120 * T + 1, 32, device=dev)
+    ops.hift_stft(ref.to(dev), spec)
+    _close(spec[:, :, :9], sp.real.transpose(1, 2), 1e-5, "stft re")
+    _close(spec[:, :, 9:18], sp.imag.transpose(1, 2), 1e-5, "stft im")
+    assert float(spec[:, :, 18:].abs().max()) == 0.0
+    # iSTFT head
+    x = _r((B, 18, 120 * T + 1), 5)
+    x[:, :9] = x[:, :9] * 1.5 - 1.0
+    mag, ph = torch.exp(x[:, :9]).clip(max=1e2), torch.sin(x[:, 9:])
+    wref = torch.istft(torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)), 16, 4, 16, window=win).clamp(-0.99, 0.99)
+    xd = torch.zeros(B, 120 * T + 1, 32, device=dev)
+    xd[:, :, :18] = x.transpose(1, 2).to(dev)
+    wav = torch.empty(B, 480 * T, device=dev)
+    ops.hift_istft(xd, wav)
+    _close(wav, wref, 1e-5, "istft")
+    ops.hift_istft(xd, wav, fade_n=480)
+    _close(wav, O.trim_fade(wref), 1e-5, "istft + trim_fade")

@@ -59,7 +59,7 @@ _SIGS = {
     "cbx_cfm_euler_f32": ([c_f, c_f, c_int, c_long, c_int, c_long, c_long, c_long, c_long, c_float, c_float, c_int, c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
-    "cbx_hift_stft_f32": ([c_f, c_f, c_int, c_long, c_long, c_f], c_int),
+    "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),
     "cbx_hift_istft_f32": ([c_f, c_f, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
 }
 

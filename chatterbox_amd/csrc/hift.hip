@@ -70,18 +70,21 @@ __constant__ float c_hann16[16] = {0.0f, 0.03806023f, 0.14644661f, 0.30865828f, 
                                    1.0f, 0.96193977f, 0.85355339f, 0.69134172f, 0.5f, 0.30865828f, 0.14644661f, 0.03806023f};
 
 // spec[b][t][0..8] = Re, [9..17] = Im, [18..ld) = 0
-__global__ void stft_kernel(const float* __restrict__ s, float* __restrict__ spec, int B, long L, long frames, long ld) {
+__global__ void stft_kernel(const float* __restrict__ s, float* __restrict__ spec, const int* __restrict__ sample_lens, int B,
+                            long L, long frames, long ld) {
     const long total = (long)B * frames;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int b = (int)(i / frames);
         long t = i - (long)b * frames;
         const float* x = s + (long)b * L;
+        const long Lb = sample_lens ? min((long)sample_lens[b], L) : L;  // ragged batch: reflect at the row's own end
         float xw[16];
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             long q = 4 * t + n - 8;  // reflect padding (center=True)
             if (q < 0) q = -q;
-            if (q >= L) q = 2 * (L - 1) - q;
+            if (q >= Lb) q = 2 * (Lb - 1) - q;
+            if (q < 0) q = 0;
             xw[n] = x[q] * c_hann16[n];
         }
         float* o = spec + i * ld;
@@ -173,11 +176,12 @@ extern "C" int cbx_hift_source_f32(const float* f0, const float* phase, const fl
     return cbx_check_launch("hift_source");
 }
 
-extern "C" int cbx_hift_stft_f32(const float* s, float* spec, int B, long L, long ld_spec, void* stream) {
+extern "C" int cbx_hift_stft_f32(const float* s, float* spec, const int* sample_lens, int B, long L, long ld_spec,
+                                 void* stream) {
     CBX_REQUIRE(s && spec && B > 0 && L >= 16 && L % 4 == 0 && ld_spec >= 18, "hift_stft: bad args");
     long frames = L / 4 + 1, total = (long)B * frames;
     unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(stft_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, spec, B, L, frames, ld_spec);
+    hipLaunchKernelGGL(stft_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, spec, sample_lens, B, L, frames, ld_spec);
     return cbx_check_launch("hift_stft");
 }
 

@@ -187,9 +187,9 @@ def hift_source(f0, phase, noise, lin_w, lin_b, s, frame_cum, up=480, sr=24000.0
     return s
 
 
-def hift_stft(s, spec):
+def hift_stft(s, spec, sample_lens=None):
     B, L = s.shape
-    check(lib.cbx_hift_stft_f32(_p(s), _p(spec), B, L, spec.stride(1), _stream()), "cbx_hift_stft_f32")
+    check(lib.cbx_hift_stft_f32(_p(s), _p(spec), _p(sample_lens), B, L, spec.stride(1), _stream()), "cbx_hift_stft_f32")
     return spec
 
 

@@ -1,0 +1,316 @@
+"""S3Gen token->mel on MI355X: host-side mirror of `CausalMaskedDiffWithXvec.inference` (reference
+models/s3gen/flow.py:131-198): UpsampleConformerEncoder -> encoder_proj -> 10-step Euler CFM with CFG over the
+ConditionalDecoder estimator.  All tensors are channel-last (rows = frames), so every Conv1d/Linear is one call of
+the implicit-GEMM kernel and the attention reads Q/K/V straight out of the fused projection buffer.
+
+Batched (the reference is batch-1): utterances are right-padded; causal convs never look right, attention masks
+keys by per-row length, and the look-ahead conv zero-fills beyond each row's own length, so every valid frame gets
+exactly the value a batch-1 reference call would produce.
+"""
+import math
+
+import torch
+
+from . import ops, weights
+
+
+def _dev(t, dev):
+    return t.float().contiguous().to(dev)
+
+
+class FlowEngine:
+    def __init__(self, sd, device="cuda", meanflow=False):
+        self.dev = dev = torch.device(device)
+        self.meanflow = meanflow
+        d = lambda t: _dev(t, dev)
+        self.emb = d(sd["flow.input_embedding.weight"])
+        self.spk_w, self.spk_b = d(sd["flow.spk_embed_affine_layer.weight"]), d(sd["flow.spk_embed_affine_layer.bias"])
+        self.proj_w, self.proj_b = d(sd["flow.encoder_proj.weight"]), d(sd["flow.encoder_proj.bias"])
+        e = "flow.encoder."
+
+        def embed(p):
+            return dict(w=d(sd[p + "out.0.weight"]), b=d(sd[p + "out.0.bias"]), lnw=d(sd[p + "out.1.weight"]), lnb=d(sd[p + "out.1.bias"]))
+
+        def conf(p):
+            a = p + "self_attn."
+            wq, bq = sd[a + "linear_q.weight"], sd[a + "linear_q.bias"]
+            u, v = sd[a + "pos_bias_u"].reshape(-1), sd[a + "pos_bias_v"].reshape(-1)
+            # fused projection [q+u | q+v | k | v]: the two pos-bias copies of q come out of the GEMM for free
+            w4 = torch.cat([wq, wq, sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0)
+            b4 = torch.cat([bq + u, bq + v, sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0)
+            f = p + "feed_forward."
+            return dict(w4=d(w4), b4=d(b4), wpos=d(sd[a + "linear_pos.weight"]), wo=d(sd[a + "linear_out.weight"]),
+                        bo=d(sd[a + "linear_out.bias"]), ln_mha=(d(sd[p + "norm_mha.weight"]), d(sd[p + "norm_mha.bias"])),
+                        ln_ff=(d(sd[p + "norm_ff.weight"]), d(sd[p + "norm_ff.bias"])), w1=d(sd[f + "w_1.weight"]),
+                        b1=d(sd[f + "w_1.bias"]), w2=d(sd[f + "w_2.weight"]), b2=d(sd[f + "w_2.bias"]))
+
+        def count(prefix):
+            n = 0
+            while f"{prefix}{n}.norm_ff.weight" in sd:
+                n += 1
+            return n
+
+        self.embed, self.up_embed = embed(e + "embed."), embed(e + "up_embed.")
+        self.pl1 = (d(weights.pack_conv(sd[e + "pre_lookahead_layer.conv1.weight"])), d(sd[e + "pre_lookahead_layer.conv1.bias"]))
+        self.pl2 = (d(weights.pack_conv(sd[e + "pre_lookahead_layer.conv2.weight"])), d(sd[e + "pre_lookahead_layer.conv2.bias"]))
+        self.up_conv = (d(weights.pack_conv(sd[e + "up_layer.conv.weight"])), d(sd[e + "up_layer.conv.bias"]))
+        self.enc = [conf(e + f"encoders.{i}.") for i in range(count(e + "encoders."))]
+        self.up_enc = [conf(e + f"up_encoders.{i}.") for i in range(count(e + "up_encoders."))]
+        self.after_norm = (d(sd[e + "after_norm.weight"]), d(sd[e + "after_norm.bias"]))
+
+        # ---- CFM estimator
+        q = "flow.decoder.estimator."
+        self.t1 = (d(sd[q + "time_mlp.linear_1.weight"]), d(sd[q + "time_mlp.linear_1.bias"]))
+        self.t2 = (d(sd[q + "time_mlp.linear_2.weight"]), d(sd[q + "time_mlp.linear_2.bias"]))
+        self.t_mix = d(sd[q + "time_embed_mixer.weight"]) if meanflow else None
+
+        def stage(p, tail):
+            r = p + "0."
+            s = dict(c1=(d(weights.pack_conv(sd[r + "block1.block.0.weight"])), d(sd[r + "block1.block.0.bias"])),
+                     n1=(d(sd[r + "block1.block.2.weight"]), d(sd[r + "block1.block.2.bias"])),
+                     c2=(d(weights.pack_conv(sd[r + "block2.block.0.weight"])), d(sd[r + "block2.block.0.bias"])),
+                     n2=(d(sd[r + "block2.block.2.weight"]), d(sd[r + "block2.block.2.bias"])),
+                     res=(d(weights.pack_conv(sd[r + "res_conv.weight"])), d(sd[r + "res_conv.bias"])),
+                     cin=sd[r + "res_conv.weight"].shape[1], tb=[])
+            for j in range(4):
+                t = p + f"1.{j}."
+                s["tb"].append(dict(
+                    n1=(d(sd[t + "norm1.weight"]), d(sd[t + "norm1.bias"])),
+                    wqkv=d(torch.cat([sd[t + f"attn1.to_{c}.weight"] for c in "qkv"], 0)),
+                    wo=d(sd[t + "attn1.to_out.0.weight"]), bo=d(sd[t + "attn1.to_out.0.bias"]),
+                    n3=(d(sd[t + "norm3.weight"]), d(sd[t + "norm3.bias"])),
+                    w1=d(sd[t + "ff.net.0.proj.weight"]), b1=d(sd[t + "ff.net.0.proj.bias"]),
+                    w2=d(sd[t + "ff.net.2.weight"]), b2=d(sd[t + "ff.net.2.bias"])))
+            if tail:
+                s["tail"] = (d(weights.pack_conv(sd[p + "2.weight"])), d(sd[p + "2.bias"]))
+            return s
+
+        self.stages = [stage(q + "down_blocks.0.", True)]
+        i = 0
+        while f"{q}mid_blocks.{i}.0.mlp.1.weight" in sd:
+            self.stages.append(stage(q + f"mid_blocks.{i}.", False))
+            i += 1
+        self.stages.append(stage(q + "up_blocks.0.", True))
+        self.n_mid = i
+        # all 14 ResNet time-MLPs (Mish -> Linear 1024->256) concatenated: one GEMM gives every block's time bias
+        names = [q + "down_blocks.0."] + [q + f"mid_blocks.{k}." for k in range(i)] + [q + "up_blocks.0."]
+        self.tmlp_w = d(torch.cat([sd[n + "0.mlp.1.weight"] for n in names], 0))
+        self.tmlp_b = d(torch.cat([sd[n + "0.mlp.1.bias"] for n in names], 0))
+        self.fin = dict(c=(d(weights.pack_conv(sd[q + "final_block.block.0.weight"])), d(sd[q + "final_block.block.0.bias"])),
+                        n=(d(sd[q + "final_block.block.2.weight"]), d(sd[q + "final_block.block.2.bias"])),
+                        proj=(d(weights.pack_conv(sd[q + "final_proj.weight"])), d(sd[q + "final_proj.bias"])))
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ conformer encoder
+    @staticmethod
+    def _rel_pos_table(T, dev, dm=512):
+        """EspnetRelPositionalEncoding (transformer/embedding.py:224-294): row r <-> relative position T-1-r."""
+        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
+        div = torch.exp(torch.arange(0, dm, 2, dtype=torch.float32) * -(math.log(10000.0) / dm))
+        pe = torch.zeros(2 * T - 1, dm)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe.to(dev)
+
+    def _conformer(self, lw, x, B, T, pe, lens, ws):
+        """ConformerEncoderLayer.forward + RelPositionMultiHeadedAttention (encoder_layer.py:160-236, attention.py:249-330)."""
+        M = B * T
+        h, q4 = ws["h"][:M], ws["q4"][:M]
+        ops.layernorm(x, lw["ln_mha"][0], lw["ln_mha"][1], h, 1e-12)
+        ops.linear(h, lw["w4"], q4, bias=lw["b4"])
+        P = 2 * T - 1
+        pp = ws["pp"][:P]
+        ops.linear(pe, lw["wpos"], pp)
+        q5 = q4.view(B, T, 4, 8, 64)
+        Tp, Pp = ws["Tp"], ws["Pp"]
+        ac, bd, pr = ws["ac"], ws["bd"], ws["pr"]
+        ops.bmm(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3), ac[..., :T])
+        ops.bmm(q5[:, :, 1].permute(0, 2, 1, 3), pp.view(1, P, 8, 64).permute(0, 2, 1, 3).expand(B, 8, P, 64), bd[..., :P])
+        ops.softmax_relpos(ac[..., :T], bd, pr, 0.125, key_lens=lens)
+        att = ws["att"][:M]
+        ops.bmm(pr[..., :T], q5[:, :, 3].permute(0, 2, 1, 3), att.view(B, T, 8, 64).permute(0, 2, 1, 3), nn=True)
+        ops.linear(att, lw["wo"], x, bias=lw["bo"], residual=x)
+        ops.layernorm(x, lw["ln_ff"][0], lw["ln_ff"][1], h, 1e-12)
+        f = ws["ff"][:M]
+        ops.linear(h, lw["w1"], f, bias=lw["b1"], act=ops.SILU)
+        ops.linear(f, lw["w2"], x, bias=lw["b2"], residual=x)
+
+    def encode(self, tok, lens):
+        """tok (B,N) int64 padded with any valid id, lens (B,) int32 -> mu (B, 2N, 80) channel-last."""
+        dev, (B, N) = self.dev, tok.shape
+        T2 = 2 * N
+        f = lambda *s: torch.empty(*s, device=dev)
+        Tp, Pp = (T2 + 3) // 4 * 4, (2 * T2 - 1 + 3) // 4 * 4
+        ws = dict(h=f(B * T2, 512), q4=f(B * T2, 2048), pp=f(2 * T2, 512), att=f(B * T2, 512), ff=f(B * T2, 2048),
+                  ac=f(B, 8, T2, Tp), bd=f(B, 8, T2, Pp), pr=f(B, 8, T2, Tp), Tp=Tp, Pp=Pp)
+        ids = tok.reshape(-1).clone()
+        pad = (torch.arange(N, device=dev)[None, :] >= lens[:, None]).reshape(-1)
+        ids[pad] = -1  # `input_embedding(token) * mask` (flow.py:161-166): padded rows are zero vectors
+        x0 = f(B * N, 512)
+        ops.embed(ids, self.emb, x0)
+
+        def embed(ew, xin, M):
+            y = f(M, 512)
+            ops.linear(xin, ew["w"], y, bias=ew["b"])
+            ops.layernorm(y, ew["lnw"], ew["lnb"], y, 1e-5, scale=math.sqrt(512.0))
+            return y
+
+        x = embed(self.embed, x0, B * N)
+        # PreLookaheadLayer (upsample_encoder.py:81-96): right-pad 3 conv k4 -> leaky_relu -> left-pad 2 conv k3 -> + x
+        y1, x3 = f(B, N, 512), x.view(B, N, 512)
+        ops.conv1d(x3, self.pl1[0], y1, taps=4, cin=512, bias=self.pl1[1], pad_left=0, lens=lens, act=ops.LRELU, act_slope=0.01)
+        x2 = f(B, N, 512)
+        ops.conv1d(y1, self.pl2[0], x2, taps=3, cin=512, bias=self.pl2[1], pad_left=2, residual=x3)
+        x = x2.view(B * N, 512)
+        pe = self._rel_pos_table(N, dev)
+        wsN = dict(ws, ac=ws["ac"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4),
+                   bd=ws["bd"].view(-1)[: B * 8 * N * ((2 * N - 1 + 3) // 4 * 4)].view(B, 8, N, (2 * N - 1 + 3) // 4 * 4),
+                   pr=ws["pr"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4))
+        for lw in self.enc:
+            self._conformer(lw, x, B, N, pe, lens, wsN)
+        # Upsample1D (upsample_encoder.py:59-63): nearest x2, left-pad 4, conv k5 -- fused in the A-operand address map
+        xu = f(B, T2, 512)
+        ops.conv1d(x.view(B, N, 512), self.up_conv[0], xu, taps=5, cin=512, bias=self.up_conv[1], pad_left=4, up=2)
+        x = embed(self.up_embed, xu.view(B * T2, 512), B * T2)
+        pe2 = self._rel_pos_table(T2, dev)
+        lens2 = (lens * 2).to(torch.int32)
+        for lw in self.up_enc:
+            self._conformer(lw, x, B, T2, pe2, lens2, ws)
+        ops.layernorm(x, self.after_norm[0], self.after_norm[1], x, 1e-5)
+        mu = f(B, T2, 80)
+        ops.linear(x, self.proj_w, mu.view(B * T2, 80), bias=self.proj_b)
+        return mu
+
+    # ------------------------------------------------------------------ CFM estimator (decoder.py:243-333)
+    def _resnet(self, sw, xin, cin, rows, T, tb, ws, x):
+        """CausalResnetBlock1D: block1 -> + time bias -> block2 -> + res_conv(xin), written to `x` (must not alias xin:
+        the 1x1 res_conv reads whole input rows while other workgroups write output column tiles)."""
+        M = rows * T
+        a, b = ws["ra"], ws["rb"]
+        ops.conv1d(xin, sw["c1"][0], a, taps=3, cin=cin, bias=sw["c1"][1], pad_left=2)
+        a2, b2 = a.view(M, 256), b.view(M, 256)
+        ops.layernorm(a2, sw["n1"][0], sw["n1"][1], a2, 1e-5, act=ops.MISH, post_add=tb)
+        ops.conv1d(a, sw["c2"][0], b, taps=3, cin=256, bias=sw["c2"][1], pad_left=2)
+        ops.layernorm(b2, sw["n2"][0], sw["n2"][1], b2, 1e-5, act=ops.MISH)
+        ops.conv1d(xin, sw["res"][0], x, taps=1, cin=cin, bias=sw["res"][1], residual=b)
+        return x
+
+    def _tblock(self, tw, x, rows, T, lens, ws):
+        """BasicTransformerBlock (matcha/transformer.py:243-316) with diffusers Attention/GELU semantics."""
+        M = rows * T
+        x2, h, qkv, att, ff = x.view(M, 256), ws["h"], ws["qkv"], ws["att"], ws["ff"]
+        ops.layernorm(x2, tw["n1"][0], tw["n1"][1], h, 1e-5)
+        ops.linear(h, tw["wqkv"], qkv)
+        q5 = qkv.view(rows, T, 3, 8, 64)
+        ops.flash_attn(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], att.view(rows, T, 8, 64), 0.125, key_lens=lens)
+        ops.linear(att, tw["wo"], x2, bias=tw["bo"], residual=x2)
+        ops.layernorm(x2, tw["n3"][0], tw["n3"][1], h, 1e-5)
+        ops.linear(h, tw["w1"], ff, bias=tw["b1"], act=ops.GELU_ERF)
+        ops.linear(ff, tw["w2"], x2, bias=tw["b2"], residual=x2)
+
+    def _estimator(self, xin, rows, T, lens, tbias, ws):
+        """One ConditionalDecoder.forward on the packed input xin (rows,T,320) -> ws['v'] (rows,T,80)."""
+        st = self.stages
+        x = self._resnet(st[0], xin, 320, rows, T, tbias[0], ws, ws["x"])
+        for tw in st[0]["tb"]:
+            self._tblock(tw, x, rows, T, lens, ws)
+        cat = ws["cat"]  # [x | skip] for the up block: the skip half is written here right away
+        ops.axpby(x.view(rows * T, 256), cat.view(rows * T, 512)[:, 256:], 1.0, 0.0)
+        y = ws["y"]
+        ops.conv1d(x, st[0]["tail"][0], y, taps=3, cin=256, bias=st[0]["tail"][1], pad_left=2)
+        cur = y
+        for k in range(1, 1 + self.n_mid):
+            x = self._resnet(st[k], cur, 256, rows, T, tbias[k], ws, ws["x"] if cur is not ws["x"] else ws["x2"])
+            for tw in st[k]["tb"]:
+                self._tblock(tw, x, rows, T, lens, ws)
+            cur = x
+        ops.axpby(cur.view(rows * T, 256), cat.view(rows * T, 512)[:, :256], 1.0, 0.0)
+        up = st[-1]
+        x = self._resnet(up, cat, 512, rows, T, tbias[-1], ws, ws["x"])
+        for tw in up["tb"]:
+            self._tblock(tw, x, rows, T, lens, ws)
+        ops.conv1d(x, up["tail"][0], y, taps=3, cin=256, bias=up["tail"][1], pad_left=2)
+        a = ws["ra"]
+        ops.conv1d(y, self.fin["c"][0], a, taps=3, cin=256, bias=self.fin["c"][1], pad_left=2)
+        a2 = a.view(rows * T, 256)
+        ops.layernorm(a2, self.fin["n"][0], self.fin["n"][1], a2, 1e-5, act=ops.MISH)
+        ops.conv1d(a, self.fin["proj"][0], ws["v"], taps=1, cin=256, bias=self.fin["proj"][1])
+        return ws["v"]
+
+    def _time_bias(self, t_vals, r_vals=None):
+        """SinusoidalPosEmb -> TimestepEmbedding (-> meanflow mixer) -> every ResNet's Mish+Linear (matcha/decoder.py:20-29,
+        105-117; decoder.py:264-268): returns (n_steps, n_resnets, 256)."""
+        dev = self.dev
+
+        def tmlp(tv):
+            half = 160
+            fr = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+            e = 1000.0 * tv[:, None] * fr[None]
+            e = torch.cat([e.sin(), e.cos()], -1).to(dev)
+            n = e.shape[0]
+            h1, h2 = torch.empty(n, 1024, device=dev), torch.empty(n, 1024, device=dev)
+            ops.linear(e, self.t1[0], h1, bias=self.t1[1], act=ops.SILU)
+            ops.linear(h1, self.t2[0], h2, bias=self.t2[1])
+            return h2
+
+        temb = tmlp(t_vals)
+        if r_vals is not None:
+            cat = torch.cat([temb, tmlp(r_vals)], 1).contiguous()
+            temb = torch.empty_like(temb)
+            ops.linear(cat, self.t_mix, temb)
+        n = temb.shape[0]
+        m = torch.empty(n, 1024, device=dev)
+        ops.act(temb, m, ops.MISH)
+        out = torch.empty(n, self.tmlp_w.shape[0], device=dev)
+        ops.linear(m, self.tmlp_w, out, bias=self.tmlp_b)
+        return out.view(n, -1, 256)
+
+    def cfm(self, mu, lens, spk, cond, z, n_steps=10, cfg_rate=0.7):
+        """CausalConditionalCFM.forward + solve_euler (flow_matching.py:78-145,196-233).
+        mu/cond/z (B,T,80) channel-last, lens (B,) int32 valid frames, spk (B,80).  Returns x (B,T,80)."""
+        dev, (B, T, _) = self.dev, mu.shape
+        cfg = not self.meanflow
+        rows = 2 * B if cfg else B
+        f = lambda *s: torch.empty(*s, device=dev)
+        ws = dict(ra=f(rows, T, 256), rb=f(rows, T, 256), x=f(rows, T, 256), x2=f(rows, T, 256), y=f(rows, T, 256),
+                  cat=f(rows, T, 512),
+                  h=f(rows * T, 256), qkv=f(rows * T, 1536), att=f(rows * T, 512), ff=f(rows * T, 1024), v=f(rows, T, 80))
+        xin = torch.zeros(rows, T, 320, device=dev)
+        xin[:B, :, 0:80] = z
+        xin[:B, :, 80:160] = mu
+        xin[:B, :, 160:240] = spk[:, None, :]
+        xin[:B, :, 240:320] = cond
+        if cfg:
+            xin[B:, :, 0:80] = z
+        lens_r = torch.cat([lens, lens]).contiguous() if cfg else lens
+        t_span = torch.linspace(0, 1, n_steps + 1)
+        if not self.meanflow:
+            t_span = 1 - torch.cos(t_span * 0.5 * math.pi)
+        tb = self._time_bias(t_span[:-1], t_span[1:] if self.meanflow else None)
+        for k in range(n_steps):
+            v = self._estimator(xin, rows, T, lens_r, tb[k], ws)
+            ops.cfm_euler(xin, v, B, T, 80, float(t_span[k + 1] - t_span[k]), cfg_rate, cfg=cfg)
+        return xin[:B, :, :80]
+
+    # ------------------------------------------------------------------ flow.inference
+    @torch.inference_mode()
+    def inference(self, tokens, token_lens, ref, z=None, n_steps=10):
+        """tokens (B,N) int64 (right-padded), token_lens (B,), ref dict as produced by S3Gen.embed_ref, z optional
+        injected noise (B, 2P+2N, 80) channel-last.  Returns mel (B, 2N, 80) channel-last (frames >= 2*len undefined)."""
+        dev = self.dev
+        B, N = tokens.shape
+        ptok = ref["prompt_token"].to(dev).long().view(1, -1)
+        P = ptok.shape[1]
+        tok = torch.cat([ptok.expand(B, -1), tokens.to(dev).long()], 1).contiguous()
+        lens = (token_lens.to(dev).to(torch.int32) + P).contiguous()
+        mu = self.encode(tok, lens)
+        T = mu.shape[1]
+        emb = torch.nn.functional.normalize(ref["embedding"].to(dev).float().view(1, -1), dim=1)
+        spk = torch.empty(1, 80, device=dev)
+        ops.linear(emb.contiguous(), self.spk_w, spk, bias=self.spk_b)
+        cond = torch.zeros(B, T, 80, device=dev)
+        cond[:, : 2 * P] = ref["prompt_feat"].to(dev).float().view(1, 2 * P, 80)
+        if z is None:
+            z = torch.randn(B, T, 80, device=dev)
+        x = self.cfm(mu, (2 * lens).to(torch.int32), spk.expand(B, -1), cond, z.to(dev), n_steps)
+        return x[:, 2 * P:, :].contiguous()

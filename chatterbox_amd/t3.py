@@ -1,0 +1,271 @@
+"""T3 speech-token transformer on MI355X: host-side mirror of `T3.inference` (reference models/t3/t3.py:226-390).
+
+Python only sequences kernel launches; all arithmetic runs in libcbx_hip.so.  One decode step (embedding gather ->
+30 x [RMSNorm, fused QKV GEMM, RoPE + KV append, decode attention, O-proj + residual, RMSNorm, gate/up GEMM with
+SwiGLU epilogue, down-proj + residual] -> final norm -> speech head -> device sampler) is captured ONCE as a
+hipGraph and replayed per token: positions, context lengths, the next token id and the EOS flags live in device
+memory, so there is no host synchronisation inside the loop (the reference syncs every token, t3.py:366).
+
+Batching (not in the reference, which is batch-1): utterance b occupies row b (conditional) and row B+b (CFG
+unconditional); rows are right-padded to a common prefill length -- causal attention keeps padding invisible and
+the decode steps then overwrite it in the KV cache at each row's own position.
+"""
+import math
+
+import torch
+
+from . import ops, weights
+
+START_SPEECH, STOP_SPEECH = 6561, 6562
+START_TEXT, STOP_TEXT = 255, 0
+
+
+def llama3_rope_tables(max_pos, head_dim=64, theta=500000.0, factor=8.0, low=1.0, high=4.0, orig=8192):
+    """cos/sin tables [max_pos][64] for HF rope_type 'llama3' (reference llama_configs.py:22-30)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    wl = 2 * math.pi / inv
+    scaled = torch.where(wl > orig / low, inv / factor, inv)
+    smooth = (orig / wl - low) / (high - low)
+    mid = (1 - smooth) * scaled / factor + smooth * scaled
+    is_mid = ~(wl < orig / high) & ~(wl > orig / low)
+    inv = torch.where(is_mid, mid, scaled)
+    fr = torch.arange(max_pos).float()[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], -1)
+    return emb.cos().contiguous(), emb.sin().contiguous()
+
+
+class T3Engine:
+    D, H, HD, F = 1024, 16, 64, 4096
+
+    def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):
+        self.dev = torch.device(device)
+        if n_layers is None:
+            n_layers = 0
+            while f"tfmr.layers.{n_layers}.input_layernorm.weight" in sd:
+                n_layers += 1
+        self.L = n_layers
+        d = lambda t: t.float().contiguous().to(self.dev)
+        self.layers = []
+        for i in range(n_layers):
+            p = f"tfmr.layers.{i}."
+            self.layers.append(dict(
+                ln1=d(sd[p + "input_layernorm.weight"]), ln2=d(sd[p + "post_attention_layernorm.weight"]),
+                wqkv=d(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)),
+                wo=d(sd[p + "self_attn.o_proj.weight"]),
+                wgu=d(weights.pack_swiglu(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])),
+                wd=d(sd[p + "mlp.down_proj.weight"])))
+        self.norm = d(sd["tfmr.norm.weight"])
+        self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
+        self.text_pos, self.speech_pos = d(sd["text_pos_emb.emb.weight"]), d(sd["speech_pos_emb.emb.weight"])
+        self.head = d(sd["speech_head.weight"])
+        self.V = self.head.shape[0]
+        c = "cond_enc."
+        self.spkr_w, self.spkr_b = d(sd[c + "spkr_enc.weight"]), d(sd[c + "spkr_enc.bias"])
+        self.emo_w = d(sd[c + "emotion_adv_fc.weight"].view(-1))
+        self.pq = d(sd[c + "perceiver.pre_attention_query"][0])
+        self.p_ln = (d(sd[c + "perceiver.attn.norm.weight"]), d(sd[c + "perceiver.attn.norm.bias"]))
+        self.p_q = (d(sd[c + "perceiver.attn.to_q.weight"]), d(sd[c + "perceiver.attn.to_q.bias"]))
+        self.p_kv = (d(torch.cat([sd[c + "perceiver.attn.to_k.weight"], sd[c + "perceiver.attn.to_v.weight"]], 0)),
+                     d(torch.cat([sd[c + "perceiver.attn.to_k.bias"], sd[c + "perceiver.attn.to_v.bias"]], 0)))
+        self.p_out = (d(sd[c + "perceiver.attn.proj_out.weight"]), d(sd[c + "perceiver.attn.proj_out.bias"]))
+        cos, sin = llama3_rope_tables(max_pos)
+        self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
+        self.max_pos = max_pos
+        self._state = {}
+
+    # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
+    def _perceiver_block(self, x1, x2):
+        """AttentionBlock2.forward (perceiver.py:156-170): x1 (n1,1024) queries attend to x2 (n2,1024)."""
+        f = lambda *s: torch.empty(*s, device=self.dev)
+        n1, n2 = x1.shape[0], x2.shape[0]
+        h1, h2 = f(n1, 1024), f(n2, 1024)
+        ops.layernorm(x1, self.p_ln[0], self.p_ln[1], h1)
+        ops.layernorm(x2, self.p_ln[0], self.p_ln[1], h2)
+        q, kv = f(n1, 1024), f(n2, 2048)
+        ops.linear(h1, self.p_q[0], q, bias=self.p_q[1])
+        ops.linear(h2, self.p_kv[0], kv, bias=self.p_kv[1])
+        n2p = (n2 + 3) // 4 * 4
+        s, pr = f(1, 4, n1, n2p), f(1, 4, n1, n2p)
+        kv8 = kv.view(1, n2, 8, 256)  # heads 0-3 = K heads, 4-7 = V heads
+        ops.bmm(q.view(1, n1, 4, 256).permute(0, 2, 1, 3), kv8[:, :, :4].permute(0, 2, 1, 3), s[..., :n2])
+        ops.softmax_rows(s, pr, 1.0 / 16.0, n2)
+        o = f(n1, 1024)
+        ops.bmm(pr[..., :n2], kv8[:, :, 4:].permute(0, 2, 1, 3), o.view(1, n1, 4, 256).permute(0, 2, 1, 3), nn=True)
+        out = f(n1, 1024)
+        ops.linear(o, self.p_out[0], out, bias=self.p_out[1], residual=x1)
+        return out
+
+    def cond_embeds(self, cond):
+        """T3.prepare_conditioning -> (34, 1024): [speaker | 32 perceiver latents | emotion]."""
+        dev = self.dev
+        out = torch.empty(34, 1024, device=dev)
+        spk = cond["speaker_emb"].to(dev).float().view(1, 256)
+        ops.linear(spk, self.spkr_w, out[0:1], bias=self.spkr_b)
+        toks = cond["cond_prompt_speech_tokens"].to(dev).long().view(-1)
+        n = toks.shape[0]
+        pe = torch.empty(n, 1024, device=dev)
+        ops.embed(toks, self.speech_emb, pe, table2=self.speech_pos, ids2=torch.arange(n, dtype=torch.int32, device=dev))
+        pre = self._perceiver_block(self.pq, pe)
+        out[1:33] = self._perceiver_block(pre, pre)
+        emo = float(torch.as_tensor(cond["emotion_adv"]).reshape(-1)[0])
+        ops.axpby(self.emo_w.view(1, -1), out[33:34], a=emo, b=0.0)
+        return out
+
+    # ------------------------------------------------------------------ one transformer layer
+    def _layer_prefill(self, lw, x, ws, S, rows, kc, vc, pos, crow):
+        M = rows * S
+        ops.layernorm(x, lw["ln1"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wqkv"], ws["qkv"])
+        ops.rope_kv(ws["qkv"], pos, self.cos, self.sin, kc, vc, self.H, cache_rows=crow)
+        q4 = ws["qkv"].view(rows, S, 3, self.H, 64)
+        ops.flash_attn(q4[:, :, 0], q4[:, :, 1], q4[:, :, 2], ws["att"].view(rows, S, self.H, 64), 0.125, causal=True)
+        ops.linear(ws["att"], lw["wo"], x, residual=x)
+        ops.layernorm(x, lw["ln2"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
+        ops.linear(ws["g"], lw["wd"], x, residual=x)
+
+    def _layer_decode(self, lw, x, ws, kc, vc, st):
+        ops.layernorm(x, lw["ln1"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wqkv"], ws["qkv"])
+        ops.rope_kv(ws["qkv"], st["positions"], self.cos, self.sin, kc, vc, self.H)
+        ops.decode_attn(ws["qkv"], kc, vc, ws["att"], st["ctx_lens"], 0.125)
+        ops.linear(ws["att"], lw["wo"], x, residual=x)
+        ops.layernorm(x, lw["ln2"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
+        ops.linear(ws["g"], lw["wd"], x, residual=x)
+
+    def _decode_step(self, st):
+        ws, x = st["dws"], st["dws"]["x"]
+        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
+        for i, lw in enumerate(self.layers):
+            self._layer_decode(lw, x, ws, st["kc"][i], st["vc"][i], st)
+        ops.layernorm(x, self.norm, None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], self.head, st["logits"])
+        self._sample(st)
+
+    def _sample(self, st):
+        sp = st["samp"]
+        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, cfg_weight=sp["cfg_weight"],
+                      temperature=sp["temperature"], min_p=sp["min_p"], top_p=sp["top_p"], rep_penalty=sp["repetition_penalty"],
+                      top_k=0, order=0, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH, seen=st["seen"],
+                      uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"], out_tokens=st["out_tokens"],
+                      done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"], next_pos_ids=st["next_pos_ids"],
+                      positions=st["positions"], ctx_lens=st["ctx_lens"])
+
+    # ------------------------------------------------------------------ state / workspaces
+    def _get_state(self, B, max_ctx, max_steps):
+        key = (B, max_ctx, max_steps)
+        if key in self._state:
+            return self._state[key]
+        self._state.clear()  # one live configuration at a time (the KV cache dominates memory)
+        dev, rows = self.dev, 2 * B
+        f = lambda *s: torch.empty(*s, device=dev)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        st = dict(B=B, rows=rows, max_ctx=max_ctx, max_steps=max_steps,
+                  kc=torch.zeros(self.L, rows, self.H, max_ctx, 64, device=dev),
+                  vc=torch.zeros(self.L, rows, self.H, max_ctx, 64, device=dev),
+                  logits=f(rows, self.V), seen=torch.zeros(B, self.V, dtype=torch.uint8, device=dev),
+                  uniforms=f(B, max_steps), step=i32(B), out_tokens=torch.zeros(B, max_steps, dtype=torch.int64, device=dev),
+                  done=i32(B), n_generated=i32(B), next_ids=torch.zeros(rows, dtype=torch.int64, device=dev),
+                  next_pos_ids=i32(rows), positions=i32(rows), ctx_lens=i32(rows),
+                  dws=dict(x=f(rows, self.D), h=f(rows, self.D), qkv=f(rows, 3 * self.D), att=f(rows, self.D), g=f(rows, self.F)),
+                  graph=None, samp=None)
+        self._state[key] = st
+        return st
+
+    # ------------------------------------------------------------------ T3.inference
+    @torch.inference_mode()
+    def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
+                 repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, use_graph=True, poll_every=16,
+                 return_prefill_logits=False, debug_logits=False):
+        """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
+        carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled)."""
+        dev, B = self.dev, len(text_tokens)
+        rows = 2 * B
+        if isinstance(conds, dict):
+            ce = [self.cond_embeds(conds)] * B
+        else:
+            ce = [self.cond_embeds(c) for c in conds]
+        tl = [int(t.numel()) for t in text_tokens]
+        s0 = [34 + n + 2 for n in tl]
+        S = max(s0)
+        max_ctx = (S + max_new_tokens + 63) // 64 * 64
+        assert max_ctx <= self.max_pos, "context exceeds the RoPE table"
+        st = self._get_state(B, max_ctx, max_new_tokens)
+        samp = dict(temperature=float(temperature), top_p=float(top_p), min_p=float(min_p),
+                    repetition_penalty=float(repetition_penalty), cfg_weight=float(cfg_weight), ban_eos=bool(ban_eos))
+        if st["samp"] != samp:
+            st["samp"], st["graph"] = samp, None
+        for k in ("seen", "step", "done", "n_generated", "out_tokens"):
+            st[k].zero_()
+        st["seen"][:, START_SPEECH] = 1
+        if uniforms is None:
+            st["uniforms"].uniform_()
+        else:
+            st["uniforms"].copy_(torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)[:, :max_new_tokens])
+
+        # ---- prefill embeddings (prepare_input_embeds + second BOS, t3.py:102-130,305-313)
+        x = torch.zeros(rows, S, self.D, device=dev)
+        bos = torch.full((2,), START_SPEECH, dtype=torch.int64, device=dev)
+        zero2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        for b in range(B):
+            ids = text_tokens[b].to(dev).long().view(-1)
+            pos = torch.arange(tl[b], dtype=torch.int32, device=dev)
+            for r, scale in ((b, 1.0), (B + b, 0.0)):
+                x[r, :34] = ce[b]
+                ops.embed(ids, self.text_emb, x[r, 34:34 + tl[b]], table2=self.text_pos, ids2=pos, scale=scale)
+                ops.embed(bos, self.speech_emb, x[r, 34 + tl[b]:s0[b]], table2=self.speech_pos, ids2=zero2)
+        xf = x.view(rows * S, self.D)
+        pws = dict(h=torch.empty(rows * S, self.D, device=dev), qkv=torch.empty(rows * S, 3 * self.D, device=dev),
+                   att=torch.empty(rows * S, self.D, device=dev), g=torch.empty(rows * S, self.F, device=dev))
+        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(rows)
+        crow = torch.arange(rows, dtype=torch.int32, device=dev).repeat_interleave(S)
+        for i, lw in enumerate(self.layers):
+            self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
+        last = torch.tensor([r * S + s0[r % B] - 1 for r in range(rows)], device=dev)
+        hl = xf.index_select(0, last).contiguous()
+        ops.layernorm(hl, self.norm, None, st["dws"]["h"], 1e-5, rms=True)
+        ops.linear(st["dws"]["h"], self.head, st["logits"])
+        prefill_logits = st["logits"].clone() if return_prefill_logits else None
+        del x, xf, pws
+
+        # ---- decode loop: positions / ctx_lens hold the state BEFORE the first sample (incremented by the sampler)
+        s0t = torch.tensor(s0 + s0, dtype=torch.int32, device=dev)
+        st["positions"].copy_(s0t - 1)
+        st["ctx_lens"].copy_(s0t)
+        step_logits = [st["logits"].clone()] if debug_logits else None
+        self._sample(st)
+        if debug_logits:
+            use_graph = False
+        if use_graph and st["graph"] is None and max_new_tokens > 1:
+            torch.cuda.synchronize()
+            saved = {k: st[k].clone() for k in ("seen", "step", "done", "n_generated", "out_tokens", "next_ids",
+                                                "next_pos_ids", "positions", "ctx_lens", "logits")}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step(st)
+            for k, v in saved.items():  # the capture warm-up must not leak into the real sequence
+                st[k].copy_(v)
+            st["graph"] = g
+        for i in range(1, max_new_tokens):
+            if use_graph and st["graph"] is not None:
+                st["graph"].replay()
+            elif debug_logits:  # forward and sampler split so that the raw logits of every step can be inspected
+                ws, x = st["dws"], st["dws"]["x"]
+                ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
+                for li, lw in enumerate(self.layers):
+                    self._layer_decode(lw, x, ws, st["kc"][li], st["vc"][li], st)
+                ops.layernorm(x, self.norm, None, ws["h"], 1e-5, rms=True)
+                ops.linear(ws["h"], self.head, st["logits"])
+                step_logits.append(st["logits"].clone())
+                self._sample(st)
+            else:
+                self._decode_step(st)
+            if not ban_eos and (i % poll_every == 0) and bool(st["done"].all()):
+                break
+        n = st["n_generated"].tolist()
+        toks = st["out_tokens"].cpu()
+        out = [toks[b, : n[b]].clone() for b in range(B)]
+        if debug_logits:
+            return out, torch.stack(step_logits)  # (steps, 2B, V)
+        return (out, prefill_logits) if return_prefill_logits else out

@@ -132,7 +132,8 @@ int cbx_t3_sample(const cbx_sampler_t* p, void* stream);
 /* ---- HiFT source + (i)STFT (hifigan.py:201-231,267-283,396-410) ---- */
 int cbx_hift_source_f32(const float* f0, const float* phase, const float* noise, const float* lin_w, float lin_b,
                         float* s, double* frame_cum, int B, int T, int up, float sr, void* stream);
-int cbx_hift_stft_f32(const float* s, float* spec, int B, long L, long ld_spec, void* stream);
+/* sample_lens[b] (or NULL): per-row signal length; the centre-reflect padding mirrors at that row's own end */
+int cbx_hift_stft_f32(const float* s, float* spec, const int* sample_lens, int B, long L, long ld_spec, void* stream);
 /* x[b][frame][0..8] log-magnitude, [9..17] phase pre-sin (conv_post output); fade_n>0 applies S3Gen trim_fade. */
 int cbx_hift_istft_f32(const float* x, float* wav, int B, long frames, long ldx, float clamp, int fade_n,
                        void* stream);

@@ -33,11 +33,17 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class GemvParams(ctypes.Structure):
+    _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
+                ("part_stride", c_long)]
+
+
 class SamplerParams(ctypes.Structure):
     _fields_ = [
         ("logits", c_f), ("ld", c_long), ("V", c_int), ("B", c_int), ("cfg", c_int),
         ("cfg_weight", c_float), ("temperature", c_float), ("min_p", c_float), ("top_p", c_float),
-        ("rep_penalty", c_float), ("top_k", c_int), ("order", c_int), ("ban_token", c_int), ("eos_token", c_int),
+        ("rep_penalty", c_float), ("top_k", c_int), ("order", c_int), ("ban_token", c_int), ("eos_token", c_int), ("ban_from", c_int),
         ("seen", c_f), ("uniforms", c_f), ("max_steps", c_int), ("step", c_f), ("out_tokens", c_f),
         ("done", c_f), ("n_generated", c_f), ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f),
         ("ctx_lens", c_f),
@@ -48,6 +54,8 @@ _SIGS = {
     "cbx_abi_version": ([], c_int),
     "cbx_last_error": ([], ctypes.c_char_p),
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
+    "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
+    "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     const int i0 = tid * per, i1 = min(V, i0 + per);
     double loc = 0.0;
     for (int i = i0; i < i1; ++i) {
-        float e = (i == p.ban_token) ? 0.f : __expf(l[i] - m);
+        float e = (i == p.ban_token || i >= p.ban_from) ? 0.f : __expf(l[i] - m);
         loc += (double)e;
     }
     // exclusive scan of `loc` over threads: inclusive wave scan + wave bases
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
         double run = excl;
         int pick = -1;
         for (int i = i0; i < i1; ++i) {
-            float e = (i == p.ban_token) ? 0.f : __expf(l[i] - m);
+            float e = (i == p.ban_token || i >= p.ban_from) ? 0.f : __expf(l[i] - m);
             if (e > 0.f) {
                 pick = i;
                 run += (double)e;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
         int tok = chosen;
         if (tok < 0) {  // numerical corner (target == total): last id with non-zero probability
             for (int i = V - 1; i >= 0; --i)
-                if (i != p.ban_token && l[i] > -INFINITY) { tok = i; break; }
+                if (i != p.ban_token && i < p.ban_from && l[i] > -INFINITY) { tok = i; break; }
         }
         p.out_tokens[(long)b * p.max_steps + step] = tok;
         seen[tok] = 1;
@@ -231,6 +231,8 @@ extern "C" int cbx_t3_sample(const cbx_sampler_t* p, void* stream) {
     CBX_REQUIRE(p && p->logits && p->seen && p->uniforms && p->step && p->out_tokens && p->done && p->n_generated,
                 "t3_sample: null operand");
     CBX_REQUIRE(p->V > 0 && p->V <= MAXV, "t3_sample: V=%d exceeds %d", p->V, MAXV);
-    hipLaunchKernelGGL(t3_sample_kernel, dim3(p->B), dim3(NT), 0, (hipStream_t)stream, *p);
+    cbx_sampler_t q = *p;
+    if (q.ban_from <= 0) q.ban_from = q.V;
+    hipLaunchKernelGGL(t3_sample_kernel, dim3(q.B), dim3(NT), 0, (hipStream_t)stream, q);
     return cbx_check_launch("t3_sample");
 }

@@ -1,0 +1,88 @@
+"""Data-parallel utterance sharding over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference has no distributed path; utterances are independent, so the path shards with NO
+collective inside it.  Only two exchanges exist, both outside the kernels' critical path:
+  C1  broadcast of the packed voice `Conditionals` (~170 KB) from the rank that analysed the prompt,
+  C2  gather of the finished waveforms (padded to the longest + int32 lengths) to rank 0.
+Over 7 xGMI links x ~153 GB/s a 31 MB/GPU gather costs < 1 ms, so scaling is decided by load balance: shards are
+contiguous blocks of the utterance list (length-sorted lists balance best).
+"""
+import torch
+import torch.distributed as dist
+
+_T3_KEYS = ("speaker_emb", "cond_prompt_speech_tokens", "emotion_adv")
+_GEN_KEYS = ("prompt_token", "prompt_token_len", "prompt_feat", "embedding")
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition: the first (n % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _flatten(t3_cond, gen_ref):
+    tensors = [torch.as_tensor(t3_cond[k]) for k in _T3_KEYS] + [torch.as_tensor(gen_ref[k]) for k in _GEN_KEYS]
+    meta = [(tuple(t.shape), t.dtype) for t in tensors]
+    flat = torch.cat([t.reshape(-1).to(torch.float64) for t in tensors])  # ids < 2^53: exact in fp64
+    return flat, meta
+
+
+def _unflatten(flat, meta):
+    out, off = [], 0
+    for shape, dtype in meta:
+        n = 1
+        for s in shape:
+            n *= s
+        out.append(flat[off:off + n].to(dtype).reshape(shape))
+        off += n
+    return (dict(zip(_T3_KEYS, out[:3])), dict(zip(_GEN_KEYS, out[3:]), prompt_feat_len=None))
+
+
+def broadcast_conditionals(t3_cond, gen_ref, src=0, device=None):
+    """C1: every rank returns (t3_cond, gen_ref) of `src`.  Non-src ranks may pass None."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t3_cond, gen_ref
+    rank = dist.get_rank()
+    obj = [None]
+    if rank == src:
+        flat, meta = _flatten(t3_cond, gen_ref)
+        obj = [(meta, flat.numel())]
+    dist.broadcast_object_list(obj, src=src)  # tiny metadata (shapes/dtypes)
+    meta, n = obj[0]
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    buf = flat.to(dev) if rank == src else torch.empty(n, dtype=torch.float64, device=dev)
+    dist.broadcast(buf, src=src)
+    t3c, gen = _unflatten(buf.cpu(), meta)
+    return t3c, gen
+
+
+def gather_waveforms(wavs, dst=0):
+    """C2: `wavs` is this rank's list of 1-D float tensors.  Returns, on rank `dst`, the list over all ranks in rank
+    order (CPU tensors); None elsewhere.  One all_gather of a padded (n_local_max, L_max) block + lengths."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [w.detach().cpu() for w in wavs]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = wavs[0].device if len(wavs) and dist.get_backend() == "nccl" else torch.device("cpu")
+    shape = torch.tensor([len(wavs), max([w.numel() for w in wavs], default=0)], dtype=torch.int64, device=dev)
+    shapes = [torch.zeros_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape)
+    n_max = int(max(s[0] for s in shapes))
+    l_max = int(max(s[1] for s in shapes))
+    block = torch.zeros(n_max, l_max, dtype=torch.float32, device=dev)
+    lens = torch.zeros(n_max, dtype=torch.int32, device=dev)
+    for i, w in enumerate(wavs):
+        block[i, : w.numel()] = w.to(dev)
+        lens[i] = w.numel()
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    dist.all_gather(all_lens, lens)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        for i in range(int(shapes[r][0])):
+            out.append(blocks[r][i, : int(all_lens[r][i])].cpu())
+    return out

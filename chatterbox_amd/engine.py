@@ -1,0 +1,82 @@
+"""generate() = T3.inference -> S3Gen.flow_inference -> HiFT.inference for a BATCH of utterances on one MI355X.
+
+Mirrors the body of `ChatterboxMultilingualTTS.generate` (reference mtl_tts.py:324-352) after text tokenisation:
+speech tokens are stripped of SOS/EOS (`drop_invalid_tokens`, s3tokenizer/__init__.py:16-30), the flow + vocoder run
+on the padded batch, and each waveform is cut to its own length (the multilingual path also drops the last
+token's 40 ms, mtl_tts.py:348-352).
+"""
+import time
+
+import torch
+
+from .hift import HiFTEngine
+from .s3gen import FlowEngine
+from .t3 import T3Engine, START_SPEECH, STOP_SPEECH
+
+SPEECH_VOCAB = 6561
+SAMPLES_PER_TOKEN = 960  # 24 kHz / 25 tokens per second
+
+
+def drop_invalid_tokens(x):
+    """Strip [SOS ... EOS) and ids outside the S3 codebook (reference s3tokenizer/__init__.py:16-30, tts.py:260-262)."""
+    x = x.view(-1)
+    sos = (x == START_SPEECH).nonzero()
+    s = int(sos[0]) + 1 if len(sos) else 0
+    eos = (x == STOP_SPEECH).nonzero()
+    e = int(eos[0]) if len(eos) else len(x)
+    x = x[s:e]
+    return x[x < SPEECH_VOCAB]
+
+
+class ChatterboxEngine:
+    def __init__(self, t3_sd, s3gen_sd, device="cuda", n_t3_layers=None, meanflow=False):
+        self.dev = torch.device(device)
+        self.t3 = T3Engine(t3_sd, self.dev, n_layers=n_t3_layers)
+        self.flow = FlowEngine(s3gen_sd, self.dev, meanflow=meanflow)
+        self.hift = HiFTEngine(s3gen_sd, self.dev)
+        self.last_timing = {}
+
+    @torch.inference_mode()
+    def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False):
+        """S3Gen.inference for a list of 1-D token tensors (already valid ids).  Returns (list of 1-D wav tensors on
+        device, mel (B, 2Nmax, 80) channel-last)."""
+        B = len(speech_tokens)
+        ns = [int(t.numel()) for t in speech_tokens]
+        Nmax = max(ns)
+        tok = torch.zeros(B, Nmax, dtype=torch.long)
+        for b, t in enumerate(speech_tokens):
+            tok[b, : ns[b]] = t
+        lens = torch.tensor(ns, dtype=torch.int32)
+        t0 = time.perf_counter()
+        mel = self.flow.inference(tok.to(self.dev), lens.to(self.dev), gen_ref, z=z, n_steps=n_cfm_timesteps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        same = all(n == Nmax for n in ns)
+        mel_lens = None if same else (2 * lens).to(self.dev)
+        wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        self.last_timing.update(flow_s=t1 - t0, hift_s=t2 - t1)
+        out = []
+        for b, n in enumerate(ns):
+            keep = max(1, n - 1) if drop_last_token else n
+            out.append(wav[b, : keep * SAMPLES_PER_TOKEN])
+        return out, mel
+
+    @torch.inference_mode()
+    def synthesize(self, text_tokens, t3_conds, gen_ref, *, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
+                   repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, z=None, phase=None,
+                   noise=None, n_cfm_timesteps=10, drop_last_token=True):
+        """Full hot path for B utterances.  Returns (wavs: list of 1-D device tensors, speech_tokens: list)."""
+        t0 = time.perf_counter()
+        toks = self.t3.generate(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
+                                min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms,
+                                ban_eos=ban_eos, ban_from=ban_from)
+        torch.cuda.synchronize()
+        self.last_timing = dict(t3_s=time.perf_counter() - t0)
+        st = [drop_invalid_tokens(t) for t in toks]
+        st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
+        wavs, _ = self.vocode(st, gen_ref, z=z, phase=phase, noise=noise, n_cfm_timesteps=n_cfm_timesteps,
+                              drop_last_token=drop_last_token)
+        self.last_timing["total_s"] = time.perf_counter() - t0
+        return wavs, st

@@ -7,9 +7,43 @@ import ctypes
 
 import torch
 
-from ._lib import GemmParams, SamplerParams, check, lib
+from ._lib import GemmParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches of selected kernel classes, on the stream they are launched on.
+    Used by bench.py for the roofline line (average launch duration + algorithmic FLOPs/bytes per launch)."""
+
+    def __init__(self, kinds):
+        self.kinds = set(kinds)
+        self.rec = []  # (kind, start_event, end_event, flops, bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, e0, e1, fl, by in self.rec:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+TIMER = None  # set to a KernelTimer to time launches (never during hipGraph capture)
+
+
+def _timed(kind, flops, nbytes, fn):
+    if TIMER is None or kind not in TIMER.kinds:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    TIMER.rec.append((kind, e0, e1, float(flops), float(nbytes)))
+    return r
 
 
 def _p(t):
@@ -45,7 +79,10 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc, p.c_s1, p.c_s2 = ldc, c_s[0], c_s[1]
     p.ldr, p.r_s1, p.r_s2 = ldr, r_s[0], r_s[1]
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
-    check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32")
+    nz = nz1 * nz2
+    kind = "gemm_f32_skinny" if M <= 32 else "gemm_f32"
+    _timed(kind, 2.0 * M * N * K * nz, 4.0 * nz * (M * K / max(1, taps) + N * K + M * N),
+           lambda: check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32"))
     return C
 
 
@@ -88,6 +125,33 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
+def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False):
+    """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials."""
+    M, K = x.shape
+    N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
+    p = GemvParams()
+    p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
+    p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu = M, N, K, ksplit, nw, int(swiglu)
+    p.ldx, p.ldw = x.stride(0), w.stride(0)
+    if ksplit > 1:
+        assert out.dim() == 3 and out.shape[0] == ksplit
+        p.ldo, p.part_stride = out.stride(1), out.stride(0)
+    else:
+        p.ldo, p.part_stride = out.stride(0), 0
+    _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
+           lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
+    return out
+
+
+def add_rmsnorm(x, part, w, h, eps=1e-5):
+    """x += sum_k part[k]; h = rmsnorm(x) * w.   part (ksplit, rows, C) or None."""
+    rows, C = x.shape
+    ks = 0 if part is None else part.shape[0]
+    check(lib.cbx_add_rmsnorm_f32(_p(x), _p(part), ks, 0 if part is None else part.stride(0), 0 if part is None else part.stride(1),
+                                  _p(w), _p(h), rows, C, x.stride(0), h.stride(0), eps, _stream()), "cbx_add_rmsnorm_f32")
+    return h
+
+
 def layernorm(x, w, b, out, eps=1e-5, rms=False, act=NONE, post_add=None, scale=1.0):
     rows, C = x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1
@@ -103,9 +167,11 @@ def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
     assert D == 64
     for t in (q, k, v, out):
         assert t.stride(3) == 1 and t.stride(2) == 64
-    check(lib.cbx_flash_attn_f32(_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1),
-                                 k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale,
-                                 int(causal), _stream()), "cbx_flash_attn_f32")
+    _timed("flash_attn_f32", 4.0 * Z * H * Tq * Tk * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * (2 * Tq + 2 * Tk),
+           lambda: check(lib.cbx_flash_attn_f32(_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0),
+                                                q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                out.stride(0), out.stride(1), scale, int(causal), _stream()),
+                         "cbx_flash_attn_f32"))
     return out
 
 

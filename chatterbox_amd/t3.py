@@ -124,30 +124,36 @@ class T3Engine:
         ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
         ops.linear(ws["g"], lw["wd"], x, residual=x)
 
-    def _layer_decode(self, lw, x, ws, kc, vc, st):
-        ops.layernorm(x, lw["ln1"], None, ws["h"], 1e-5, rms=True)
-        ops.linear(ws["h"], lw["wqkv"], ws["qkv"])
-        ops.rope_kv(ws["qkv"], st["positions"], self.cos, self.sin, kc, vc, self.H)
-        ops.decode_attn(ws["qkv"], kc, vc, ws["att"], st["ctx_lens"], 0.125)
-        ops.linear(ws["att"], lw["wo"], x, residual=x)
-        ops.layernorm(x, lw["ln2"], None, ws["h"], 1e-5, rms=True)
-        ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
-        ops.linear(ws["g"], lw["wd"], x, residual=x)
+    def _forward_decode(self, st):
+        """One token for every row.  The residual stream x is only touched by add_rmsnorm, which folds the split-K
+        partials of the previous projection, the residual add and the RMSNorm into one pass."""
+        ws, x = st["dws"], st["dws"]["x"]
+        h, qkv, att, g, po, pd = ws["h"], ws["qkv"], ws["att"], ws["g"], ws["po"], ws["pd"]
+        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
+        part = None
+        for i, lw in enumerate(self.layers):
+            ops.add_rmsnorm(x, part, lw["ln1"], h)
+            ops.gemv(h, lw["wqkv"], qkv, nw=8)
+            ops.rope_kv(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], self.H)
+            ops.decode_attn(qkv, st["kc"][i], st["vc"][i], att, st["ctx_lens"], 0.125)
+            ops.gemv(att, lw["wo"], po, ksplit=4, nw=4)
+            ops.add_rmsnorm(x, po, lw["ln2"], h)
+            ops.gemv(h, lw["wgu"], g, swiglu=True, nw=8)
+            ops.gemv(g, lw["wd"], pd, ksplit=8, nw=4)
+            part = pd
+        ops.add_rmsnorm(x, part, self.norm, h)
+        ops.gemv(h, self.head, st["logits"], nw=4)
 
     def _decode_step(self, st):
-        ws, x = st["dws"], st["dws"]["x"]
-        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
-        for i, lw in enumerate(self.layers):
-            self._layer_decode(lw, x, ws, st["kc"][i], st["vc"][i], st)
-        ops.layernorm(x, self.norm, None, ws["h"], 1e-5, rms=True)
-        ops.linear(ws["h"], self.head, st["logits"])
+        self._forward_decode(st)
         self._sample(st)
 
     def _sample(self, st):
         sp = st["samp"]
         ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, cfg_weight=sp["cfg_weight"],
                       temperature=sp["temperature"], min_p=sp["min_p"], top_p=sp["top_p"], rep_penalty=sp["repetition_penalty"],
-                      top_k=0, order=0, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH, seen=st["seen"],
+                      top_k=0, order=0, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH,
+                      ban_from=sp["ban_from"], seen=st["seen"],
                       uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"], out_tokens=st["out_tokens"],
                       done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"], next_pos_ids=st["next_pos_ids"],
                       positions=st["positions"], ctx_lens=st["ctx_lens"])
@@ -168,7 +174,8 @@ class T3Engine:
                   uniforms=f(B, max_steps), step=i32(B), out_tokens=torch.zeros(B, max_steps, dtype=torch.int64, device=dev),
                   done=i32(B), n_generated=i32(B), next_ids=torch.zeros(rows, dtype=torch.int64, device=dev),
                   next_pos_ids=i32(rows), positions=i32(rows), ctx_lens=i32(rows),
-                  dws=dict(x=f(rows, self.D), h=f(rows, self.D), qkv=f(rows, 3 * self.D), att=f(rows, self.D), g=f(rows, self.F)),
+                  dws=dict(x=f(rows, self.D), h=f(rows, self.D), qkv=f(rows, 3 * self.D), att=f(rows, self.D), g=f(rows, self.F),
+                           po=f(4, rows, self.D), pd=f(8, rows, self.D)),
                   graph=None, samp=None)
         self._state[key] = st
         return st
@@ -176,7 +183,7 @@ class T3Engine:
     # ------------------------------------------------------------------ T3.inference
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
-                 repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, use_graph=True, poll_every=16,
+                 repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16,
                  return_prefill_logits=False, debug_logits=False):
         """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
         carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled)."""
@@ -193,7 +200,7 @@ class T3Engine:
         assert max_ctx <= self.max_pos, "context exceeds the RoPE table"
         st = self._get_state(B, max_ctx, max_new_tokens)
         samp = dict(temperature=float(temperature), top_p=float(top_p), min_p=float(min_p),
-                    repetition_penalty=float(repetition_penalty), cfg_weight=float(cfg_weight), ban_eos=bool(ban_eos))
+                    repetition_penalty=float(repetition_penalty), cfg_weight=float(cfg_weight), ban_eos=bool(ban_eos), ban_from=int(ban_from))
         if st["samp"] != samp:
             st["samp"], st["graph"] = samp, None
         for k in ("seen", "step", "done", "n_generated", "out_tokens"):
@@ -251,12 +258,7 @@ class T3Engine:
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
             elif debug_logits:  # forward and sampler split so that the raw logits of every step can be inspected
-                ws, x = st["dws"], st["dws"]["x"]
-                ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
-                for li, lw in enumerate(self.layers):
-                    self._layer_decode(lw, x, ws, st["kc"][li], st["vc"][li], st)
-                ops.layernorm(x, self.norm, None, ws["h"], 1e-5, rms=True)
-                ops.linear(ws["h"], self.head, st["logits"])
+                self._forward_decode(st)
                 step_logits.append(st["logits"].clone())
                 self._sample(st)
             else:

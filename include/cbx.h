@@ -57,6 +57,23 @@ typedef struct cbx_gemm_t {
 } cbx_gemm_t;
 int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
 
+/* ---- skinny-M weight-streaming GEMM for decode (M = 2*B rows <= 64), HBM-roofline kernel ----
+ * out[ks][m][n] = sum_{k in slice ks} x[m][k] * W[n][k]  (+ bias on slice 0);  ksplit > 1 leaves partial sums that
+ * cbx_add_rmsnorm_f32 reduces in fixed order.  swiglu: W is the packed [32 gate | 32 up] image, N = #features,
+ * out[m][f] = silu(gate_f) * up_f.  Replaces the q_len == 1 HF Llama projections + speech head (t3.py:378-386). */
+typedef struct cbx_gemv_t {
+    const float* x; const float* W; const float* bias; float* out;
+    int M, N, K;
+    int ksplit;      /* K slices across workgroups (grid.y) */
+    int nw;          /* waves per workgroup sharing one 16-column tile: 4 or 8 */
+    int swiglu;
+    long ldx, ldw, ldo, part_stride;
+} cbx_gemv_t;
+int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
+/* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
+int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
+                        int rows, int C, long ldx, long ldh, float eps, void* stream);
+
 /* ---- normalisation (wavefront reductions, one wave per row) ----
  * LayerNorm / RMSNorm over the last dim (C <= 4096, C % 4 == 0):
  *   y = act( (x-mean)*rstd*w + b ) [+ post_add[c]] [* rowmask]            (nn.LayerNorm, HF LlamaRMSNorm)
@@ -115,6 +132,8 @@ typedef struct cbx_sampler_t {
                                   (temperature,top-k,top-p,penalty)  (t3.py:339-356 vs 396-404) */
     int ban_token;             /* probability forced to 0 (EOS ban for fixed-length runs) or -1 */
     int eos_token;
+    int ban_from;              /* ids >= ban_from (EOS included) get probability 0; 0 = off.  Synthetic random-weight
+                                  fixed-length runs use 6561 so that only valid S3 tokens are emitted */
     unsigned char* seen;       /* [B][V] 0/1 map of generated ids (repetition penalty) */
     const float* uniforms;     /* [B][max_steps] U[0,1): the injected RNG of torch.multinomial */
     int max_steps;

@@ -300,3 +300,36 @@ def test_hift_source_stft_istft(dev):
     _close(wav, wref, 1e-5, "istft")
     ops.hift_istft(xd, wav, fade_n=480)
     _close(wav, O.trim_fade(wref), 1e-5, "istft + trim_fade")
+
+
+@pytest.mark.parametrize("M,N,K,ks,nw", [(16, 3072, 1024, 1, 8), (16, 1024, 1024, 4, 4), (16, 1024, 4096, 8, 4), (16, 8194, 1024, 1, 4),
+                                         (2, 1024, 1024, 4, 4), (6, 64, 256, 1, 4), (40, 1024, 1024, 2, 4), (64, 3072, 1024, 1, 8)])
+def test_gemv_decode(dev, M, N, K, ks, nw):
+    from chatterbox_amd import ops
+    x, w, b = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3)
+    if ks == 1:
+        out = torch.empty(M, N, device=dev)
+        ops.gemv(x.to(dev), w.to(dev), out, bias=b.to(dev), nw=nw)
+        _close(out, F.linear(x, w, b), 3e-5 * math.sqrt(K / 256), "gemv")
+    else:
+        part = torch.empty(ks, M, N, device=dev)
+        ops.gemv(x.to(dev), w.to(dev), part, ksplit=ks, nw=nw)
+        _close(part.sum(0), F.linear(x, w), 3e-5 * math.sqrt(K / 256), "gemv split-K")
+        # consumer: residual + reduce + RMSNorm
+        from oracle import ref_torch as O
+        res, g = _r((M, N), 4), 1 + 0.1 * _r((N,), 5)
+        xr, h = res.clone().to(dev), torch.empty(M, N, device=dev)
+        ops.add_rmsnorm(xr, part, g.to(dev), h)
+        ref = res + F.linear(x, w)
+        _close(xr, ref, 3e-5 * math.sqrt(K / 256), "add (residual stream)")
+        _close(h, O.rms_norm(ref, g), 5e-5 * math.sqrt(K / 256), "rmsnorm of the sum")
+
+
+def test_gemv_swiglu(dev):
+    from chatterbox_amd import ops, weights
+    for M in (16, 33):
+        D, Fh = 1024, 512
+        x, g, u = _r((M, D), 1), _r((Fh, D), 2, 0.03), _r((Fh, D), 3, 0.03)
+        out = torch.empty(M, Fh, device=dev)
+        ops.gemv(x.to(dev), weights.pack_swiglu(g, u).to(dev), out, swiglu=True, nw=8)
+        _close(out, F.silu(F.linear(x, g)) * F.linear(x, u), 5e-5, "gemv swiglu")

@@ -237,6 +237,110 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Fused decode attention: RoPE(q,k) + KV-cache append + single-pass online-softmax attention, one workgroup per
+// (row, head).  Replaces three launches (rope_kv, decode_attn and their round trip through HBM) on the per-token
+// critical path.  Each 16-lane group owns one key row per step (float4 per lane = one 256-B K row and V row), four
+// steps are issued back to back so that 8 KiB of K/V per wave are in flight; the running (max, sum, acc) state of the
+// 16 lane groups is merged through LDS at the end.  The new token's k/v are taken from LDS (never re-read from HBM).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DA_U = 4;
+
+__global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
+                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                               float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
+                                                               int n_heads, long ld_qkv, long o_ld, long row_stride, long head_stride,
+                                                               float scale) {
+    __shared__ __attribute__((aligned(16))) float q_s[64], k_new[64], v_new[64];
+    __shared__ __attribute__((aligned(16))) float st_acc[16][64];
+    __shared__ float st_m[16], st_l[16];
+    const int row = blockIdx.y, head = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = lane >> 4, l16 = lane & 15;
+    const int pos = positions[row];
+    float* kb = kc + (long)row * row_stride + (long)head * head_stride;
+    float* vb = vc + (long)row * row_stride + (long)head * head_stride;
+    if (wid == 0) {
+        const float* qp = qkv + (long)row * ld_qkv + head * 64;
+        const float qv = qp[lane], kv = qp[(long)n_heads * 64 + lane], vv = qp[(long)n_heads * 128 + lane];
+        const float c = cos_t[(long)pos * 64 + lane], s = sin_t[(long)pos * 64 + lane];
+        const float sgn = lane < 32 ? -1.f : 1.f;
+        const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
+        const float kn = kv * c + sgn * __shfl_xor(kv, 32) * s;
+        q_s[lane] = qn * scale;
+        k_new[lane] = kn;
+        v_new[lane] = vv;
+        kb[(long)pos * 64 + lane] = kn;
+        vb[(long)pos * 64 + lane] = vv;
+    }
+    __syncthreads();
+    const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
+    const int ctx = pos + 1;
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // lane group g = wid*4 + sub handles positions g, g+16, g+32, ...
+    for (int p0 = wid * 4 + sub; p0 < ctx + 16 * (DA_U - 1); p0 += 16 * DA_U) {
+        f32x4 kv[DA_U], vv[DA_U];
+        bool ok[DA_U];
+#pragma unroll
+        for (int u = 0; u < DA_U; ++u) {
+            const int p = p0 + 16 * u;
+            ok[u] = p < ctx;
+            const int pc = ok[u] ? (p < pos ? p : 0) : 0;  // clamped: loads are unconditional (never the new position)
+            kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
+            vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
+            if (p == pos) {
+                kv[u] = *reinterpret_cast<const f32x4*>(&k_new[l16 * 4]);
+                vv[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
+            }
+        }
+        float d[DA_U];
+        float mt = m;
+#pragma unroll
+        for (int u = 0; u < DA_U; ++u) {
+            float t = kv[u][0] * qv4[0] + kv[u][1] * qv4[1] + kv[u][2] * qv4[2] + kv[u][3] * qv4[3];
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 1);
+            d[u] = ok[u] ? t : -INFINITY;
+            mt = fmaxf(mt, d[u]);
+        }
+        if (mt > -INFINITY) {
+            const float a = __expf(m - mt);
+            acc *= a;
+            l *= a;
+#pragma unroll
+            for (int u = 0; u < DA_U; ++u) {
+                const float pw = __expf(d[u] - mt);
+                l += pw;
+                acc += vv[u] * pw;
+            }
+            m = mt;
+        }
+    }
+    const int g = wid * 4 + sub;
+    *reinterpret_cast<f32x4*>(&st_acc[g][l16 * 4]) = acc;
+    if (l16 == 0) {
+        st_m[g] = m;
+        st_l[g] = l;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float M = st_m[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) M = fmaxf(M, st_m[i]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float f = st_m[i] > -INFINITY ? __expf(st_m[i] - M) : 0.f;
+            num += f * st_acc[i][tid];
+            den += f * st_l[i];
+        }
+        o[(long)row * o_ld + head * 64 + tid] = num / den;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Conformer rel-pos softmax over materialised scores: one wave per query row.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_relpos_kernel(const float* __restrict__ ac, const float* __restrict__ bd,
@@ -297,6 +401,16 @@ extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float*
     hipLaunchKernelGGL(decode_attn_f32_kernel, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, q, kc, vc, o,
                        ctx_lens, q_ld, o_ld, cache_row_stride, cache_head_stride, scale);
     return cbx_check_launch("decode_attn");
+}
+
+extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
+                                        float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld,
+                                        long cache_row_stride, long cache_head_stride, float scale, void* stream) {
+    CBX_REQUIRE(qkv && positions && cos_t && sin_t && kc && vc && o, "decode_attn_rope: null operand");
+    CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
+    hipLaunchKernelGGL(decode_attn_rope_kernel, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
+                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
+    return cbx_check_launch("decode_attn_rope");
 }
 
 extern "C" int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int* key_lens, int nz1, int nz2,

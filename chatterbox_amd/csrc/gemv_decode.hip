@@ -139,34 +139,51 @@ int launch_mt(const cbx_gemv_t& p, hipStream_t st) {
     return cbx_set_error(CBX_EINVAL, "gemv: M=%d > 64", p.M);
 }
 
-// x[row] += sum_ks partial[ks][row]  (fixed order);  h[row] = rmsnorm(x[row]) * w     -- one wave per row
+// x[row] += sum_ks partial[ks][row]  (fixed order);  h[row] = rmsnorm(x[row]) * w.
+// One 256-thread workgroup per row, one float4 (x up to 4) per thread, all partial loads issued before the first add:
+// the op is pure latency (16..64 rows), so the only lever is memory-level parallelism.
+constexpr int AR_MAXKS = 8;
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float* __restrict__ part, int ksplit, long part_stride,
                                                           long ldp, const float* __restrict__ w, float* __restrict__ h, int rows,
                                                           int C, long ldx, long ldh, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = C >> 2;
     float* xr = x + (long)row * ldx;
-    f32x4 v[16];
+    f32x4 v[4];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int c4 = i * 64 + lane;
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = i * 256 + tid;
         if (c4 < nv) {
             f32x4 t = *reinterpret_cast<const f32x4*>(xr + c4 * 4);
-            for (int k = 0; k < ksplit; ++k) t += *reinterpret_cast<const f32x4*>(part + k * part_stride + (long)row * ldp + c4 * 4);
+            if (ksplit > 0) {  // unconditional loads from a clamped slice index: every load is in flight before the first add
+                f32x4 pk[AR_MAXKS];
+#pragma unroll
+                for (int k = 0; k < AR_MAXKS; ++k) {
+                    const int kk = k < ksplit ? k : ksplit - 1;
+                    pk[k] = *reinterpret_cast<const f32x4*>(part + kk * part_stride + (long)row * ldp + c4 * 4);
+                }
+#pragma unroll
+                for (int k = 0; k < AR_MAXKS; ++k) {
+                    const float on = k < ksplit ? 1.0f : 0.0f;
+                    t += pk[k] * on;
+                }
+            }
             v[i] = t;
-            *reinterpret_cast<f32x4*>(xr + c4 * 4) = t;
+            if (ksplit > 0) *reinterpret_cast<f32x4*>(xr + c4 * 4) = t;
             ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
         }
     }
     ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = (red[0] + red[1]) + (red[2] + red[3]);
     const float rstd = rsqrtf(ss / C + eps);
     float* hr = h + (long)row * ldh;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int c4 = i * 64 + lane;
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = i * 256 + tid;
         if (c4 < nv) {
             f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4 * 4);
             f32x4 o = {v[i][0] * rstd * wv[0], v[i][1] * rstd * wv[1], v[i][2] * rstd * wv[2], v[i][3] * rstd * wv[3]};
@@ -193,7 +210,8 @@ extern "C" int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long
                                    int rows, int C, long ldx, long ldh, float eps, void* stream) {
     CBX_REQUIRE(x && w && h && (ksplit == 0 || part), "add_rmsnorm: null operand");
     CBX_REQUIRE(C % 4 == 0 && C <= 4096 && ldx % 4 == 0 && ldh % 4 == 0 && ldp % 4 == 0 && part_stride % 4 == 0, "add_rmsnorm: alignment");
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, part, ksplit, part_stride, ldp,
+    CBX_REQUIRE(ksplit >= 0 && ksplit <= AR_MAXKS, "add_rmsnorm: ksplit=%d > %d", ksplit, AR_MAXKS);
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, part, ksplit, part_stride, ldp,
                        w, h, rows, C, ldx, ldh, eps);
     return cbx_check_launch("add_rmsnorm");
 }

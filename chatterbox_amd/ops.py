@@ -183,6 +183,15 @@ def decode_attn(q, kc, vc, out, ctx_lens, scale):
     return out
 
 
+def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale):
+    """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)."""
+    rows, H = kc.shape[0], kc.shape[1]
+    check(lib.cbx_decode_attn_rope_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out), rows, H,
+                                       qkv.stride(0), out.stride(0), kc.stride(0), kc.stride(1), scale, _stream()),
+          "cbx_decode_attn_rope_f32")
+    return out
+
+
 def softmax_relpos(ac, bd, p, scale, key_lens=None):
     """ac (Z1,Z2,Tq,>=Tk), bd (Z1,Z2,Tq,>=2Tk-1) or None, p (Z1,Z2,Tq,ld_p) (pad columns written as 0)."""
     Z1, Z2, Tq = ac.shape[:3]

@@ -134,8 +134,7 @@ class T3Engine:
         for i, lw in enumerate(self.layers):
             ops.add_rmsnorm(x, part, lw["ln1"], h)
             ops.gemv(h, lw["wqkv"], qkv, nw=8)
-            ops.rope_kv(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], self.H)
-            ops.decode_attn(qkv, st["kc"][i], st["vc"][i], att, st["ctx_lens"], 0.125)
+            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125)
             ops.gemv(att, lw["wo"], po, ksplit=4, nw=4)
             ops.add_rmsnorm(x, po, lw["ln2"], h)
             ops.gemv(h, lw["wgu"], g, swiglu=True, nw=8)

@@ -97,6 +97,12 @@ int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float*
                         int rows, int n_heads, long q_ld, long o_ld, long cache_row_stride, long cache_head_stride,
                         float scale, void* stream);
 
+/* Fused per-token attention of the decode loop: HF apply_rotary_pos_emb on q,k of the fused qkv row (head_dim 64,
+ * rotate_half form) + DynamicCache append at positions[row] + sdpa over positions [0, positions[row]] (t3.py:378-384). */
+int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
+                             float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, long cache_row_stride,
+                             long cache_head_stride, float scale, void* stream);
+
 /* Row softmax over materialised scores with optional relative-position term and key mask
  * (RelPositionMultiHeadedAttention.forward, transformer/attention.py:249-330):
  *   p[z][i][j] = softmax_j( scale*(ac[z][i][j] + bd[z][i][T-1-i+j]) ), keys j >= key_lens[z1] -> 0. */

@@ -333,3 +333,27 @@ def test_gemv_swiglu(dev):
         out = torch.empty(M, Fh, device=dev)
         ops.gemv(x.to(dev), weights.pack_swiglu(g, u).to(dev), out, swiglu=True, nw=8)
         _close(out, F.silu(F.linear(x, g)) * F.linear(x, u), 5e-5, "gemv swiglu")
+
+
+def test_decode_attn_rope_fused(dev):
+    """Fused RoPE + cache append + attention == rope_kv followed by decode_attn == oracle."""
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    rows, H, maxp = 6, 16, 512
+    kc0, vc0, qkv = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2), _r((rows, 3 * H * 64), 3)
+    pos = torch.tensor([0, 4, 63, 128, 300, 511], dtype=torch.int32)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.empty(rows, H * 64, device=dev)
+    ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cos.to(dev), sin.to(dev), kc, vc, out, 0.125)
+    q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
+    c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
+    qr, kr = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
+    for r in range(rows):
+        n = int(pos[r])
+        kk = torch.cat([kc0[r, :, :n], kr[r][:, None]], 1)
+        vv = torch.cat([vc0[r, :, :n], v[r][:, None]], 1)
+        ref = F.scaled_dot_product_attention(qr[r].view(H, 1, 64), kk, vv)
+        _close(out[r].view(H, 64), ref[:, 0], 2e-5, f"fused decode attention row {r}")
+        _close(kc[r, :, n], kr[r], 1e-6, "k appended")
+        _close(vc[r, :, n], v[r], 0.0, "v appended")
+        _close(kc[r, :, :n], kc0[r, :, :n], 0.0, "cache untouched")

@@ -1,0 +1,77 @@
+"""CPU (-m "not gpu"): the oracle restatement (oracle/ref_torch.py) against the golden vectors that
+tests/golden/make_golden.py produced by running the UNMODIFIED reference.  This is what pins the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chatterbox_amd import synth
+from oracle import ref_torch as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SAMP = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+
+
+def _fp(sd):
+    keys = sorted(sd)[:: max(1, len(sd) // 16)]
+    return np.array([float(sd[k].double().sum()) for k in keys])
+
+
+@pytest.mark.parametrize("name", ["t3_l2", "t3_l30"])
+def test_t3_oracle_matches_reference(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    L, steps, n_text = int(g["n_layers"]), int(g["steps"]), int(g["n_text"])
+    sd = synth.t3_state_dict(L, 0)
+    np.testing.assert_allclose(_fp(sd), g["fp"], rtol=1e-9)
+    tt = synth.text_tokens(n_text)
+    with torch.inference_mode():
+        toks, logits = O.t3_inference(sd, L, synth.t3_cond(), torch.stack([tt, tt]), steps, torch.from_numpy(g["uniforms"]),
+                                      ban_eos=True, return_logits=True, **SAMP)
+    idx = torch.from_numpy(g["logit_idx"]).long()
+    err = (logits[:, :, idx] - torch.from_numpy(g["logits_sub"])).abs().max().item()
+    assert err < 1e-4, err
+    assert toks.tolist() == g["tokens"].tolist()
+
+
+def test_s3gen_oracle_matches_reference():
+    g = np.load(os.path.join(GOLD, "s3gen_small.npz"))
+    P, N = int(g["P"]), int(g["N"])
+    sd = synth.s3gen_state_dict(0)
+    np.testing.assert_allclose(_fp(sd), g["fp"], rtol=1e-9)
+    ref = synth.s3gen_ref(n_prompt_tokens=P)
+    toks = synth.speech_tokens(N)[None]
+    z = synth.randn((1, 80, 2 * (P + N)), seed=5)
+    phase = (synth.rand((1, 9, 1), seed=6) * 2 - 1) * math.pi
+    phase[:, 0] = 0
+    noise = synth.randn((1, 9, 960 * N), seed=6)
+    with torch.inference_mode():
+        wav, mel = O.s3gen_inference(sd, toks, torch.tensor([N]), ref, z, phase, noise, int(g["n_steps"]))
+        gm = torch.from_numpy(g["mel"])
+        assert (mel[0] - gm).abs().mean() < 1e-5
+        # vocoder on the reference's own mel (removes the F0 phase-drift amplification of mel rounding)
+        w2, src = O.hift_inference(sd, gm[None], phase, noise)
+    gw = torch.from_numpy(g["wav"])
+    assert (O.trim_fade(w2)[0] - gw).pow(2).mean().sqrt() < 1e-4
+    assert (src[0, 0, ::7] - torch.from_numpy(g["src"])).abs().max() < 1e-3
+    assert (wav[0] - gw).pow(2).mean().sqrt() < 1e-3
+
+
+def test_sampler_semantics_match_hf_processors():
+    """process_logits restates the HF logits processors the reference calls (t3.py:320-356)."""
+    from transformers.generation.logits_process import (MinPLogitsWarper, RepetitionPenaltyLogitsProcessor,
+                                                        TopPLogitsWarper)
+    g = torch.Generator().manual_seed(0)
+    for top_p, min_p in ((1.0, 0.05), (0.9, 0.02), (0.7, 0.0)):
+        c, u = torch.randn(8194, generator=g) * 2, torch.randn(8194, generator=g) * 2
+        ids = torch.randint(0, 8194, (1, 40), generator=g)
+        l = (c + 0.5 * (c - u))[None]
+        l = RepetitionPenaltyLogitsProcessor(1.2)(ids, l) / 0.8
+        if min_p > 0:
+            l = MinPLogitsWarper(min_p)(ids, l)
+        l = TopPLogitsWarper(top_p)(ids, l)
+        mine = O.process_logits(c, u, ids[0], 0.5, 0.8, min_p, top_p, 1.2)
+        assert torch.equal(torch.isinf(mine), torch.isinf(l[0]))
+        keep = ~torch.isinf(mine)
+        assert torch.allclose(mine[keep], l[0][keep], atol=1e-6)

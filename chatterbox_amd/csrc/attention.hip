@@ -1,5 +1,6 @@
 // Attention kernels (fp32 exact): flash-style tiled attention on v_mfma_f32_32x32x2_f32, single-query decode
 // attention streaming the KV cache, and the materialised rel-pos softmax of the conformer encoder.
+#include <stdlib.h>
 #include "cbx_common.h"
 
 namespace {
@@ -26,6 +27,7 @@ struct FlashArgs {
     int causal;  // 0 = none; else key j allowed iff j <= i + (Tk - Tq)
 };
 
+template <bool PREFETCH>
 __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
@@ -65,26 +67,34 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
     if (a.causal) kend = min(kend, q0 + 128 + coff);  // keys beyond the block's last query are never visible
     const int ld_row = tid >> 2, ld_c = (tid & 3) * 16;
 
-    for (int j0 = 0; j0 < kend; j0 += KT) {
-        // ---- stage K/V tile (64 keys x 64 d each)
-        {
-            const int j = j0 + ld_row;
-            const bool ok = j < klen;
-            const float* kp = kb + (long)(ok ? j : 0) * a.k_st + ld_c;
-            const float* vp = vb + (long)(ok ? j : 0) * a.v_st + ld_c;
+    // K/V staging: the next tile's 8 float4 per thread are fetched into registers while the current tile is consumed
+    f32x4 kreg[4], vreg[4];
+    auto fetch = [&](int j0) {
+        const int j = j0 + ld_row;
+        const bool ok = j < klen;
+        const float* kp = kb + (long)(ok ? j : 0) * a.k_st + ld_c;
+        const float* vp = vb + (long)(ok ? j : 0) * a.v_st + ld_c;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
-                    vv = *reinterpret_cast<const f32x4*>(vp + c * 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Ks[ld_row * K_LD + ld_c + c * 4 + e] = kv[e];
-                *reinterpret_cast<f32x4*>(&Vs[ld_row * V_LD + ld_c + c * 4]) = vv;
-            }
+        for (int c = 0; c < 4; ++c) {
+            kreg[c] = ok ? *reinterpret_cast<const f32x4*>(kp + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vreg[c] = ok ? *reinterpret_cast<const f32x4*>(vp + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ks[ld_row * K_LD + ld_c + c * 4 + e] = kreg[c][e];
+            *reinterpret_cast<f32x4*>(&Vs[ld_row * V_LD + ld_c + c * 4]) = vreg[c];
+        }
+    };
+    if (PREFETCH && kend > 0) fetch(0);
+
+    for (int j0 = 0; j0 < kend; j0 += KT) {
+        if (!PREFETCH) fetch(j0);
+        stage();
         __syncthreads();
+        if (PREFETCH && j0 + KT < kend) fetch(j0 + KT);
 
         // ---- S^T = K Q^T  (2 sub-tiles of 32 keys)
         f32x16 st[2];
@@ -389,7 +399,12 @@ extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v
     CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn: 16-byte alignment");
     FlashArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
-    hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    static const int prefetch = getenv("CBX_FLASH_PREFETCH") ? atoi(getenv("CBX_FLASH_PREFETCH")) : 1;
+    if (prefetch) {
+        hipLaunchKernelGGL(flash_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(flash_attn_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     return cbx_check_launch("flash_attn");
 }
 

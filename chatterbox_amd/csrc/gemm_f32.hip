@@ -12,6 +12,7 @@
 // for output row m is (m*stride + j*dil - pad_left)/up, zero outside [0, min(Tin, lens[z1])) -- that single
 // address generator gives Linear, Conv1d (any stride/dilation/padding, causal or not), nearest-upsample+conv,
 // phase-packed ConvTranspose1d and ragged-batch masking without ever materialising im2col.
+#include <stdlib.h>
 #include "cbx_common.h"
 
 namespace {
@@ -41,57 +42,57 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const cbx_gemm_t p) {
     const int lim = p.lens ? min(p.Tin, p.lens[z1]) : p.Tin;
     const int K = p.K;
 
-    // ---- per-thread loader state
+    // ---- per-thread loader state.  Everything that does not change along K is folded into base pointers; the K walk
+    // itself is incremental (column offset + tap counter), so a tile costs a handful of integer ops per load.
     const int a_c4 = (tid & 3) * 4;
-    int a_base[A_IT];
+    const float* a_ptr[A_IT];   // row pointer at tap 0, column a_c4
+    int a_row[A_IT];            // input row at tap 0 (may be negative: left padding)
     bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        int m = m0 + (tid >> 2) + 64 * i;
+        const int m = m0 + (tid >> 2) + 64 * i;
         a_ok[i] = m < p.M && (!A_PART || (tid >> 2) + 64 * i < BM);
-        a_base[i] = m * p.stride - p.pad_left;
+        a_row[i] = m * p.stride - p.pad_left;
+        a_ptr[i] = Ab + (long)a_row[i] * p.lda + a_c4;
     }
+    const float* b_ptr[B_IT];
+    bool b_ok[B_IT];
+    if constexpr (!W_KN) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + (tid >> 2) + 64 * i;
+            b_ok[i] = n < p.N;
+            b_ptr[i] = Wb + (long)(b_ok[i] ? n : 0) * p.ldw + a_c4;
+        }
+    }
+    int ld_tap = 0, ld_c0 = 0;          // tap / channel offset of the NEXT tile to load
+    long ld_aoff = 0;                   // = ld_tap*dil*lda + ld_c0
+    const long tap_step = (long)p.dil * p.lda - p.Cin;
     f32x4 ra[A_IT], rb[B_IT];
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
-        int tap = 0, c0 = k0;
-        if (p.taps > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
         const int kk = k0 + a_c4;
+        const bool kfull = (k0 + BK) <= K;  // wave-uniform: only the last tile of a ragged K takes the guarded path
+        const int tap_rows = ld_tap * p.dil;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            int rr = a_base[i] + tap * p.dil;
-            bool ok = a_ok[i] && rr >= 0;
-            int row = (p.up > 1) ? (rr / p.up) : rr;
-            ok = ok && row < lim;
+            const int rr = a_row[i] + tap_rows;
+            bool ok = a_ok[i] && rr >= 0 && (kfull || kk < K);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float* src = Ab + (long)row * p.lda + c0 + a_c4;
-                if (kk + 3 < K) {
-                    v = *reinterpret_cast<const f32x4*>(src);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (kk + e < K) v[e] = src[e];
-                }
+            if (p.up > 1) {  // nearest-neighbour upsampled input (conformer Upsample1D): row index is not linear in the tap
+                const int row = rr / p.up;
+                if (ok && row < lim) v = *reinterpret_cast<const f32x4*>(Ab + (long)row * p.lda + ld_c0 + a_c4);
+            } else {
+                if (ok && rr < lim) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_aoff);
             }
             ra[i] = v;
         }
         if constexpr (!W_KN) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                int n = n0 + (tid >> 2) + 64 * i;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.N) {
-                    const float* src = Wb + (long)n * p.ldw + kk;
-                    if (kk + 3 < K) {
-                        v = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (kk + e < K) v[e] = src[e];
-                    }
-                }
+                if (b_ok[i] && (kfull || kk < K)) v = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
                 rb[i] = v;
             }
         } else {
@@ -114,6 +115,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const cbx_gemm_t p) {
                 }
                 rb[i] = v;
             }
+        }
+        // advance the K walk
+        ld_c0 += BK;
+        ld_aoff += BK;
+        if (p.taps > 1 && ld_c0 >= p.Cin) {
+            ld_c0 = 0;
+            ld_tap += 1;
+            ld_aoff += tap_step;
         }
     };
 
@@ -263,5 +272,17 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     }
     if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
     if (p.N <= 64) return launch<128, 64, 2, 2, false>(p, st);
+    {
+        // 256 CUs: a grid below ~2 workgroups per CU leaves each SIMD with a single in-order wave (no latency hiding)
+        static const int force = getenv("CBX_GEMM_TILE") ? atoi(getenv("CBX_GEMM_TILE")) : 0;
+        const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
+        // measured on the CFM / HiFT shapes (bench.py, MI355X): 64x64 tiles 492 ms per flow pass, 128x64 543, 64x128 536,
+        // 128x128 803 -- the single-stage pipeline needs many co-resident waves to hide its load->LDS->barrier latency
+        (void)g128;
+        if (force == 128) return launch<128, 128, 2, 2, false>(p, st);
+        if (force == 64128) return launch<64, 128, 2, 2, false>(p, st);
+        if (force == 64) return launch<128, 64, 2, 2, false>(p, st);
+        return launch<64, 64, 2, 2, false>(p, st);
+    }
     return launch<128, 128, 2, 2, false>(p, st);
 }

@@ -33,6 +33,8 @@ const char* cbx_last_error(void);
  *   transformer-block linears (models/s3gen/decoder.py:243-333, matcha/transformer.py:243-316), conformer
  *   encoder linears/convs (transformer/upsample_encoder.py:237-304), HiFT convs (hifigan.py:412-444).
  * z = z1*nz2 + z2 (two-level batch: e.g. utterance row, attention head).
+ * K is walked in float4 units: K % 4 == 0, except with w_kn where A only has to be readable and finite up to the next
+ * multiple of 4 (W rows >= K read as zero).
  */
 typedef struct cbx_gemm_t {
     const float* A; const float* W; float* C;

@@ -35,7 +35,7 @@ class GemmParams(ctypes.Structure):
 
 class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
-                ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
+                ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long)]
 
 
@@ -55,6 +55,7 @@ _SIGS = {
     "cbx_last_error": ([], ctypes.c_char_p),
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
+    "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),

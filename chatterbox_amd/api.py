@@ -16,8 +16,8 @@ from typing import Optional
 import torch
 
 from . import synth
-from .engine import ChatterboxEngine
-from .text import EnTokenizer, MTLTokenizer, punc_norm
+from .engine import ChatterboxEngine, TurboEngine
+from .text import EnTokenizer, MTLTokenizer, punc_norm, punc_norm_turbo
 
 S3GEN_SR, S3_SR = 24000, 16000
 REPO_ID = "ResembleAI/chatterbox"
@@ -212,6 +212,68 @@ class ChatterboxMultilingualTTS(_Base):
         toks = self.tokenizer.text_to_tokens(punc_norm(text), language_id=language_id.lower() if language_id else None)
         return self._generate(toks, drop_last_token=True, temperature=temperature, cfg_weight=cfg_weight,
                               repetition_penalty=repetition_penalty, min_p=min_p, top_p=top_p)
+
+
+class ChatterboxTurboTTS:
+    """Reference tts_turbo.py:111-320: GPT2-medium (Turbo) or GPT2-small (Nano) T3, meanflow S3Gen, GPT-2 BPE tokenizer."""
+    sr = S3GEN_SR
+
+    def __init__(self, engine, tokenizer, device, conds=None, model_label="Turbo"):
+        self.engine, self.tokenizer, self.device, self.conds, self.model_label = engine, tokenizer, device, conds, model_label
+        self.t3, self.s3gen, self.ve = engine.t3, engine, None
+        self.watermarker = _watermarker()
+
+    @classmethod
+    def from_local(cls, ckpt_dir, device, nano=False):
+        d = Path(ckpt_dir)
+        t3_sd = _load_state(d / ("t3_nano_v1.safetensors" if nano else "t3_turbo_v1.safetensors"))
+        t3_sd.pop("tfmr.wte.weight", None)  # present in the file, unused (reference deletes it after loading, tts_turbo.py:167)
+        eng = TurboEngine(t3_sd, _load_state(d / "s3gen_meanflow.safetensors"), device)
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(str(d))
+        if tok.pad_token is None:
+            tok.pad_token = tok.eos_token
+        conds = Conditionals.load(d / "conds.pt") if (d / "conds.pt").exists() else None
+        return cls(eng, tok, device, conds, "Nano" if nano else "Turbo")
+
+    @classmethod
+    def from_pretrained(cls, device, nano=False):
+        from huggingface_hub import snapshot_download
+        d = snapshot_download(repo_id="ResembleAI/chatterbox-nano" if nano else "ResembleAI/chatterbox-turbo", token=os.getenv("HF_TOKEN"),
+                              allow_patterns=["*.safetensors", "*.json", "*.txt", "*.pt", "*.model"])
+        return cls.from_local(d, device, nano=nano)
+
+    @classmethod
+    def from_synthetic(cls, device="cuda", seed=0, nano=False, t3_layers=None):
+        dmodel, layers = (768, 12) if nano else (1024, 24)
+        layers = t3_layers or layers
+        eng = TurboEngine(synth.t3_turbo_state_dict(layers, dmodel, seed), synth.s3gen_state_dict(seed, meanflow=True), device,
+                          n_t3_layers=layers)
+        c = synth.t3_cond(prompt_len=375)
+        return cls(eng, None, device, Conditionals(T3Cond(speaker_emb=c["speaker_emb"], cond_prompt_speech_tokens=c["cond_prompt_speech_tokens"],
+                                                          emotion_adv=None), synth.s3gen_ref()), "Nano" if nano else "Turbo")
+
+    def prepare_conditionals(self, wav_fpath, exaggeration=0.0, norm_loudness=True):
+        raise NotImplementedError("voice-prompt analysis is a 'next' row (SURVEY.md 8f N1/N2): load conds.pt instead")
+
+    def _generate(self, text_tokens, **samp):
+        wavs, _ = self.engine.synthesize([text_tokens.view(-1).long().cpu()], self.conds.t3.as_dict(), self.conds.gen, **samp)
+        wav = wavs[0].detach().float().cpu()
+        if self.watermarker is not None:
+            wav = torch.from_numpy(self.watermarker.apply_watermark(wav.numpy(), sample_rate=self.sr))
+        return wav.unsqueeze(0)
+
+    def generate(self, text, repetition_penalty=1.2, min_p=0.00, top_p=0.95, audio_prompt_path=None, exaggeration=0.0, cfg_weight=0.0,
+                 temperature=0.8, top_k=1000, norm_loudness=True):
+        if audio_prompt_path:
+            self.prepare_conditionals(audio_prompt_path, exaggeration=exaggeration, norm_loudness=norm_loudness)
+        else:
+            assert self.conds is not None, "Please `prepare_conditionals` first or specify `audio_prompt_path`"
+        if cfg_weight > 0.0 or exaggeration > 0.0 or min_p > 0.0:
+            import logging
+            logging.getLogger(__name__).warning(f"CFG, min_p and exaggeration are not supported by the {self.model_label} version and will be ignored.")
+        ids = self.tokenizer(punc_norm_turbo(text), return_tensors="pt", padding=True, truncation=True).input_ids
+        return self._generate(ids[0], temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty)
 
 
 class ChatterboxVC:

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     if (wid == 0) {
         const float* qp = qkv + (long)row * ld_qkv + head * 64;
         const float qv = qp[lane], kv = qp[(long)n_heads * 64 + lane], vv = qp[(long)n_heads * 128 + lane];
-        const float c = cos_t[(long)pos * 64 + lane], s = sin_t[(long)pos * 64 + lane];
+        const float c = cos_t ? cos_t[(long)pos * 64 + lane] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + lane] : 0.f;  // GPT-2: no RoPE
         const float sgn = lane < 32 ? -1.f : 1.f;
         const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
         const float kn = kv * c + sgn * __shfl_xor(kv, 32) * s;
@@ -421,7 +421,7 @@ extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float*
 extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                                         float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld,
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
-    CBX_REQUIRE(qkv && positions && cos_t && sin_t && kc && vc && o, "decode_attn_rope: null operand");
+    CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
     hipLaunchKernelGGL(decode_attn_rope_kernel, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
                        kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* qkv, const int* __r
     const long r = w / n_heads;
     const int h = (int)(w - r * n_heads), d = threadIdx.x & 63;
     const int pos = positions[r];
-    const float c = cos_t[(long)pos * 64 + d], s = sin_t[(long)pos * 64 + d];
+    const float c = cos_t ? cos_t[(long)pos * 64 + d] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + d] : 0.f;  // NULL tables: GPT-2, no RoPE
     float* qp = qkv + r * ld_qkv + h * 64;
     float* kp = qp + (long)n_heads * 64;
     const float* vp = kp + (long)n_heads * 64;
@@ -151,7 +151,7 @@ extern "C" int cbx_embed_f32(const long long* ids, const float* table, const flo
 extern "C" int cbx_rope_kv_f32(float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                                float* vc, const int* cache_rows, long n_rows, int n_heads, long ld_qkv,
                                long cache_row_stride, long cache_head_stride, void* stream) {
-    CBX_REQUIRE(qkv && positions && cos_t && sin_t, "rope_kv: null");
+    CBX_REQUIRE(qkv && positions && (!cos_t == !sin_t), "rope_kv: null");
     if (n_rows <= 0) return 0;
     long waves = n_rows * n_heads;
     hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, qkv, positions,

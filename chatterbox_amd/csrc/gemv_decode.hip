@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int DEPTH = (MT == 1 && !SWIGLU) ? 4 : 2;
+    constexpr int DEPTH = (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int it0 = 0; it0 < nit; it0 += DEPTH) {
@@ -110,8 +110,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         }
         if constexpr (SWIGLU) {
             v = (v / (1.0f + __expf(-v))) * v2;
-        } else if (p.bias && ks == 0) {
-            v += p.bias[n];
+        } else {
+            if (p.bias && ks == 0) v += p.bias[n];
+            if (p.act) v = cbx_act(v, p.act, 0.f, 0.f);  // only meaningful with ksplit == 1
         }
         p.out[(long)ks * p.part_stride + (long)m * p.ldo + n] = v;
     }
@@ -144,8 +145,9 @@ int launch_mt(const cbx_gemv_t& p, hipStream_t st) {
 // the op is pure latency (16..64 rows), so the only lever is memory-level parallelism.
 constexpr int AR_MAXKS = 8;
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float* __restrict__ part, int ksplit, long part_stride,
-                                                          long ldp, const float* __restrict__ w, float* __restrict__ h, int rows,
-                                                          int C, long ldx, long ldh, float eps) {
+                                                          long ldp, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ h, int rows, int C, long ldx, long ldh, float eps,
+                                                          int rms) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = C >> 2;
@@ -175,6 +177,28 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float*
             ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
         }
     }
+    float mean = 0.f;
+    if (!rms) {  // LayerNorm (GPT-2): two-pass mean / variance over the row held in registers
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 256 + tid < nv) sm += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        sm = wave_sum(sm);
+        if ((tid & 63) == 0) red[tid >> 6] = sm;
+        __syncthreads();
+        mean = ((red[0] + red[1]) + (red[2] + red[3])) / C;
+        __syncthreads();
+        ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 256 + tid < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mean;
+                    ss += d * d;
+                }
+            }
+    }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
@@ -186,7 +210,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float*
         const int c4 = i * 256 + tid;
         if (c4 < nv) {
             f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4 * 4);
-            f32x4 o = {v[i][0] * rstd * wv[0], v[i][1] * rstd * wv[1], v[i][2] * rstd * wv[2], v[i][3] * rstd * wv[3]};
+            f32x4 bv = b ? *reinterpret_cast<const f32x4*>(b + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
             *reinterpret_cast<f32x4*>(hr + c4 * 4) = o;
         }
     }
@@ -203,15 +230,24 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);
     CBX_REQUIRE(p.ldx % 4 == 0 && p.ldw % 4 == 0 && (((uintptr_t)p.x | (uintptr_t)p.W) & 15) == 0, "gemv: alignment");
     CBX_REQUIRE(!p.swiglu || (p.ksplit == 1 && p.N % 32 == 0), "gemv: swiglu needs ksplit == 1 and N %% 32 == 0");
+    CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
     return p.swiglu ? launch_mt<true>(p, (hipStream_t)stream) : launch_mt<false>(p, (hipStream_t)stream);
 }
 
+extern "C" int cbx_add_norm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, const float* b,
+                                float* h, int rows, int C, long ldx, long ldh, float eps, int rms, void* stream);
+
 extern "C" int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
                                    int rows, int C, long ldx, long ldh, float eps, void* stream) {
+    return cbx_add_norm_f32(x, part, ksplit, part_stride, ldp, w, nullptr, h, rows, C, ldx, ldh, eps, 1, stream);
+}
+
+extern "C" int cbx_add_norm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, const float* b,
+                                float* h, int rows, int C, long ldx, long ldh, float eps, int rms, void* stream) {
     CBX_REQUIRE(x && w && h && (ksplit == 0 || part), "add_rmsnorm: null operand");
     CBX_REQUIRE(C % 4 == 0 && C <= 4096 && ldx % 4 == 0 && ldh % 4 == 0 && ldp % 4 == 0 && part_stride % 4 == 0, "add_rmsnorm: alignment");
     CBX_REQUIRE(ksplit >= 0 && ksplit <= AR_MAXKS, "add_rmsnorm: ksplit=%d > %d", ksplit, AR_MAXKS);
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, part, ksplit, part_stride, ldp,
-                       w, h, rows, C, ldx, ldh, eps);
+                       w, b, h, rows, C, ldx, ldh, eps, rms);
     return cbx_check_launch("add_rmsnorm");
 }

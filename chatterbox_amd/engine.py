@@ -80,3 +80,35 @@ class ChatterboxEngine:
                               drop_last_token=drop_last_token)
         self.last_timing["total_s"] = time.perf_counter() - t0
         return wavs, st
+
+
+S3GEN_SIL = 4299  # reference models/s3gen/const.py:2
+
+
+class TurboEngine:
+    """ChatterboxTurboTTS hot path (reference tts_turbo.py:298-317): GPT-2 T3 (no CFG) -> ids < 6561 + 3 silence tokens ->
+    2-step meanflow S3Gen (no CFG) -> HiFT."""
+
+    def __init__(self, t3_sd, s3gen_sd, device="cuda", n_t3_layers=None):
+        from .t3_turbo import T3TurboEngine
+        self.dev = torch.device(device)
+        self.t3 = T3TurboEngine(t3_sd, self.dev, n_layers=n_t3_layers)
+        self.flow = FlowEngine(s3gen_sd, self.dev, meanflow=True)
+        self.hift = HiFTEngine(s3gen_sd, self.dev)
+        self.last_timing = {}
+
+    vocode = ChatterboxEngine.vocode
+
+    @torch.inference_mode()
+    def synthesize(self, text_tokens, t3_conds, gen_ref, *, max_gen_len=1000, temperature=0.8, top_k=1000, top_p=0.95,
+                   repetition_penalty=1.2, uniforms=None, ban_eos=False, ban_from=0, z=None, phase=None, noise=None):
+        t0 = time.perf_counter()
+        toks = self.t3.generate(t3_conds, text_tokens, max_gen_len=max_gen_len, temperature=temperature, top_k=top_k, top_p=top_p,
+                                repetition_penalty=repetition_penalty, uniforms=uniforms, ban_eos=ban_eos, ban_from=ban_from)
+        torch.cuda.synchronize()
+        self.last_timing = dict(t3_s=time.perf_counter() - t0)
+        sil = torch.full((3,), S3GEN_SIL, dtype=torch.long)
+        st = [torch.cat([t[t < SPEECH_VOCAB], sil]) for t in toks]
+        wavs, _ = self.vocode(st, gen_ref, z=z, phase=phase, noise=noise, n_cfm_timesteps=2, drop_last_token=False)
+        self.last_timing["total_s"] = time.perf_counter() - t0
+        return wavs, st

@@ -125,13 +125,13 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
-def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False):
+def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials."""
     M, K = x.shape
     N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
     p = GemvParams()
     p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
-    p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu = M, N, K, ksplit, nw, int(swiglu)
+    p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu, p.act = M, N, K, ksplit, nw, int(swiglu), act
     p.ldx, p.ldw = x.stride(0), w.stride(0)
     if ksplit > 1:
         assert out.dim() == 3 and out.shape[0] == ksplit
@@ -143,12 +143,12 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False):
     return out
 
 
-def add_rmsnorm(x, part, w, h, eps=1e-5):
-    """x += sum_k part[k]; h = rmsnorm(x) * w.   part (ksplit, rows, C) or None."""
+def add_rmsnorm(x, part, w, h, eps=1e-5, bias=None, rms=True):
+    """x += sum_k part[k]; h = rmsnorm(x) * w  (rms=False: LayerNorm with bias).   part (ksplit, rows, C) or None."""
     rows, C = x.shape
     ks = 0 if part is None else part.shape[0]
-    check(lib.cbx_add_rmsnorm_f32(_p(x), _p(part), ks, 0 if part is None else part.stride(0), 0 if part is None else part.stride(1),
-                                  _p(w), _p(h), rows, C, x.stride(0), h.stride(0), eps, _stream()), "cbx_add_rmsnorm_f32")
+    check(lib.cbx_add_norm_f32(_p(x), _p(part), ks, 0 if part is None else part.stride(0), 0 if part is None else part.stride(1),
+                               _p(w), _p(bias), _p(h), rows, C, x.stride(0), h.stride(0), eps, int(rms), _stream()), "cbx_add_norm_f32")
     return h
 
 

@@ -100,6 +100,35 @@ def t3_state_dict(n_layers=30, seed=0, text_vocab=2454):
     return sd
 
 
+def t3_turbo_state_dict(n_layers=24, d=1024, seed=0, include_wte=False):
+    """Keys of the Turbo/Nano `T3` (GPT2-medium d=1024/24L, GPT2-small d=768/12L; reference tts_turbo.py:153-167).
+    HF Conv1D weights are [in, out].  `tfmr.wte` exists in the checkpoint files and is deleted after loading."""
+    sd = {}
+    sd["tfmr.wpe.weight"] = _normal("tfmr.wpe.weight", (8196, d), 0.02, seed)
+    if include_wte:
+        sd["tfmr.wte.weight"] = _normal("tfmr.wte.weight", (50276, d), 0.02, seed)
+    for i in range(n_layers):
+        p = f"tfmr.h.{i}."
+        _norm(sd, p + "ln_1", d, seed)
+        _norm(sd, p + "ln_2", d, seed)
+        for nm, (i_f, o_f) in dict(**{"attn.c_attn": (d, 3 * d), "attn.c_proj": (d, d), "mlp.c_fc": (d, 4 * d), "mlp.c_proj": (4 * d, d)}).items():
+            sd[p + nm + ".weight"] = _normal(p + nm + ".weight", (i_f, o_f), 0.03, seed)
+            sd[p + nm + ".bias"] = _uniform(p + nm + ".bias", (o_f,), 0.05, seed)
+    _norm(sd, "tfmr.ln_f", d, seed)
+    _linear(sd, "cond_enc.spkr_enc", d, 256, seed)
+    sd["text_emb.weight"] = _normal("text_emb.weight", (50276, d), 1.0, seed)
+    sd["speech_emb.weight"] = _normal("speech_emb.weight", (6563, d), 1.0, seed)
+    sd["text_head.weight"] = _normal("text_head.weight", (50276, d), 0.05, seed)
+    sd["speech_head.weight"] = _normal("speech_head.weight", (6563, d), 0.08, seed)
+    sd["speech_head.bias"] = _uniform("speech_head.bias", (6563,), 0.1, seed)
+    return sd
+
+
+def turbo_text_tokens(n=64, seed=1):
+    """GPT-2 BPE ids uniform in [0, 50257) (no SOT/EOT are added on the Turbo path, tts_turbo.py:295-296)."""
+    return torch.randint(0, 50257, (n,), generator=torch.Generator().manual_seed(1500 + seed)).long()
+
+
 # ----------------------------------------------------------------------------- S3Gen (flow + HiFT)
 
 

@@ -1,0 +1,189 @@
+"""Turbo / Nano T3 (GPT-2 backbone) on MI355X: host-side mirror of `T3.inference_turbo` (reference models/t3/t3.py:392-468,
+configuration tts_turbo.py:153-167).  Same kernel set as the Llama path with other epilogues: LayerNorm(+bias) instead of
+RMSNorm, fused c_attn with bias (HF Conv1D weights are stored [in,out] and transposed once at load), no RoPE (learned wpe is
+added when the token is embedded), gelu_new in the c_fc epilogue, speech head with bias, no CFG (rows = utterances), sampler
+in the Temperature -> TopK -> TopP -> RepetitionPenalty order.  One decode step is a hipGraph (6 kernels per layer).
+"""
+import torch
+
+from . import ops
+
+START_SPEECH, STOP_SPEECH = 6561, 6562
+
+
+class T3TurboEngine:
+    def __init__(self, sd, device="cuda", n_layers=None):
+        self.dev = dev = torch.device(device)
+        if n_layers is None:
+            n_layers = 0
+            while f"tfmr.h.{n_layers}.ln_1.weight" in sd:
+                n_layers += 1
+        self.L = n_layers
+        d = lambda t: t.float().contiguous().to(dev)
+        tw = lambda t: t.float().t().contiguous().to(dev)  # Conv1D [in,out] -> [out,in]
+        self.D = sd["tfmr.wpe.weight"].shape[1]
+        self.H = self.D // 64
+        self.layers = []
+        for i in range(n_layers):
+            p = f"tfmr.h.{i}."
+            self.layers.append(dict(
+                ln1=(d(sd[p + "ln_1.weight"]), d(sd[p + "ln_1.bias"])), ln2=(d(sd[p + "ln_2.weight"]), d(sd[p + "ln_2.bias"])),
+                wqkv=tw(sd[p + "attn.c_attn.weight"]), bqkv=d(sd[p + "attn.c_attn.bias"]),
+                wo=tw(sd[p + "attn.c_proj.weight"]), bo=d(sd[p + "attn.c_proj.bias"]),
+                wfc=tw(sd[p + "mlp.c_fc.weight"]), bfc=d(sd[p + "mlp.c_fc.bias"]),
+                wpr=tw(sd[p + "mlp.c_proj.weight"]), bpr=d(sd[p + "mlp.c_proj.bias"])))
+        self.lnf = (d(sd["tfmr.ln_f.weight"]), d(sd["tfmr.ln_f.bias"]))
+        self.wpe = d(sd["tfmr.wpe.weight"])
+        self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
+        self.head, self.head_b = d(sd["speech_head.weight"]), d(sd["speech_head.bias"])
+        self.V = self.head.shape[0]
+        self.spkr_w, self.spkr_b = d(sd["cond_enc.spkr_enc.weight"]), d(sd["cond_enc.spkr_enc.bias"])
+        # split-K factors of the two down-projections: K must be a multiple of 32 * ksplit * 4
+        self.ks_o = 4 if self.D % 512 == 0 else 2
+        self.ks_p = 8
+        self._state = {}
+
+    def _forward_decode(self, st):
+        ws = st["dws"]
+        x, h, qkv, att, g, po, pd = ws["x"], ws["h"], ws["qkv"], ws["att"], ws["g"], ws["po"], ws["pd"]
+        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.wpe, ids2=st["positions"])
+        part = None
+        for i, lw in enumerate(self.layers):
+            ops.add_rmsnorm(x, part, lw["ln1"][0], h, bias=lw["ln1"][1], rms=False)
+            ops.gemv(h, lw["wqkv"], qkv, bias=lw["bqkv"], nw=8)
+            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125)
+            ops.gemv(att, lw["wo"], po, bias=lw["bo"], ksplit=self.ks_o, nw=4)
+            ops.add_rmsnorm(x, po, lw["ln2"][0], h, bias=lw["ln2"][1], rms=False)
+            ops.gemv(h, lw["wfc"], g, bias=lw["bfc"], nw=8, act=ops.GELU_TANH)
+            ops.gemv(g, lw["wpr"], pd, bias=lw["bpr"], ksplit=self.ks_p, nw=4)
+            part = pd
+        ops.add_rmsnorm(x, part, self.lnf[0], h, bias=self.lnf[1], rms=False)
+        ops.gemv(h, self.head, st["logits"], bias=self.head_b, nw=4)
+
+    def _sample(self, st):
+        sp = st["samp"]
+        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, cfg_weight=0.0,
+                      temperature=sp["temperature"], min_p=0.0, top_p=sp["top_p"], rep_penalty=sp["repetition_penalty"],
+                      top_k=sp["top_k"], order=1, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH,
+                      ban_from=sp["ban_from"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
+                      out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
+                      next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
+
+    def _decode_step(self, st):
+        self._forward_decode(st)
+        self._sample(st)
+
+    def _get_state(self, B, max_ctx, max_steps):
+        key = (B, max_ctx, max_steps)
+        if key in self._state:
+            return self._state[key]
+        self._state.clear()
+        dev, D = self.dev, self.D
+        f = lambda *s: torch.empty(*s, device=dev)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        st = dict(B=B, max_ctx=max_ctx, max_steps=max_steps,
+                  kc=torch.zeros(self.L, B, self.H, max_ctx, 64, device=dev), vc=torch.zeros(self.L, B, self.H, max_ctx, 64, device=dev),
+                  logits=f(B, self.V), seen=torch.zeros(B, self.V, dtype=torch.uint8, device=dev), uniforms=f(B, max_steps), step=i32(B),
+                  out_tokens=torch.zeros(B, max_steps, dtype=torch.int64, device=dev), done=i32(B), n_generated=i32(B),
+                  next_ids=torch.zeros(B, dtype=torch.int64, device=dev), next_pos_ids=i32(B), positions=i32(B), ctx_lens=i32(B),
+                  dws=dict(x=f(B, D), h=f(B, D), qkv=f(B, 3 * D), att=f(B, D), g=f(B, 4 * D), po=f(self.ks_o, B, D), pd=f(self.ks_p, B, D)),
+                  graph=None, samp=None)
+        self._state[key] = st
+        return st
+
+    @torch.inference_mode()
+    def generate(self, conds, text_tokens, max_gen_len=1000, temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2,
+                 uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16, debug_logits=False):
+        """conds: one cond dict (speaker_emb (1,256), cond_prompt_speech_tokens (1,375)) or a list of B; text_tokens: list of B
+        1-D LongTensors (GPT-2 BPE ids, no SOT/EOT).  Returns a list of B 1-D LongTensors without the trailing EOS."""
+        dev, B, D = self.dev, len(text_tokens), self.D
+        conds = [conds] * B if isinstance(conds, dict) else conds
+        n_prompt = [int(c["cond_prompt_speech_tokens"].numel()) for c in conds]
+        tl = [int(t.numel()) for t in text_tokens]
+        s0 = [1 + n_prompt[b] + tl[b] + 1 for b in range(B)]
+        S = max(s0)
+        n_samples = max_gen_len + 1
+        max_ctx = (S + n_samples + 63) // 64 * 64
+        assert max_ctx <= self.wpe.shape[0], "context exceeds GPT-2 n_positions"
+        st = self._get_state(B, max_ctx, n_samples)
+        samp = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p), repetition_penalty=float(repetition_penalty),
+                    ban_eos=bool(ban_eos), ban_from=int(ban_from))
+        if st["samp"] != samp:
+            st["samp"], st["graph"] = samp, None
+        for k in ("seen", "step", "done", "n_generated", "out_tokens"):
+            st[k].zero_()
+        st["seen"][:, START_SPEECH] = 1  # the first processor call sees ids = [start token] (t3.py:428)
+        if uniforms is None:
+            st["uniforms"].uniform_()
+        else:
+            st["uniforms"].copy_(torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)[:, :n_samples])
+
+        # ---- prefill: [speaker | prompt-token embeddings | text | start-speech] + wpe (prepare_input_embeds, t3.py:102-130,407-423)
+        x = torch.zeros(B, S, D, device=dev)
+        for b in range(B):
+            pos = torch.arange(s0[b], dtype=torch.int32, device=dev)
+            ops.linear(conds[b]["speaker_emb"].to(dev).float().view(1, 256), self.spkr_w, x[b, 0:1], bias=self.spkr_b)
+            ops.axpby(self.wpe[0:1], x[b, 0:1], 1.0, 1.0)
+            a, e = 1, 1 + n_prompt[b]
+            ops.embed(conds[b]["cond_prompt_speech_tokens"].to(dev).long().view(-1), self.speech_emb, x[b, a:e], table2=self.wpe, ids2=pos[a:e])
+            a, e = e, e + tl[b]
+            ops.embed(text_tokens[b].to(dev).long().view(-1), self.text_emb, x[b, a:e], table2=self.wpe, ids2=pos[a:e])
+            ops.embed(torch.full((1,), START_SPEECH, dtype=torch.int64, device=dev), self.speech_emb, x[b, e:e + 1], table2=self.wpe, ids2=pos[e:e + 1])
+        M = B * S
+        xf = x.view(M, D)
+        h, qkv, att, g = (torch.empty(M, n, device=dev) for n in (D, 3 * D, D, 4 * D))
+        posr = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+        crow = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(S)
+        for i, lw in enumerate(self.layers):
+            ops.layernorm(xf, lw["ln1"][0], lw["ln1"][1], h, 1e-5)
+            ops.linear(h, lw["wqkv"], qkv, bias=lw["bqkv"])
+            ops.rope_kv(qkv, posr, None, None, st["kc"][i], st["vc"][i], self.H, cache_rows=crow)
+            q4 = qkv.view(B, S, 3, self.H, 64)
+            ops.flash_attn(q4[:, :, 0], q4[:, :, 1], q4[:, :, 2], att.view(B, S, self.H, 64), 0.125, causal=True)
+            ops.linear(att, lw["wo"], xf, bias=lw["bo"], residual=xf)
+            ops.layernorm(xf, lw["ln2"][0], lw["ln2"][1], h, 1e-5)
+            ops.linear(h, lw["wfc"], g, bias=lw["bfc"], act=ops.GELU_TANH)
+            ops.linear(g, lw["wpr"], xf, bias=lw["bpr"], residual=xf)
+        last = torch.tensor([b * S + s0[b] - 1 for b in range(B)], device=dev)
+        hl = xf.index_select(0, last).contiguous()
+        ops.layernorm(hl, self.lnf[0], self.lnf[1], st["dws"]["h"], 1e-5)
+        ops.linear(st["dws"]["h"], self.head, st["logits"], bias=self.head_b)
+        del x, xf, h, qkv, att, g
+
+        s0t = torch.tensor(s0, dtype=torch.int32, device=dev)
+        st["positions"].copy_(s0t - 1)
+        st["ctx_lens"].copy_(s0t)
+        step_logits = [st["logits"].clone()] if debug_logits else None
+        self._sample(st)
+        # later processor calls see ids = tokens generated so far, without the start token (t3.py:448-449)
+        st["seen"][:, START_SPEECH] = (st["out_tokens"][:, 0] == START_SPEECH).to(torch.uint8)
+        if debug_logits:
+            use_graph = False
+        if use_graph and st["graph"] is None and n_samples > 1:
+            torch.cuda.synchronize()
+            saved = {k: st[k].clone() for k in ("seen", "step", "done", "n_generated", "out_tokens", "next_ids", "next_pos_ids",
+                                                "positions", "ctx_lens", "logits")}
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._decode_step(st)
+            for k, v in saved.items():
+                st[k].copy_(v)
+            st["graph"] = gr
+        for i in range(1, n_samples):
+            if use_graph and st["graph"] is not None:
+                st["graph"].replay()
+            elif debug_logits:
+                self._forward_decode(st)
+                step_logits.append(st["logits"].clone())
+                self._sample(st)
+            else:
+                self._decode_step(st)
+            if not ban_eos and (i % poll_every == 0) and bool(st["done"].all()):
+                break
+        n = st["n_generated"].tolist()
+        toks = st["out_tokens"].cpu()
+        out = []
+        for b in range(B):
+            t = toks[b, : n[b]]
+            out.append(t[:-1].clone() if n[b] and int(t[-1]) == STOP_SPEECH else t.clone())
+        return (out, torch.stack(step_logits)) if debug_logits else out

@@ -33,6 +33,24 @@ def punc_norm(text: str) -> str:
     return text
 
 
+_TURBO_PUNC_MAP = {"…": ", ", ":": ",", "—": "-", "–": "-", " ,": ",", "“": '"', "”": '"', "‘": "'", "’": "'"}
+
+
+def punc_norm_turbo(text: str) -> str:
+    """The Turbo/Nano variant of the helper (reference tts_turbo.py:30-66): a shorter replacement table, ASCII enders."""
+    if not text:
+        return "You need to add some text for me to talk."
+    if text[0].islower():
+        text = text[0].upper() + text[1:]
+    text = " ".join(text.split())
+    for old, new in _TURBO_PUNC_MAP.items():
+        text = text.replace(old, new)
+    text = text.rstrip(" ")
+    if not text.endswith((".", "!", "?", "-", ",")):
+        text += "."
+    return text
+
+
 class MTLTokenizer:
     SOT, EOT, SPACE = "[START]", "[STOP]", "[SPACE]"
 

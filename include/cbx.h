@@ -69,12 +69,16 @@ typedef struct cbx_gemv_t {
     int ksplit;      /* K slices across workgroups (grid.y) */
     int nw;          /* waves per workgroup sharing one 16-column tile: 4 or 8 */
     int swiglu;
+    int act;         /* CBX_ACT_* applied after the bias (ksplit == 1 only): gelu_new of GPT-2's c_fc */
     long ldx, ldw, ldo, part_stride;
 } cbx_gemv_t;
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
                         int rows, int C, long ldx, long ldh, float eps, void* stream);
+/* same with LayerNorm (rms = 0, bias b) for the GPT-2 backbone of Turbo/Nano (HF GPT2Block ln_1 / ln_2 / ln_f) */
+int cbx_add_norm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, const float* b,
+                     float* h, int rows, int C, long ldx, long ldh, float eps, int rms, void* stream);
 
 /* ---- normalisation (wavefront reductions, one wave per row) ----
  * LayerNorm / RMSNorm over the last dim (C <= 4096, C % 4 == 0):
@@ -100,7 +104,8 @@ int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float*
                         float scale, void* stream);
 
 /* Fused per-token attention of the decode loop: HF apply_rotary_pos_emb on q,k of the fused qkv row (head_dim 64,
- * rotate_half form) + DynamicCache append at positions[row] + sdpa over positions [0, positions[row]] (t3.py:378-384). */
+ * rotate_half form; cos_t == sin_t == NULL skips the rotation: GPT-2) + DynamicCache append at positions[row] + sdpa over
+ * positions [0, positions[row]] (t3.py:378-384, 438-446). */
 int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                              float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, long cache_row_stride,
                              long cache_head_stride, float scale, void* stream);

@@ -525,3 +525,85 @@ def log_mel(wav):
                     return_complex=True)
     mag = torch.sqrt(sp.real ** 2 + sp.imag ** 2 + 1e-9)
     return torch.log(torch.clamp(slaney_mel_filter() @ mag, min=1e-5))
+
+
+# =============================================================================
+# Turbo / Nano: GPT-2 backbone T3 + meanflow S3Gen       models/t3/t3.py:392-468, tts_turbo.py:153-167
+# =============================================================================
+
+
+def gpt2_forward(sd, x, n_layers, n_heads, past=None):
+    """HF GPT2Model on inputs_embeds (third-party; llama_configs.py:35-103): learned wpe added to EVERY input at its
+    absolute position, pre-LN blocks, Conv1D weights stored [in, out], gelu_new, final ln_f."""
+    B, S, D = x.shape
+    hd = D // n_heads
+    p0 = 0 if past is None else past[0][0].shape[2]
+    x = x + sd["tfmr.wpe.weight"][p0:p0 + S][None]
+    new_past = []
+    for i in range(n_layers):
+        p = f"tfmr.h.{i}."
+        h = F.layer_norm(x, (D,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], 1e-5)
+        qkv = h @ sd[p + "attn.c_attn.weight"] + sd[p + "attn.c_attn.bias"]
+        q, k, v = (t.view(B, S, n_heads, hd).transpose(1, 2) for t in qkv.split(D, dim=2))
+        if past is not None:
+            k, v = torch.cat([past[i][0], k], 2), torch.cat([past[i][1], v], 2)
+        new_past.append((k, v))
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and past is None))
+        a = a.transpose(1, 2).reshape(B, S, D)
+        x = x + a @ sd[p + "attn.c_proj.weight"] + sd[p + "attn.c_proj.bias"]
+        h = F.layer_norm(x, (D,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], 1e-5)
+        g = F.gelu(h @ sd[p + "mlp.c_fc.weight"] + sd[p + "mlp.c_fc.bias"], approximate="tanh")
+        x = x + g @ sd[p + "mlp.c_proj.weight"] + sd[p + "mlp.c_proj.bias"]
+    return F.layer_norm(x, (D,), sd["tfmr.ln_f.weight"], sd["tfmr.ln_f.bias"], 1e-5), new_past
+
+
+def process_logits_turbo(l, ids, temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2):
+    """LogitsProcessorList order of inference_turbo (t3.py:396-404): Temperature -> TopK -> TopP -> RepetitionPenalty."""
+    if temperature > 0 and temperature != 1.0:
+        l = l / temperature
+    if top_k > 0:
+        kth = torch.topk(l, min(top_k, l.numel()))[0][-1]
+        l = l.masked_fill(l < kth, float("-inf"))
+    if top_p < 1.0:
+        sl, si = torch.sort(l, descending=False)
+        rm = sl.softmax(-1).cumsum(-1) <= (1 - top_p)
+        rm[-1] = False
+        l = l.masked_fill(torch.zeros_like(rm).scatter(0, si, rm), float("-inf"))
+    if repetition_penalty != 1.0:
+        u = torch.unique(ids)
+        s = l[u]
+        l = l.clone()
+        l[u] = torch.where(s < 0, s * repetition_penalty, s / repetition_penalty)
+    return l
+
+
+def t3_inference_turbo(sd, n_layers, n_heads, cond_in, text_tokens, max_gen_len, uniforms, temperature=0.8, top_k=1000,
+                       top_p=0.95, repetition_penalty=1.2, ban_eos=False, return_logits=False):
+    """T3.inference_turbo (t3.py:392-468) for one utterance: prefix [speaker | 375 prompt-token embeddings | text |
+    start-speech], no CFG, no positional embedding of our own (GPT-2's wpe does it).  Returns ids without a trailing EOS."""
+    stop = 6562
+    spk = F.linear(cond_in["speaker_emb"].view(-1, 256), sd["cond_enc.spkr_enc.weight"], sd["cond_enc.spkr_enc.bias"])[:, None]
+    prm = sd["speech_emb.weight"][cond_in["cond_prompt_speech_tokens"].view(1, -1)]
+    emb = torch.cat([spk, prm, sd["text_emb.weight"][text_tokens.view(1, -1)], sd["speech_emb.weight"][START_SPEECH].view(1, 1, -1)], 1)
+    hid, past = gpt2_forward(sd, emb, n_layers, n_heads)
+    logits = F.linear(hid[:, -1], sd["speech_head.weight"], sd["speech_head.bias"])[0]
+    out, all_logits = [], []
+    ids = torch.tensor([START_SPEECH])
+    for i in range(max_gen_len + 1):
+        if return_logits:
+            all_logits.append(logits.clone())
+        l = process_logits_turbo(logits, ids, temperature, top_k, top_p, repetition_penalty)
+        pr = torch.softmax(l, -1)
+        if ban_eos:
+            pr[stop] = 0.0
+        tok = sample_inverse_cdf(pr, uniforms[i])
+        out.append(tok)
+        if tok == stop:
+            break
+        ids = torch.tensor(out)
+        hid, past = gpt2_forward(sd, sd["speech_emb.weight"][tok].view(1, 1, -1), n_layers, n_heads, past)
+        logits = F.linear(hid[:, -1], sd["speech_head.weight"], sd["speech_head.bias"])[0]
+    if out and out[-1] == stop:
+        out = out[:-1]
+    res = torch.tensor(out, dtype=torch.long)
+    return (res, torch.stack(all_logits)) if return_logits else res

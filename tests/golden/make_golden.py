@@ -139,9 +139,78 @@ def golden_s3gen(name, P, N, n_steps=10):
                         wav=wav[0].numpy(), src=src[0, 0, ::7].numpy(), fp=fingerprint(sd))
 
 
+# ----------------------------------------------------------------------------- Turbo / Nano (GPT-2 T3, meanflow S3Gen)
+
+
+def golden_t3_turbo(name, n_layers, d, steps, n_text, cfg_name):
+    T3, T3Config, T3Cond, lc = ref_import.load_T3()
+    lc.LLAMA_CONFIGS[cfg_name]["n_layer"] = n_layers
+    hp = T3Config(text_tokens_dict_size=50276)
+    hp.llama_config_name, hp.speech_tokens_dict_size, hp.input_pos_emb = cfg_name, 6563, None
+    hp.speech_cond_prompt_len, hp.use_perceiver_resampler, hp.emotion_adv = 375, False, False
+    sd = synth.t3_turbo_state_dict(n_layers, d, 0, include_wte=True)
+    m = T3(hp).eval()
+    m.load_state_dict(sd, strict=True)
+    del m.tfmr.wte
+    n_heads = d // 64
+    ci = synth.t3_cond(prompt_len=375)
+    cond = T3Cond(speaker_emb=ci["speaker_emb"], cond_prompt_speech_tokens=ci["cond_prompt_speech_tokens"], emotion_adv=None)
+    tt = synth.turbo_text_tokens(n_text)
+    u = synth.rand((steps + 1,), seed=7)
+    raw, step = [], [0]
+    hook = m.speech_head.register_forward_hook(lambda mod, i, o: raw.append(o[:, -1].detach().clone()))
+    orig = torch.multinomial
+
+    def fake_multinomial(probs, num_samples=1, **kw):
+        p = probs[0].clone()
+        p[6562] = 0.0
+        tok = O.sample_inverse_cdf(p, u[step[0]])
+        step[0] += 1
+        return torch.tensor([[tok]])
+
+    torch.multinomial = fake_multinomial
+    try:
+        toks = m.inference_turbo(cond, tt[None], temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2, max_gen_len=steps)
+    finally:
+        torch.multinomial = orig
+        hook.remove()
+    raw = torch.stack(raw[: steps + 1])[:, 0]
+    o_toks, o_logits = O.t3_inference_turbo(sd, n_layers, n_heads, ci, tt, steps, u, ban_eos=True, return_logits=True)
+    err = (o_logits - raw).abs().max().item()
+    print(f"[{name}] ref tokens {toks[0].tolist()}\n[{name}] oracle-vs-reference logits max-abs {err:.3e}; tokens equal: {torch.equal(o_toks, toks[0])}")
+    assert err < 2e-3 and torch.equal(o_toks, toks[0])
+    idx = torch.arange(0, 6563, 13)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
+                        logits_sub=raw[:, idx].numpy(), logit_idx=idx.numpy(), uniforms=u.numpy(), fp=fingerprint({k: v for k, v in sd.items() if k != "tfmr.wte.weight"}))
+
+
+def golden_meanflow(name, P, N):
+    S3 = ref_import.load_S3Gen()
+    sd = synth.s3gen_state_dict(0, meanflow=True)
+    m = S3(meanflow=True).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("tokenizer.", "speaker_encoder.")) for k in missing)
+    ref = synth.s3gen_ref(n_prompt_tokens=P)
+    toks = synth.speech_tokens(N)[None]
+    T = 2 * (P + N)
+    z = synth.randn((1, 80, T), seed=5)
+    o_rl, o_rn = torch.randn_like, torch.randn
+    try:
+        torch.randn_like = lambda t, **kw: z.clone()
+        torch.randn = lambda *a, **kw: z[:, :, 2 * P:].clone()  # the generated-region noise drawn in flow_inference (s3gen.py:314-316)
+        mel = m.flow_inference(toks, ref_dict=dict(ref), n_cfm_timesteps=2, finalize=True)
+    finally:
+        torch.randn_like, torch.randn = o_rl, o_rn
+    o_mel = O.flow_inference(sd, toks, torch.tensor([N]), ref, z, 2, meanflow=True)
+    e = (o_mel - mel).abs()
+    print(f"[{name}] meanflow mel std {mel.std():.3f}; oracle-vs-ref L1 {e.mean():.3e} max {e.max():.3e}")
+    assert e.mean() < 1e-4
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), P=P, N=N, mel=mel[0].numpy(), fp=fingerprint(sd))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["t3_l2", "t3_l30", "s3gen_small"]
+    which = sys.argv[1:] or ["t3_l2", "t3_l30", "s3gen_small", "turbo_l2", "nano_l12", "meanflow_small"]
     with torch.inference_mode():
         if "t3_l2" in which:
             golden_t3("t3_l2", 2, 12, 16)
@@ -149,3 +218,9 @@ if __name__ == "__main__":
             golden_t3("t3_l30", 30, 6, 24)
         if "s3gen_small" in which:
             golden_s3gen("s3gen_small", P=12, N=20)
+        if "turbo_l2" in which:
+            golden_t3_turbo("turbo_l2", 2, 1024, 10, 20, "GPT2_medium")
+        if "nano_l12" in which:
+            golden_t3_turbo("nano_l12", 12, 768, 6, 16, "GPT2_small")
+        if "meanflow_small" in which:
+            golden_meanflow("meanflow_small", P=10, N=16)

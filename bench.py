@@ -34,9 +34,13 @@ def parse():
     ap.add_argument("--tokens", type=int, default=250, help="speech tokens per utterance (25/s)")
     ap.add_argument("--text-tokens", type=int, default=64)
     ap.add_argument("--t3-layers", type=int, default=30)
+    ap.add_argument("--workload", default="mtl", choices=["mtl", "turbo", "nano"],
+                    help="mtl = configs[2] (the headline metric); turbo / nano = configs[1] / configs[0] architectures (GPT-2 T3, 2-step meanflow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=25, help="speech tokens of the bounded CPU-baseline sample")
-    ap.add_argument("--roofline-kernel", default="flash_attn_f32", choices=["flash_attn_f32", "gemm_f32", "gemm_f32_skinny"])
+    ap.add_argument("--roofline-kernel", default="gemm_f32", choices=["gemm_f32", "flash_attn_f32", "gemv_f32"],
+                    help="kernel class timed with HIP events for the roofline object (default: the dominant one by time)")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
 
 
@@ -46,7 +50,7 @@ def cpu_baseline(t3_sd, s3_sd, args, n_layers):
     from chatterbox_amd import synth
     from oracle import ref_torch as O
     n = args.cpu_tokens
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))  # tiny decode matmuls crawl on 256 threads
     tt = synth.text_tokens(args.text_tokens)
     with torch.inference_mode():
         t0 = time.perf_counter()
@@ -84,21 +88,29 @@ def main():
     dev = torch.device("cuda", local)
 
     from chatterbox_amd import dist as cdist, ops, synth
-    from chatterbox_amd.engine import ChatterboxEngine
+    from chatterbox_amd.engine import ChatterboxEngine, TurboEngine
 
     t_build = time.perf_counter()
-    t3_sd = synth.t3_state_dict(args.t3_layers, 0)
-    s3_sd = synth.s3gen_state_dict(0)
-    eng = ChatterboxEngine(t3_sd, s3_sd, dev, n_t3_layers=args.t3_layers)
+    turbo = args.workload != "mtl"
+    if turbo:
+        dm, nl = (768, 12) if args.workload == "nano" else (1024, 24)
+        t3_sd = synth.t3_turbo_state_dict(nl, dm, 0)
+        s3_sd = synth.s3gen_state_dict(0, meanflow=True)
+        eng = TurboEngine(t3_sd, s3_sd, dev)
+        args.no_cpu_baseline = True
+    else:
+        t3_sd = synth.t3_state_dict(args.t3_layers, 0)
+        s3_sd = synth.s3gen_state_dict(0)
+        eng = ChatterboxEngine(t3_sd, s3_sd, dev, n_t3_layers=args.t3_layers)
     build_s = time.perf_counter() - t_build
     log(f"model built in {build_s:.1f}s")
 
     # C1: rank 0 "analysed the voice prompt"; everybody else receives the packed Conditionals over RCCL
-    t3c, gen = (synth.t3_cond(), synth.s3gen_ref()) if rank == 0 else (None, None)
+    t3c, gen = (synth.t3_cond(prompt_len=375 if turbo else 150), synth.s3gen_ref()) if rank == 0 else (None, None)
     t3c, gen = cdist.broadcast_conditionals(t3c, gen, src=0, device=dev)
 
     B, N = args.batch, args.tokens
-    texts = [synth.text_tokens(args.text_tokens, seed=100 * rank + b) for b in range(B)]
+    texts = [(synth.turbo_text_tokens if turbo else synth.text_tokens)(args.text_tokens, seed=100 * rank + b) for b in range(B)]
     T = 2 * (gen["prompt_token"].shape[1] + N)
 
     def one_step(seed):
@@ -106,8 +118,11 @@ def main():
         u = torch.rand(B, N, generator=g, device=dev)
         z = torch.randn(B, T, 80, generator=g, device=dev)
         t0 = time.perf_counter()
-        wavs, st = eng.synthesize(texts, t3c, gen, max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561, z=z,
-                                  drop_last_token=True)
+        if turbo:
+            wavs, st = eng.synthesize(texts, t3c, gen, max_gen_len=N - 1, uniforms=u, ban_eos=True, ban_from=6561)
+        else:
+            wavs, st = eng.synthesize(texts, t3c, gen, max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561, z=z,
+                                      drop_last_token=True)
         log(f"step seed={seed}: {eng.last_timing}")
         host = [w.cpu() for w in wavs]  # first (and only) audio reaches the host here: the path is non-streaming
         lat = time.perf_counter() - t0
@@ -146,9 +161,17 @@ def main():
     if rank == 0:
         ks = timer.summary().get(args.roofline_kernel)
         roof = None
-        if ks and ks["ms"] > 0:
+        if ks and ks["ms"] > 0 and args.roofline_kernel == "gemv_f32":
+            gbs = ks["bytes"] / (ks["ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="gemv_kernel (decode weight streaming; eager launches only, graph replays are not event-timed)",
+                        achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                        launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
+                        bytes_per_launch=round(ks["bytes"] / ks["launches"], 0))
+        elif ks and ks["ms"] > 0:
             tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=args.roofline_kernel, achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS,
+            kname = {"gemm_f32": "gemm_f32_kernel (implicit-GEMM linear/conv, every launch with M > 32)",
+                     "flash_attn_f32": "flash_attn_f32_kernel"}[args.roofline_kernel]
+            roof = dict(bound="mfma", kernel=kname, achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=ks["launches"],
                         avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
                         flops_per_launch=round(ks["flops"] / ks["launches"], 0),
@@ -160,9 +183,12 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded random-init weights in the reference checkpoint layout; synthetic prompts)",
             "p50_first_audio_latency_ms": round(1e3 * lats[len(lats) // 2], 1),
-            "config": {"workload": f"configs[2]: Chatterbox-Multilingual-V3 500M architecture (T3 Llama-520M {args.t3_layers}L + S3Gen 10-step CFG CFM + "
-                                   f"HiFT), batch {B}/GPU, {args.text_tokens} text tokens, {N} speech tokens = {N / 25:.0f} s audio per utterance, "
-                                   f"10 s voice prompt", "global_batch": B * world, "parallelism": f"dp{world}",
+            "config": {"workload": (f"configs[2]: Chatterbox-Multilingual-V3 500M architecture (T3 Llama-520M {args.t3_layers}L + S3Gen 10-step CFG CFM + "
+                                    f"HiFT), batch {B}/GPU, {args.text_tokens} text tokens, {N} speech tokens = {N / 25:.0f} s audio per utterance, "
+                                    f"10 s voice prompt") if not turbo else
+                                   (f"configs[{1 if args.workload == 'turbo' else 0}] architecture: Chatterbox-{args.workload} (GPT-2 T3, 2-step meanflow S3Gen, HiFT), "
+                                    f"batch {B}/GPU, {N} speech tokens (NOT the headline metric's config)"),
+                       "global_batch": B * world, "parallelism": f"dp{world}",
                        "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1)},
             "roofline": roof,
         }

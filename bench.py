@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--t3-layers", type=int, default=30)
     ap.add_argument("--workload", default="mtl", choices=["mtl", "turbo", "nano"],
                     help="mtl = configs[2] (the headline metric); turbo / nano = configs[1] / configs[0] architectures (GPT-2 T3, 2-step meanflow)")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the K steps strictly one after the other (default: T3 of batch k+1 overlaps the CFM/vocoder of batch k "
+                         "on a second HIP stream -- same work, same results, a serving loop's steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=25, help="speech tokens of the bounded CPU-baseline sample")
     ap.add_argument("--roofline-kernel", default="gemm_f32", choices=["gemm_f32", "flash_attn_f32", "gemv_f32"],
@@ -131,6 +134,7 @@ def main():
 
     for i in range(args.warmup):
         one_step(-1 - i)
+    pipelined = not args.serial and not turbo
     timer = ops.KernelTimer([args.roofline_kernel])
     ops.TIMER = timer
     if world > 1:
@@ -138,12 +142,19 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     audio, lats, stage = 0.0, [], {}
-    for i in range(args.steps):
-        a, lat, tm = one_step(i)
-        audio += a
-        lats.append(lat)
-        for k, v in tm.items():
-            stage[k] = stage.get(k, 0.0) + v
+    if pipelined:
+        jobs = [dict(text_tokens=texts, t3_conds=t3c, gen_ref=gen) for _ in range(args.steps)]
+        for host, st, lat in eng.synthesize_pipelined(jobs, max_new_tokens=N, ban_eos=True, ban_from=6561, drop_last_token=True):
+            audio += sum(w.numel() for w in host) / 24000.0
+            lats.append(lat)
+            cdist.gather_waveforms(host, dst=0)  # C2
+    else:
+        for i in range(args.steps):
+            a, lat, tm = one_step(i)
+            audio += a
+            lats.append(lat)
+            for k, v in tm.items():
+                stage[k] = stage.get(k, 0.0) + v
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -189,7 +200,8 @@ def main():
                                    (f"configs[{1 if args.workload == 'turbo' else 0}] architecture: Chatterbox-{args.workload} (GPT-2 T3, 2-step meanflow S3Gen, HiFT), "
                                     f"batch {B}/GPU, {N} speech tokens (NOT the headline metric's config)"),
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1)},
+                       "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1),
+                       "schedule": "pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, z = blockIdx.z;
-    const int q0 = blockIdx.x * 128;
+    // the query tiles of one (row, head) share K/V: keep them on one XCD
+    const int tile = cbx_xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int qt = tile % gridDim.x, head = (tile / gridDim.x) % gridDim.y, z = tile / (gridDim.x * gridDim.y);
+    const int q0 = qt * 128;
     const int qi = q0 + wid * 32 + lr;  // this lane's query
     const float* qb = a.q + (long)z * a.q_sb + head * 64;
     const float* kb = a.k + (long)z * a.k_sb + head * 64;

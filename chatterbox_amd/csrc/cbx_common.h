@@ -52,3 +52,12 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// XCD-aware workgroup remap (MI355X: 8 XCDs with private L2s; workgroup b is dispatched to XCD b % 8).  Returns the
+// logical tile id for this workgroup such that the workgroups resident on one XCD own CONSECUTIVE tile ids, so tiles
+// that share an operand panel (same A rows / same K,V head) hit that XCD's L2 instead of each XCD re-fetching the
+// panel.  Bijective for any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int cbx_xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}

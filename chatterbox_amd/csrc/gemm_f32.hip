@@ -37,7 +37,9 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
     const int z = blockIdx.z, z1 = z / p.nz2, z2 = z - z1 * p.nz2;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // n-tiles of one m-tile (they share the A panel) are kept on one XCD
+    const int tile = cbx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int n0 = (tile % gridDim.x) * BN, m0 = (tile / gridDim.x) * BM;
 
     const float* __restrict__ Ab = p.A + (long)z1 * p.a_s1 + (long)z2 * p.a_s2;
     const float* __restrict__ Wb = p.W + (long)z1 * p.w_s1 + (long)z2 * p.w_s2;

@@ -37,7 +37,7 @@ class ChatterboxEngine:
         self.last_timing = {}
 
     @torch.inference_mode()
-    def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False):
+    def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True):
         """S3Gen.inference for a list of 1-D token tensors (already valid ids).  Returns (list of 1-D wav tensors on
         device, mel (B, 2Nmax, 80) channel-last)."""
         B = len(speech_tokens)
@@ -49,12 +49,14 @@ class ChatterboxEngine:
         lens = torch.tensor(ns, dtype=torch.int32)
         t0 = time.perf_counter()
         mel = self.flow.inference(tok.to(self.dev), lens.to(self.dev), gen_ref, z=z, n_steps=n_cfm_timesteps)
-        torch.cuda.synchronize()
+        if sync:  # per-stage wall times; the pipelined mode never blocks the host between stages
+            torch.cuda.synchronize()
         t1 = time.perf_counter()
         same = all(n == Nmax for n in ns)
         mel_lens = None if same else (2 * lens).to(self.dev)
         wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
-        torch.cuda.synchronize()
+        if sync:
+            torch.cuda.synchronize()
         t2 = time.perf_counter()
         self.last_timing.update(flow_s=t1 - t0, hift_s=t2 - t1)
         out = []
@@ -80,6 +82,44 @@ class ChatterboxEngine:
                               drop_last_token=drop_last_token)
         self.last_timing["total_s"] = time.perf_counter() - t0
         return wavs, st
+
+
+    @torch.inference_mode()
+    def synthesize_pipelined(self, jobs, **kw):
+        """Throughput mode for a stream of batches: T3 of batch k+1 runs on a high-priority HIP stream WHILE the flow
+        matching + vocoder of batch k run on a second stream.  The AR decode is a chain of small latency-bound kernels
+        (HBM-bound GEMVs on a fraction of the CUs); the CFM is MFMA-bound on wide grids -- the two fill each other's
+        idle resources.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields (wavs, tokens, latency_s)
+        per job in order.  Results are identical to synthesize() called per job."""
+        if not hasattr(self, "_s_t3"):
+            self._s_t3 = torch.cuda.Stream(device=self.dev, priority=-1)
+            self._s_voc = torch.cuda.Stream(device=self.dev)
+        t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
+                                    "ban_from") if k in kw}
+        torch.cuda.synchronize()
+        pending = None  # (job, speech tokens, t_start)
+        for k in range(len(jobs) + 1):
+            handle = None
+            if k < len(jobs):
+                t_start = time.perf_counter()
+                with torch.cuda.stream(self._s_t3):
+                    handle = self.t3.generate(jobs[k]["t3_conds"], jobs[k]["text_tokens"], async_mode=True,
+                                              uniforms=jobs[k].get("uniforms"), **t3_kw)
+            if pending is not None:
+                job, st, t0 = pending
+                with torch.cuda.stream(self._s_voc):
+                    wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
+                                          n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
+                                          drop_last_token=kw.get("drop_last_token", True), sync=False)
+                    host = [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
+                yield host, st, time.perf_counter() - t0
+            pending = None
+            if handle is not None:
+                with torch.cuda.stream(self._s_t3):
+                    toks = self.t3.collect(handle)
+                st = [drop_invalid_tokens(t) for t in toks]
+                st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
+                pending = (jobs[k], st, t_start)
 
 
 S3GEN_SIL = 4299  # reference models/s3gen/const.py:2

@@ -72,6 +72,8 @@ class T3Engine:
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
         self.max_pos = max_pos
         self._state = {}
+        # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
+        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4)
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -127,21 +129,21 @@ class T3Engine:
     def _forward_decode(self, st):
         """One token for every row.  The residual stream x is only touched by add_rmsnorm, which folds the split-K
         partials of the previous projection, the residual add and the RMSNorm into one pass."""
-        ws, x = st["dws"], st["dws"]["x"]
-        h, qkv, att, g, po, pd = ws["h"], ws["qkv"], ws["att"], ws["g"], ws["po"], ws["pd"]
+        ws, x, tn = st["dws"], st["dws"]["x"], self.tune
+        h, qkv, att, g, po, pd = ws["h"], ws["qkv"], ws["att"], ws["g"], ws["po"][: tn["o_ks"]], ws["pd"][: tn["d_ks"]]
         ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"])
         part = None
         for i, lw in enumerate(self.layers):
             ops.add_rmsnorm(x, part, lw["ln1"], h)
-            ops.gemv(h, lw["wqkv"], qkv, nw=8)
+            ops.gemv(h, lw["wqkv"], qkv, nw=tn["qkv_nw"])
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125)
-            ops.gemv(att, lw["wo"], po, ksplit=4, nw=4)
+            ops.gemv(att, lw["wo"], po, ksplit=tn["o_ks"], nw=4)
             ops.add_rmsnorm(x, po, lw["ln2"], h)
-            ops.gemv(h, lw["wgu"], g, swiglu=True, nw=8)
-            ops.gemv(g, lw["wd"], pd, ksplit=8, nw=4)
+            ops.gemv(h, lw["wgu"], g, swiglu=True, nw=tn["gu_nw"])
+            ops.gemv(g, lw["wd"], pd, ksplit=tn["d_ks"], nw=4)
             part = pd
         ops.add_rmsnorm(x, part, self.norm, h)
-        ops.gemv(h, self.head, st["logits"], nw=4)
+        ops.gemv(h, self.head, st["logits"], nw=tn["head_nw"])
 
     def _decode_step(self, st):
         self._forward_decode(st)
@@ -174,16 +176,23 @@ class T3Engine:
                   done=i32(B), n_generated=i32(B), next_ids=torch.zeros(rows, dtype=torch.int64, device=dev),
                   next_pos_ids=i32(rows), positions=i32(rows), ctx_lens=i32(rows),
                   dws=dict(x=f(rows, self.D), h=f(rows, self.D), qkv=f(rows, 3 * self.D), att=f(rows, self.D), g=f(rows, self.F),
-                           po=f(4, rows, self.D), pd=f(8, rows, self.D)),
+                           po=f(8, rows, self.D), pd=f(8, rows, self.D)),
                   graph=None, samp=None)
         self._state[key] = st
         return st
+
+    def collect(self, handle):
+        """Fetch the tokens of an (async) generate() call.  Must run on the stream the call was enqueued on."""
+        st, B = handle["st"], handle["B"]
+        n = st["n_generated"].tolist()
+        toks = st["out_tokens"].cpu()
+        return [toks[b, : n[b]].clone() for b in range(B)]
 
     # ------------------------------------------------------------------ T3.inference
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
                  repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16,
-                 return_prefill_logits=False, debug_logits=False):
+                 return_prefill_logits=False, debug_logits=False, async_mode=False):
         """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
         carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled)."""
         dev, B = self.dev, len(text_tokens)
@@ -262,11 +271,11 @@ class T3Engine:
                 self._sample(st)
             else:
                 self._decode_step(st)
-            if not ban_eos and (i % poll_every == 0) and bool(st["done"].all()):
+            if not ban_eos and not async_mode and (i % poll_every == 0) and bool(st["done"].all()):
                 break
-        n = st["n_generated"].tolist()
-        toks = st["out_tokens"].cpu()
-        out = [toks[b, : n[b]].clone() for b in range(B)]
+        if async_mode:  # everything is enqueued on the current stream; no host synchronisation happened
+            return dict(st=st, B=B)
+        out = self.collect(dict(st=st, B=B))
         if debug_logits:
             return out, torch.stack(step_logits)  # (steps, 2B, V)
         return (out, prefill_logits) if return_prefill_logits else out

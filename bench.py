@@ -21,7 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (the split-operand kernels issue 3 or 6 of these per fp32 product)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -36,13 +37,19 @@ def parse():
     ap.add_argument("--t3-layers", type=int, default=30)
     ap.add_argument("--workload", default="mtl", choices=["mtl", "turbo", "nano"],
                     help="mtl = configs[2] (the headline metric); turbo / nano = configs[1] / configs[0] architectures (GPT-2 T3, 2-step meanflow)")
-    ap.add_argument("--serial", action="store_true",
-                    help="run the K steps strictly one after the other (default: T3 of batch k+1 overlaps the CFM/vocoder of batch k "
-                         "on a second HIP stream -- same work, same results, a serving loop's steady state)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="throughput mode: T3 of batch k+1 overlaps the CFM/vocoder of batch k on a second HIP stream (same work, "
+                         "same results, ~+10%% audio-s/s but ~2x per-batch latency).  Default: the K steps run strictly one after the other")
+    ap.add_argument("--serial", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=25, help="speech tokens of the bounded CPU-baseline sample")
-    ap.add_argument("--roofline-kernel", default="gemm_f32", choices=["gemm_f32", "flash_attn_f32", "gemv_f32"],
-                    help="kernel class timed with HIP events for the roofline object (default: the dominant one by time)")
+    ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "flash_attn_f32", "gemv_f32"],
+                    help="kernel class reported as `roofline` (auto: the one with the largest share of a step); the others go to "
+                         "`roofline_secondary`.  All three are timed with HIP events on the launch stream")
+    ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6],
+                    help="numerics of the S3Gen GEMMs / attention: 1 exact fp32 MFMA, 6 bf16x6 (fp32-level error), 3 bf16x3 (default, "
+                         "rel. error ~4e-6 per contraction; golden mel-L1 1.4e-5 against the 1e-4 tolerance).  T3 is always exact")
+    ap.add_argument("--no-alt-precisions", action="store_true", help="skip the two extra one-step measurements at the other S3Gen precisions")
     ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
 
@@ -71,6 +78,79 @@ def cpu_baseline(t3_sd, s3_sd, args, n_layers):
                 sample=f"1 utterance, {args.text_tokens} text tokens, {n} speech tokens ({audio_s:.1f} s audio), 10 s voice prompt, "
                        f"T3 {t1 - t0:.1f} s + S3Gen/HiFT {t2 - t1:.1f} s on {torch.get_num_threads()} threads "
                        f"(reference cannot batch: B>1 = serial loop)")
+
+
+def pmc_traffic(kernel_substr, source="flow_only"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/: separate FETCH_SIZE and WRITE_SIZE runs of
+    scripts/flow_only.py resp. scripts/prof_t3_eager.py -- PMC cannot be collected inside the timed run, and rocprofv3 --pmc
+    does not survive hipGraph replays).  FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of a 16-B-per-lane
+    coalesced read (MI355X_MICROARCH.md, HBM section); units are KiB."""
+    import csv
+    tot = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(ROOT, "profiles", f"r01_{source}_pmc_{c}.csv")
+        if not os.path.exists(f):
+            return None, None
+        n = 0
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["kernel"] and r["counter"] == c:  # several template instances: launch-weighted mean
+                tot[c] = tot.get(c, 0.0) + float(r["sum"]) * 1024.0
+                n += int(r["launches"])
+        if n:
+            tot[c] /= n
+    if len(tot) != 2:
+        return None, None
+    return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"], f"profiles/r01_{source}_pmc_{{FETCH,WRITE}}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, per launch)"
+
+
+def roofline_entries(summ, elapsed, steps, eager_steps, s3_prec, n_decode):
+    """One roofline object per timed kernel class.  gemm / flash: every launch of the timed region; gemv: an eager replay of the
+    decode step after the timed region (inside the region the same kernels run from a hipGraph, which events cannot see)."""
+    out = {}
+    split = s3_prec in (3, 6)
+    nprod = {3: 3, 6: 6}.get(s3_prec, 1)
+    for kind in ("gemm_f32", "flash_attn_f32"):
+        ks = summ.get(kind)
+        if not ks or ks["ms"] <= 0:
+            continue
+        tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
+        if kind == "gemm_f32":
+            kname = ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, bf16x%d) + gemm_f32_kernel (T3 prefill, exact)" % nprod) if split \
+                else "gemm_f32_kernel (implicit-GEMM linear/conv, every launch with M > 32)"
+            sub = "gemm_split_kernel" if split else "gemm_f32_kernel<128, 64, 4, 2"
+        else:
+            kname = ("flash_attn_split_kernel (bf16x%d)" % nprod) if split else "flash_attn_f32_kernel"
+            sub = "flash_attn_split_kernel" if split else "flash_attn_f32_kernel"
+        peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        issued = tf * nprod if split else tf
+        e = dict(bound="mfma", kernel=kname, achieved=round(issued, 2), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
+                 traffic=None, launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
+                 flops_per_launch=round(ks["flops"] / ks["launches"], 0),
+                 algorithmic_bytes_per_launch=round(ks["bytes"] / ks["launches"], 0),
+                 share_of_step=round(ks["ms"] * 1e-3 / elapsed, 3))
+        if split:
+            e["fp32_equivalent_tflops"] = round(tf, 2)
+            e["note"] = (f"achieved = algorithmic fp32 FLOPs x {nprod} bf16 MFMA products per fp32 product (the work the matrix cores "
+                         f"execute), priced against the dense bf16 peak; {round(tf, 1)} TFLOP/s fp32-equivalent = "
+                         f"{round(tf / MFMA_F32_PEAK_TFLOPS, 2)}x the exact-fp32 MFMA peak")
+        tr, src = pmc_traffic(sub)
+        e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
+        out[kind] = e
+    ks = summ.get("gemv_f32")
+    if ks and ks["ms"] > 0 and eager_steps > 0:
+        gbs = ks["bytes"] / (ks["ms"] * 1e-3) / 1e9
+        per_step_ms = ks["ms"] / eager_steps
+        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down, speech head; M = 2*batch rows)",
+                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                 launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
+                 algorithmic_bytes_per_launch=round(ks["bytes"] / ks["launches"], 0),
+                 share_of_step=round(per_step_ms * 1e-3 * steps * n_decode / elapsed, 3),
+                 note="timed on an eager replay of the decode step after the timed region (same kernels, same stream); inside the "
+                      "region they run from a hipGraph")
+        tr, src = pmc_traffic("gemv_kernel", "t3_eager")
+        e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
+        out["gemv_f32"] = e
+    return out
 
 
 def log(msg):
@@ -105,6 +185,9 @@ def main():
         t3_sd = synth.t3_state_dict(args.t3_layers, 0)
         s3_sd = synth.s3gen_state_dict(0)
         eng = ChatterboxEngine(t3_sd, s3_sd, dev, n_t3_layers=args.t3_layers)
+    if args.s3gen_precision is not None:
+        eng.flow.precision = eng.hift.precision = args.s3gen_precision
+    s3_prec = eng.flow.precision
     build_s = time.perf_counter() - t_build
     log(f"model built in {build_s:.1f}s")
 
@@ -134,8 +217,8 @@ def main():
 
     for i in range(args.warmup):
         one_step(-1 - i)
-    pipelined = not args.serial and not turbo
-    timer = ops.KernelTimer([args.roofline_kernel])
+    pipelined = args.pipelined and not args.serial and not turbo
+    timer = ops.KernelTimer(["gemm_f32", "flash_attn_f32"])
     ops.TIMER = timer
     if world > 1:
         dist.barrier()
@@ -169,30 +252,47 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, audio = float(mx[0]), float(sm[1])
 
+    # ---- outside the timed region: (a) eager replay of the decode step for the gemv roofline, (b) one step at each of the other
+    # S3Gen precisions so that the exact-fp32 figure is reported by the same run
+    eager_steps, alt = 0, {}
     if rank == 0:
-        ks = timer.summary().get(args.roofline_kernel)
-        roof = None
-        if ks and ks["ms"] > 0 and args.roofline_kernel == "gemv_f32":
-            gbs = ks["bytes"] / (ks["ms"] * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="gemv_kernel (decode weight streaming; eager launches only, graph replays are not event-timed)",
-                        achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
-                        launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
-                        bytes_per_launch=round(ks["bytes"] / ks["launches"], 0))
-        elif ks and ks["ms"] > 0:
-            tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
-            kname = {"gemm_f32": "gemm_f32_kernel (implicit-GEMM linear/conv, every launch with M > 32)",
-                     "flash_attn_f32": "flash_attn_f32_kernel"}[args.roofline_kernel]
-            roof = dict(bound="mfma", kernel=kname, achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=ks["launches"],
-                        avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
-                        flops_per_launch=round(ks["flops"] / ks["launches"], 0),
-                        share_of_step=round(ks["ms"] * 1e-3 / elapsed, 3))
+        summ = timer.summary()
+        if not turbo:
+            gt = ops.KernelTimer(["gemv_f32"])
+            eager_steps = 24
+            g = torch.Generator(device=dev).manual_seed(99)
+            eng.t3.generate(t3c, texts, max_new_tokens=eager_steps + 1, uniforms=torch.rand(B, eager_steps + 1, generator=g, device=dev),
+                            ban_eos=True, ban_from=6561, use_graph=False)  # warm (first eager launches)
+            ops.TIMER = gt
+            eng.t3.generate(t3c, texts, max_new_tokens=eager_steps + 1, uniforms=torch.rand(B, eager_steps + 1, generator=g, device=dev),
+                            ban_eos=True, ban_from=6561, use_graph=False)
+            ops.TIMER = None
+            summ.update(gt.summary())
+            if not args.no_alt_precisions:
+                for pr in (1, 6, 3):
+                    if pr == s3_prec:
+                        continue
+                    eng.flow.precision = eng.hift.precision = pr
+                    one_step(-100)
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    a, _, _ = one_step(-101)
+                    torch.cuda.synchronize()
+                    alt[f"s3gen_precision_{pr}"] = round(a / (time.perf_counter() - ta), 2)
+                eng.flow.precision = eng.hift.precision = s3_prec
+        roofs = roofline_entries(summ, elapsed, args.steps, eager_steps, s3_prec, N - 1)
+        dom = args.roofline_kernel
+        if dom == "auto":
+            dom = max(roofs, key=lambda k: roofs[k]["share_of_step"]) if roofs else None
+        roof = roofs.pop(dom, None)
         lats.sort()
         out = {
             "metric": "audio-sec/wall-sec (xRT) + p50 first-audio latency, Multilingual-V3 500M",
             "value": round(audio / elapsed, 3), "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded random-init weights in the reference checkpoint layout; synthetic prompts)",
+            "dtype": "f32" if s3_prec == 1 else f"f32 (T3: exact fp32 MFMA; S3Gen: fp32 operands split into bf16 planes, bf16x{3 if s3_prec == 3 else 6} "
+                                                 f"MFMA products, fp32 accumulate)",
+            "data": "synthetic (seeded random-init weights in the reference checkpoint layout; synthetic prompts)",
             "p50_first_audio_latency_ms": round(1e3 * lats[len(lats) // 2], 1),
             "config": {"workload": (f"configs[2]: Chatterbox-Multilingual-V3 500M architecture (T3 Llama-520M {args.t3_layers}L + S3Gen 10-step CFG CFM + "
                                     f"HiFT), batch {B}/GPU, {args.text_tokens} text tokens, {N} speech tokens = {N / 25:.0f} s audio per utterance, "
@@ -203,7 +303,10 @@ def main():
                        "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1),
                        "schedule": "pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial"},
             "roofline": roof,
+            "roofline_secondary": list(roofs.values()),
         }
+        if alt:
+            out["audio_s_per_wall_s_at_other_precisions"] = alt
         if not args.no_cpu_baseline:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)

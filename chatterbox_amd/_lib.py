@@ -30,6 +30,7 @@ class GemmParams(ctypes.Structure):
         ("ldc", c_long), ("c_s1", c_long), ("c_s2", c_long),
         ("ldr", c_long), ("r_s1", c_long), ("r_s2", c_long),
         ("ldc2", c_long), ("c2_s1", c_long), ("c2_s2", c_long),
+        ("precision", c_int), ("reserved0", c_int),
     ]
 
 
@@ -59,6 +60,7 @@ _SIGS = {
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),
+    "cbx_flash_attn_split_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
     "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),

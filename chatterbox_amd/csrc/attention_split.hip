@@ -1,0 +1,272 @@
+// Flash attention (head_dim 64) on the bf16 matrix cores with split fp32 operands ("bf16x3" / "bf16x6", see
+// gemm_split.hip for the arithmetic): same swapped formulation, tiling and masking semantics as flash_attn_f32_kernel
+// (attention.hip), 5.3x / 2.7x fewer matrix-core cycles per KV tile.
+//
+//   S^T = K Q^T : A = K tile from LDS planes [key][d]   (lane: key = lane&31, d = 16kc + 8*(lane>>5) .. +8)
+//                 B = Q^T held in registers as planes   (lane: query = lane&31, same d)
+//   O^T = V^T P^T: A = V^T from LDS planes [d][key']    (lane: d = lane&31, 8 keys of chunk c)
+//                  B = P^T straight from the S accumulators: registers 8u..8u+7 of sub-tile t are keys
+//                      32t + 16u + 8(j>>2) + 4*(lane>>5) + (j&3), j = 0..7, so the V^T image stores key k of a 16-key chunk
+//                      at position (k with bits 2 and 3 swapped): the lane's 8 keys are then one ds_read_b128.
+// The MFMA sums all 16 k of both half-waves, so any k <-> (half, j) assignment is legal as long as A and B agree.
+#include "cbx_common.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int FKT = 64;   // keys per tile
+constexpr int FLD = 72;   // LDS row stride in bf16 (144 B: odd multiple of 16 B -> conflict-free ds_read_b128)
+constexpr int FPLANE = 64 * FLD;
+
+struct FlashSplitArgs {
+    const float* q; const float* k; const float* v; float* o; const int* key_lens;
+    int Tq, Tk;
+    long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
+    float scale;
+    int causal;
+};
+
+template <int NP>
+__device__ __forceinline__ void split8(const f32x8 v, bf16x8 (&out)[NP]) {
+    out[0] = __builtin_convertvector(v, bf16x8);
+    f32x8 r = v - __builtin_convertvector(out[0], f32x8);
+    out[1] = __builtin_convertvector(r, bf16x8);
+    if constexpr (NP == 3) {
+        r = r - __builtin_convertvector(out[1], f32x8);
+        out[2] = __builtin_convertvector(r, bf16x8);
+    }
+}
+
+// acc += sum over the plane products above the fp32 rounding level (smallest first)
+template <int NP>
+__device__ __forceinline__ f32x16 mma_split(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 acc) {
+    if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSplitArgs a) {
+    // planes: K [NP][64 keys][FLD], then V^T [NP][64 d][FLD]
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[NP * FPLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[NP * FPLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tile = cbx_xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int qt = tile % gridDim.x, head = (tile / gridDim.x) % gridDim.y, z = tile / (gridDim.x * gridDim.y);
+    const int q0 = qt * 128;
+    const int qi = q0 + wid * 32 + lr;  // this lane's query
+    const float* qb = a.q + (long)z * a.q_sb + head * 64;
+    const float* kb = a.k + (long)z * a.k_sb + head * 64;
+    const float* vb = a.v + (long)z * a.v_sb + head * 64;
+    const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
+    const int coff = a.Tk - a.Tq;
+
+    // Q planes: chunk kc covers d = 16kc + 8lh .. +8, pre-scaled
+    bf16x8 qf[4][NP];
+    {
+        const bool ok = qi < a.Tq;
+        const float* qp = qb + (long)(ok ? qi : 0) * a.q_st + 8 * lh;
+        const float sc = ok ? a.scale : 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp + 16 * kc);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * kc + 4);
+            f32x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            t *= sc;
+            split8<NP>(t, qf[kc]);
+        }
+    }
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kend = klen;
+    if (a.causal) kend = min(kend, q0 + 128 + coff);
+
+    // staging maps.  K: thread = (key row, 16 consecutive d).  V: thread = (group of 4 consecutive keys, 4 consecutive d)
+    // so the transposed image is written 4 keys (8 B) at a time; the (dq, g) <-> tid map keeps those stores conflict-free.
+    const int k_row = tid >> 2, k_c = (tid & 3) * 16;
+    const int v_dq = ((tid >> 4) & 7) * 2 + (tid & 1);      // d quad 0..15
+    const int v_g = (tid >> 7) * 8 + ((tid >> 1) & 7);      // key group 0..15 (keys 4g..4g+3)
+    // position of key 4g inside the V^T row: bits 2 and 3 of the key index swapped
+    const int v_pos = (v_g & ~3) * 4 + (v_g & 1) * 8 + ((v_g >> 1) & 1) * 4;
+
+    f32x4 kreg[4], vreg[4];
+    unsigned kok = 0, vok = 0;
+    auto fetch = [&](int j0) {
+        {
+            const int j = j0 + k_row;
+            const bool ok = j < klen;
+            const float* kp = kb + (long)(ok ? j : 0) * a.k_st + k_c;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kreg[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
+            kok = ok ? 1u : 0u;
+        }
+        vok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = j0 + 4 * v_g + i;
+            const bool ok = j < klen;
+            vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)(ok ? j : 0) * a.v_st + 4 * v_dq);
+            vok |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto stage = [&]() {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // K planes: 16 d of one key -> two 16-B stores per plane
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const f32x4 x0 = kok ? kreg[2 * c2] : zero, x1 = kok ? kreg[2 * c2 + 1] : zero;
+            const f32x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            bf16x8 pl[NP];
+            split8<NP>(x, pl);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(&Ks[q * FPLANE + k_row * FLD + k_c + 8 * c2]) = pl[q];
+        }
+        // V^T planes: for each of the thread's 4 d, the 4 keys of its group are contiguous (8 B)
+        f32x4 vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[i] = (vok >> i) & 1u ? vreg[i] : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 col = {vv[0][e], vv[1][e], vv[2][e], vv[3][e]};  // keys 4g..4g+3 at d = 4dq + e
+            bf16x4 h = __builtin_convertvector(col, bf16x4);
+            f32x4 r = col - __builtin_convertvector(h, f32x4);
+            bf16x4 m = __builtin_convertvector(r, bf16x4);
+            __bf16* dst = &Vt[(4 * v_dq + e) * FLD + v_pos];
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + FPLANE) = m;
+            if constexpr (NP == 3) {
+                r = r - __builtin_convertvector(m, f32x4);
+                *reinterpret_cast<bf16x4*>(dst + 2 * FPLANE) = __builtin_convertvector(r, bf16x4);
+            }
+        }
+    };
+    if (kend > 0) fetch(0);
+
+    for (int j0 = 0; j0 < kend; j0 += FKT) {
+        stage();
+        __syncthreads();
+        // unconditional prefetch (rows past the end read row 0 and are masked at staging): keeps hipcc's vmcnt exact
+        fetch(j0 + FKT);
+
+        // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, 4 d-chunks of 16)
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                bf16x8 kf[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    kf[q] = *reinterpret_cast<const bf16x8*>(&Ks[q * FPLANE + (t * 32 + lr) * FLD + 16 * kc + 8 * lh]);
+                st[t] = mma_split<NP>(kf, qf[kc], st[t]);
+            }
+        }
+
+        // ---- mask + online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int j = j0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bool vis = j < klen && (!a.causal || j <= qi + coff);
+                float sv = vis ? st[t][r] : -INFINITY;
+                st[t][r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        float alpha = 1.f;
+        if (m_new > -INFINITY) alpha = __expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = (m_new > -INFINITY) ? __expf(st[t][r] - m_new) : 0.f;
+                st[t][r] = pv;
+                ls += pv;
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T : chunk c = 2t + u contracts the 16 keys held in registers 8u..8u+7 of both half-waves
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x8 pv = {st[t][8 * u + 0], st[t][8 * u + 1], st[t][8 * u + 2], st[t][8 * u + 3],
+                                  st[t][8 * u + 4], st[t][8 * u + 5], st[t][8 * u + 6], st[t][8 * u + 7]};
+                bf16x8 pf[NP];
+                split8<NP>(pv, pf);
+                const int c = 2 * t + u;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    bf16x8 vf[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        vf[q] = *reinterpret_cast<const bf16x8*>(&Vt[q * FPLANE + (dt * 32 + lr) * FLD + 16 * c + 8 * lh]);
+                    ot[dt] = mma_split<NP>(vf, pf, ot[dt]);
+                }
+            }
+        __syncthreads();
+    }
+
+    // ---- finalise: both half-waves hold partial sums of the same query
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Tq) {
+        float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t = {ot[d][g * 4 + 0] * inv, ot[d][g * 4 + 1] * inv, ot[d][g * 4 + 2] * inv, ot[d][g * 4 + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * lh) = t;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
+                                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,
+                                        void* stream) {
+    CBX_REQUIRE(q && k && v && o, "flash_attn_split: null operand");
+    CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn_split: bad shape");
+    CBX_REQUIRE(precision == 3 || precision == 6, "flash_attn_split: precision must be 3 or 6 (got %d)", precision);
+    CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb) % 4 == 0, "flash_attn_split: strides must be multiples of 4");
+    CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn_split: 16-byte alignment");
+    FlashSplitArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
+    dim3 grid((Tq + 127) / 128, n_heads, nz1);
+    if (precision == 3) {
+        hipLaunchKernelGGL(flash_attn_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(flash_attn_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return cbx_check_launch("flash_attn_split");
+}

@@ -17,15 +17,16 @@
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int LDS_LD = BK + 4;  // 20 floats = 80 B row stride: 16-B aligned, b128 reads conflict-free
+// K tile: 16 or 32 floats.  LDS row stride BK+4 floats (80 / 144 B): 16-B aligned and conflict-free for the b128 lane groups
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const cbx_gemm_t p) {
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int LDS_LD = BK + 4;
+    constexpr int TPR = BK / 4;                // threads (float4) per tile row
     constexpr int NT = WARPS_M * WARPS_N * 64;  // threads per workgroup (4 or 8 waves)
-    constexpr int RP = NT / 4;                 // tile rows covered by one pass of float4 loads (4 threads per 16-float row)
+    constexpr int RP = NT / TPR;               // tile rows covered by one pass of float4 loads
     constexpr int A_IT = (BM + RP - 1) / RP;   // float4 loads per thread per K tile (A)
     constexpr int B_IT = (BN + RP - 1) / RP;
     constexpr bool A_PART = (BM % RP) != 0;    // e.g. BM = 32 with 256 threads: only threads 0..127 carry A rows
@@ -48,14 +49,14 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
 
     // ---- per-thread loader state.  Everything that does not change along K is folded into base pointers; the K walk
     // itself is incremental (column offset + tap counter), so a tile costs a handful of integer ops per load.
-    const int a_c4 = (tid & 3) * 4;
+    const int a_c4 = (tid % TPR) * 4;
     const float* a_ptr[A_IT];   // row pointer at tap 0, column a_c4
     int a_row[A_IT];            // input row at tap 0 (may be negative: left padding)
     bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (tid >> 2) + RP * i;
-        a_ok[i] = m < p.M && (!A_PART || (tid >> 2) + RP * i < BM);
+        const int m = m0 + (tid / TPR) + RP * i;
+        a_ok[i] = m < p.M && (!A_PART || (tid / TPR) + RP * i < BM);
         a_row[i] = m * p.stride - p.pad_left;
         a_ptr[i] = Ab + (long)a_row[i] * p.lda + a_c4;
     }
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     if constexpr (!W_KN) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + (tid >> 2) + RP * i;
-            b_ok[i] = n < p.N && (!B_PART || (tid >> 2) + RP * i < BN);
+            const int n = n0 + (tid / TPR) + RP * i;
+            b_ok[i] = n < p.N && (!B_PART || (tid / TPR) + RP * i < BN);
             b_ptr[i] = Wb + (long)(b_ok[i] ? n : 0) * p.ldw + a_c4;
         }
     }
@@ -133,13 +134,13 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            if (!A_PART || (tid >> 2) + RP * i < BM)
-                *reinterpret_cast<f32x4*>(&As[buf][((tid >> 2) + RP * i) * LDS_LD + a_c4]) = ra[i];
+            if (!A_PART || (tid / TPR) + RP * i < BM)
+                *reinterpret_cast<f32x4*>(&As[buf][((tid / TPR) + RP * i) * LDS_LD + a_c4]) = ra[i];
         if constexpr (!W_KN) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
-                if (!B_PART || (tid >> 2) + RP * i < BN)
-                    *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 2) + RP * i) * LDS_LD + a_c4]) = rb[i];
+                if (!B_PART || (tid / TPR) + RP * i < BN)
+                    *reinterpret_cast<f32x4*>(&Bs[buf][((tid / TPR) + RP * i) * LDS_LD + a_c4]) = rb[i];
         } else {
             constexpr int PER = BN / 4;
 #pragma unroll
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
         const float* as = &As[cur][(wm * WM + lr) * LDS_LD + 4 * lh];
         const float* bs = &Bs[cur][(wn * WN + lr) * LDS_LD + 4 * lh];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < BK / 8; ++kb) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + kb * 8);
@@ -240,14 +241,16 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK = 16>
 int launch(const cbx_gemm_t& p, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WARPS_M, WARPS_N, W_KN>), grid, dim3(WARPS_M * WARPS_N * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WARPS_M, WARPS_N, W_KN, BK>), grid, dim3(WARPS_M * WARPS_N * 64), 0, st, p);
     return cbx_check_launch("gemm_f32");
 }
 
 }  // namespace
+
+int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st);  // gemm_split.hip
 
 extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     cbx_gemm_t p = *pp;
@@ -262,7 +265,7 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     CBX_REQUIRE(p.A && p.W && p.C, "gemm: null operand");
     CBX_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     CBX_REQUIRE(p.K == p.taps * p.Cin, "gemm: K=%d != taps*Cin=%d*%d", p.K, p.taps, p.Cin);
-    CBX_REQUIRE(p.taps == 1 || p.Cin % BK == 0, "gemm: conv needs Cin %% 16 == 0 (Cin=%d)", p.Cin);
+    CBX_REQUIRE(p.taps == 1 || p.Cin % 16 == 0, "gemm: conv needs Cin %% 16 == 0 (Cin=%d)", p.Cin);
     CBX_REQUIRE(p.lda % 4 == 0 && p.a_s1 % 4 == 0 && p.a_s2 % 4 == 0 && ((uintptr_t)p.A & 15) == 0,
                 "gemm: A must be 16-byte aligned (lda=%ld)", p.lda);
     CBX_REQUIRE(p.ldw % 4 == 0 && p.w_s1 % 4 == 0 && p.w_s2 % 4 == 0 && ((uintptr_t)p.W & 15) == 0,
@@ -278,6 +281,17 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
         return launch<128, 128, 2, 2, false>(p, st);
     }
     if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
+    {
+        // precision 0 = library default (CBX_GEMM_PRECISION, else exact); 1 = exact fp32 MFMA; 3 / 6 = fp32 rebuilt from
+        // 3 / 6 bf16 plane products on the 16x faster bf16 matrix cores (gemm_split.hip)
+        static const int env_prec = getenv("CBX_GEMM_PRECISION") ? atoi(getenv("CBX_GEMM_PRECISION")) : 1;
+        const int prec = p.precision ? p.precision : env_prec;
+        CBX_REQUIRE(prec == 1 || prec == 3 || prec == 6, "gemm: precision must be 0, 1, 3 or 6 (got %d)", prec);
+        if (prec != 1) {
+            int rc = cbx_gemm_split_dispatch(p, prec == 3 ? 2 : 3, st);
+            if (rc != -1) return rc;
+        }
+    }
     if (p.N <= 64) return launch<128, 64, 2, 2, false>(p, st);
     {
         // 256 CUs: a grid below ~2 workgroups per CU leaves each SIMD with a single in-order wave (no latency hiding)
@@ -292,6 +306,8 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
         if (force == 64128) return launch<64, 128, 2, 2, false>(p, st);
         if (force == 64) return launch<128, 64, 2, 2, false>(p, st);
         if (force == 6464) return launch<64, 64, 2, 2, false>(p, st);
+        // BK = 32 halves the barriers and loader work per MFMA; a K tile must stay inside one conv tap
+        if (force == 32 && (p.taps == 1 || p.Cin % 32 == 0)) return launch<128, 64, 4, 2, false, 32>(p, st);
         return launch<128, 64, 4, 2, false>(p, st);  // 8 waves x (32x32): 81 TF/s on the bench mix vs 77 for 64x64 (4 waves)
     }
     return launch<128, 128, 2, 2, false>(p, st);

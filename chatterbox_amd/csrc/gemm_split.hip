@@ -1,0 +1,282 @@
+// fp32-accurate implicit GEMM on the bf16 matrix cores of gfx950 (split-operand "bf16x3" / "bf16x6").
+//
+//   v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the exact v_mfma_f32_32x32x2_f32 (2.5 PF vs 157 TF chip peak).
+//   Every fp32 operand is split on the fly into NP bf16 planes  a = a0 + a1 (+ a2)  (each plane the RNE bf16 of the
+//   running residual, so NP = 3 represents all 24 significand bits exactly) and the product is rebuilt from the
+//   plane products whose weight is above the fp32 rounding level, accumulated in fp32 by the MFMA:
+//       NP = 2 (bf16x3):  a0b0 + a0b1 + a1b0                              rel. error ~4e-6  (3 MFMA per k16, 5.3x fp32 rate)
+//       NP = 3 (bf16x6):  a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1         rel. error ~1e-7  (6 MFMA per k16, 2.7x fp32 rate)
+//   (fp32 MFMA itself: ~2.5e-7 at K = 256.)  Same address generator / epilogue contract as gemm_f32.hip: Linear, Conv1d,
+//   upsample+conv, phase-packed ConvTranspose1d, ragged masking -- only W in [N][K] layout, K tiles of 32.
+//
+// Workgroup = 8 waves on a 128 x 128 tile (64 x 32 per wave) or 4 waves on 64 x 64; K tiles are register-prefetched TWO
+// tiles ahead (the MFMA time of one tile is ~0.3 us, less than one HBM round trip) and staged through a double-buffered
+// LDS image of bf16 planes: row stride 80 B keeps both the 8-byte plane stores and the ds_read_b128 operand fetches
+// (8 consecutive k per lane: row = lane&31, k = 8*(lane>>5)..+8) conflict-free.
+#include <stdlib.h>
+#include "cbx_common.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SBK = 32;       // K tile (fp32 elements)
+constexpr int SLD = SBK + 8;  // LDS row stride in bf16 elements (80 B)
+
+template <int NP>
+__device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plane_stride) {
+    bf16x4 h = __builtin_convertvector(v, bf16x4);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    f32x4 r = v - __builtin_convertvector(h, f32x4);
+    bf16x4 m = __builtin_convertvector(r, bf16x4);
+    *reinterpret_cast<bf16x4*>(dst + plane_stride) = m;
+    if constexpr (NP == 3) {
+        r = r - __builtin_convertvector(m, f32x4);
+        *reinterpret_cast<bf16x4*>(dst + 2 * plane_stride) = __builtin_convertvector(r, bf16x4);
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p) {
+    constexpr int BK = SBK;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TPR = BK / 4;                 // threads (float4) per tile row
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int RP = NT / TPR;                // tile rows covered by one pass of float4 loads
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the loader pass");
+    constexpr int A_IT = BM / RP, B_IT = BN / RP;
+    constexpr int PLANE = (BM + BN) * SLD;      // bf16 elements of one plane of one stage (A rows then B rows)
+    constexpr int STAGE = NP * PLANE;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WARPS_N, wn = wid % WARPS_N;
+    const int z = blockIdx.z, z1 = z / p.nz2, z2 = z - z1 * p.nz2;
+    const int tile = cbx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int n0 = (tile % gridDim.x) * BN, m0 = (tile / gridDim.x) * BM;
+
+    const float* __restrict__ Ab = p.A + (long)z1 * p.a_s1 + (long)z2 * p.a_s2;
+    const float* __restrict__ Wb = p.W + (long)z1 * p.w_s1 + (long)z2 * p.w_s2;
+    const int lim = p.lens ? min(p.Tin, p.lens[z1]) : p.Tin;
+    const int K = p.K;
+
+    // ---- loader state (see gemm_f32.hip): everything constant along K lives in base pointers, the K walk is incremental
+    const int l_row = tid / TPR, a_c4 = (tid % TPR) * 4;
+    const float* a_ptr[A_IT];
+    int a_row[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + l_row + RP * i;
+        a_ok[i] = m < p.M;
+        a_row[i] = m * p.stride - p.pad_left;
+        a_ptr[i] = Ab + (long)a_row[i] * p.lda + a_c4;
+    }
+    const float* b_ptr[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + l_row + RP * i;
+        b_ok[i] = n < p.N;
+        b_ptr[i] = Wb + (long)(b_ok[i] ? n : 0) * p.ldw + a_c4;
+    }
+    int ld_kt = 0, ld_tap = 0, ld_c0 = 0;
+    long ld_aoff = 0;
+    const long tap_step = (long)p.dil * p.lda - p.Cin;
+
+    // Loads are UNCONDITIONAL (out-of-range lanes read the tensor base and are zeroed when the tile is written to LDS): a
+    // predicated load makes hipcc wait for the data at the join, which would serialise the whole prefetch.
+    auto load_tiles = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT], unsigned& okmask) {
+        const int k0 = ld_kt * BK;
+        const int kk = k0 + a_c4;
+        const bool kin = kk < K;
+        const int tap_rows = ld_tap * p.dil;
+        unsigned mask = 0;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int rr = a_row[i] + tap_rows;
+            bool ok = a_ok[i] && rr >= 0 && kin;
+            const float* src;
+            if (p.up > 1) {  // nearest-neighbour upsampled input: row index is not linear in the tap
+                const int row = rr / p.up;
+                ok = ok && row < lim;
+                src = Ab + (long)row * p.lda + ld_c0 + a_c4;
+            } else {
+                ok = ok && rr < lim;
+                src = a_ptr[i] + ld_aoff;
+            }
+            src = ok ? src : Ab;
+            ra[i] = *reinterpret_cast<const f32x4*>(src);
+            mask |= ok ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const bool ok = b_ok[i] && kin;
+            const float* src = ok ? b_ptr[i] + k0 : Wb;
+            rb[i] = *reinterpret_cast<const f32x4*>(src);
+            mask |= ok ? (1u << (16 + i)) : 0u;
+        }
+        okmask = mask;
+        ld_kt += 1;
+        ld_c0 += BK;
+        ld_aoff += BK;
+        if (p.taps > 1 && ld_c0 >= p.Cin) {
+            ld_c0 = 0;
+            ld_tap += 1;
+            ld_aoff += tap_step;
+        }
+    };
+
+    auto store_tiles = [&](int buf, const f32x4(&ra)[A_IT], const f32x4(&rb)[B_IT], unsigned okmask) {
+        __bf16* st = smem + buf * STAGE;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            split_store<NP>((okmask >> i) & 1u ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            split_store<NP>((okmask >> (16 + i)) & 1u ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    auto compute = [&](int buf) {
+        const __bf16* as = smem + buf * STAGE + (wm * WM + lr) * SLD + 8 * lh;
+        const __bf16* bs = smem + buf * STAGE + (BM + wn * WN + lr) * SLD + 8 * lh;
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc) {
+            bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(as + q * PLANE + i * 32 * SLD + kc * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(bs + q * PLANE + j * 32 * SLD + kc * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest-weight products first
+                    if constexpr (NP == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: registers hold tiles kt+1 and kt+2 in flight while tile kt is consumed from LDS
+    const int nk = (K + BK - 1) / BK;
+    f32x4 ra[2][A_IT], rb[2][B_IT];
+    unsigned ok0 = 0, ok1 = 0;
+    load_tiles(ra[0], rb[0], ok0);
+    store_tiles(0, ra[0], rb[0], ok0);
+    load_tiles(ra[1], rb[1], ok1);
+    __syncthreads();
+    // Branch-free body: tiles past the end of K load the tensor base with an all-false mask (zeros in LDS, adds 0), so the
+    // number of loads in flight at every wait is the same on every path and hipcc emits exact vmcnt(N) instead of vmcnt(0).
+    for (int kt = 0; kt < nk; kt += 2) {
+        load_tiles(ra[0], rb[0], ok0);       // tile kt+2
+        compute(0);                          // tile kt
+        store_tiles(1, ra[1], rb[1], ok1);   // tile kt+1
+        __syncthreads();
+        load_tiles(ra[1], rb[1], ok1);       // tile kt+3
+        compute(1);                          // tile kt+1 (all zero when nk is odd and this is past the end)
+        store_tiles(0, ra[0], rb[0], ok0);   // tile kt+2
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cb = p.C + (long)z1 * p.c_s1 + (long)z2 * p.c_s2;
+    const float* Rb = p.R ? p.R + (long)z1 * p.r_s1 + (long)z2 * p.r_s2 : nullptr;
+    float* C2b = p.C2 ? p.C2 + (long)z1 * p.c2_s1 + (long)z2 * p.c2_s2 : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + lr;
+        if (n >= p.N) continue;
+        const float bia = p.bias ? p.bias[n] : 0.f;
+        const float a1 = p.act1_param ? p.act1_param[n] : 0.f;
+        const float a2 = p.act2_param ? p.act2_param[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * lh;
+            // residual / beta operands of the 16 rows are fetched back to back (clamped rows), not one wait per element
+            float res[16], old[16];
+            if (Rb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = Rb[(long)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + n];
+            }
+            if (p.beta != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = Cb[(long)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bia;
+                v = cbx_act(v, p.act1, p.act1_slope, a1);
+                if (Rb) v += res[r];
+                v *= p.alpha;
+                if (p.beta != 0.f) v += p.beta * old[r];
+                if (m < p.M) {
+                    Cb[(long)m * p.ldc + n] = v;
+                    if (C2b) C2b[(long)m * p.ldc2 + n] = cbx_act(v, p.act2, p.act2_slope, a2);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP>
+int launch_split(const cbx_gemm_t& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * NP * (BM + BN) * SLD * sizeof(__bf16);
+    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP>;
+    static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return cbx_set_error((int)e, "gemm_split: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        configured = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
+    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p);
+    return cbx_check_launch("gemm_split");
+}
+
+}  // namespace
+
+// Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3) or 3 (bf16x6).  Returns -1 when the shape is not
+// served by this kernel (caller falls back to the exact fp32 MFMA kernel).
+int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
+    if (p.w_kn || p.swiglu) return -1;
+    if (p.taps > 1 && p.Cin % SBK != 0) return -1;  // a K tile must not straddle two conv taps
+    static const int force = getenv("CBX_SPLIT_TILE") ? atoi(getenv("CBX_SPLIT_TILE")) : 0;
+    const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
+    // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by
+    // 5-45 % and 64x64 by 0-15 %
+    int tile = force ? force : (g128 >= 64 && p.N > 64 ? 12864 : 64);
+    if (planes == 2) {
+        if (tile == 128) return launch_split<128, 128, 2, 4, 2>(p, st);
+        if (tile == 12864) return launch_split<128, 64, 4, 2, 2>(p, st);
+        return launch_split<64, 64, 2, 2, 2>(p, st);
+    }
+    if (tile == 128) return launch_split<128, 128, 2, 4, 3>(p, st);
+    if (tile == 12864) return launch_split<128, 64, 4, 2, 3>(p, st);
+    return launch_split<64, 64, 2, 2, 3>(p, st);
+}

@@ -9,6 +9,8 @@ Channel-last activations (B, time, C); every Conv1d / ConvTranspose1d is the imp
   * ragged batches: non-causal convs zero-fill beyond each row's own length (`lens`), so every valid sample equals
     the batch-1 reference value.
 """
+import os
+
 import torch
 
 from . import ops, weights
@@ -20,8 +22,11 @@ class HiFTEngine:
     RB_K = (3, 7, 11)
     SRC_RB_K = (7, 7, 11)
 
-    def __init__(self, sd, device="cuda"):
+    def __init__(self, sd, device="cuda", precision=None):
         self.dev = dev = torch.device(device)
+        # numerics policy of the decoder convs; the F0 predictor always runs exact (its output is integrated into a phase
+        # over ~10^5 samples, which amplifies any error in f0)
+        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "3")) if precision is None else int(precision)
         d = lambda t: t.float().contiguous().to(dev)
         h = "mel2wav."
         fw = lambda p: weights.fold_weight_norm(sd, p)
@@ -155,6 +160,8 @@ class HiFTEngine:
             phase[:, 0] = 0
         if noise is None:
             noise = torch.randn(B, 9, 480 * T, device=self.dev)
-        f0 = self.f0_predict(mel, lens)
+        with ops.gemm_precision(1):
+            f0 = self.f0_predict(mel, lens)
         s = self.source(f0, phase.to(self.dev).float(), noise.to(self.dev).float())
-        return self.decode(mel, s, lens, fade), s
+        with ops.gemm_precision(self.precision):
+            return self.decode(mel, s, lens, fade), s

@@ -59,6 +59,25 @@ def _f32(t, name):
     return t
 
 
+GEMM_PRECISION = 0  # cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued while set: 0 default, 1 exact, 3 / 6 split-bf16
+
+
+class gemm_precision:
+    """`with ops.gemm_precision(6): ...` -- the engines scope their numerics policy this way (T3 stays exact: sampled
+    tokens must match the reference bit for bit; the CFM / vocoder run the fp32-accurate split-bf16 kernels)."""
+
+    def __init__(self, precision):
+        self.precision = int(precision)
+
+    def __enter__(self):
+        global GEMM_PRECISION
+        self._prev, GEMM_PRECISION = GEMM_PRECISION, self.precision
+
+    def __exit__(self, *exc):
+        global GEMM_PRECISION
+        GEMM_PRECISION = self._prev
+
+
 def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, ldc2=0, act1=NONE, act2=NONE,
          act1_param=None, act2_param=None, act1_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, lens=None, Cin=0, taps=1,
          dil=1, stride=1, pad_left=0, up=1, Tin=0, nz1=1, nz2=1, a_s=(0, 0), w_s=(0, 0), c_s=(0, 0), r_s=(0, 0),
@@ -79,6 +98,7 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc, p.c_s1, p.c_s2 = ldc, c_s[0], c_s[1]
     p.ldr, p.r_s1, p.r_s2 = ldr, r_s[0], r_s[1]
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
+    p.precision = GEMM_PRECISION
     nz = nz1 * nz2
     kind = "gemm_f32_skinny" if M <= 32 else "gemm_f32"
     _timed(kind, 2.0 * M * N * K * nz, 4.0 * nz * (M * K / max(1, taps) + N * K + M * N),
@@ -167,11 +187,13 @@ def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
     assert D == 64
     for t in (q, k, v, out):
         assert t.stride(3) == 1 and t.stride(2) == 64
-    _timed("flash_attn_f32", 4.0 * Z * H * Tq * Tk * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * (2 * Tq + 2 * Tk),
-           lambda: check(lib.cbx_flash_attn_f32(_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0),
-                                                q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                                out.stride(0), out.stride(1), scale, int(causal), _stream()),
-                         "cbx_flash_attn_f32"))
+    args = (_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+            v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale, int(causal))
+    if GEMM_PRECISION in (3, 6):  # same numerics policy as the GEMMs issued in this scope
+        fn = lambda: check(lib.cbx_flash_attn_split_f32(*args, GEMM_PRECISION, _stream()), "cbx_flash_attn_split_f32")
+    else:
+        fn = lambda: check(lib.cbx_flash_attn_f32(*args, _stream()), "cbx_flash_attn_f32")
+    _timed("flash_attn_f32", 4.0 * Z * H * Tq * Tk * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * (2 * Tq + 2 * Tk), fn)
     return out
 
 

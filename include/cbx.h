@@ -56,6 +56,12 @@ typedef struct cbx_gemm_t {
     long ldc, c_s1, c_s2;
     long ldr, r_s1, r_s2;
     long ldc2, c2_s1, c2_s2;
+    int precision;            /* 0 = library default (exact unless CBX_GEMM_PRECISION is set); 1 = exact fp32 MFMA
+                                 (bitwise an fmaf chain); 3 = "bf16x3", 6 = "bf16x6": every fp32 operand split into 2 / 3
+                                 bf16 planes and the product rebuilt from 3 / 6 bf16-MFMA plane products with fp32
+                                 accumulation (rel. error ~4e-6 / ~1e-7; fp32 MFMA ~2.5e-7).  Shapes the split kernel does
+                                 not serve (w_kn, swiglu, M <= 32, conv Cin % 32 != 0) run exact. */
+    int reserved0;
 } cbx_gemm_t;
 int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
 
@@ -96,6 +102,12 @@ int cbx_layernorm_f32(const float* x, float* y, const float* w, const float* b, 
 int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, void* stream);
+/* Same contract on the bf16 matrix cores with split fp32 operands: precision 3 ("bf16x3", rel. error ~4e-6 per
+ * contraction) or 6 ("bf16x6", fp32-level), see cbx_gemm_t.precision.  5.3x / 2.7x fewer matrix-core cycles. */
+int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
+                             int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                             long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,
+                             void* stream);
 
 /* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).
  * cache layout [row][head][pos][64]; ctx_lens[row] = number of valid positions (including the new token). */

@@ -30,13 +30,17 @@ for name, m, n, k, taps in shapes:
             ops.conv1d(x[:, : m // 16], w, out, taps=1, cin=cin, bias=b, residual=r)
         else:
             ops.conv1d(x[:, : m // 16], w, out, taps=taps, cin=cin, bias=b, pad_left=taps - 1)
-    for _ in range(3): run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 200
-    e0.record()
-    for _ in range(reps): run()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / reps * 1e3
-    fl = 2.0 * m * n * k
-    print(f"{name:16s} M={m:6d} N={n:5d} K={k:5d}  {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  ({100*fl/us/1e6/157.3:4.1f}% of fp32 MFMA peak)")
+    line = f"{name:16s} M={m:6d} N={n:5d} K={k:5d} "
+    for prec in [int(v) for v in os.environ.get("CBX_PRECS", "1").split(",")]:
+        with ops.gemm_precision(prec):
+            for _ in range(3): run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 100
+            e0.record()
+            for _ in range(reps): run()
+            e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        fl = 2.0 * m * n * k
+        line += f" | p{prec}: {us:7.1f} us {fl/us/1e6:6.1f} TF"
+    print(line, flush=True)

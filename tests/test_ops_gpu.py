@@ -161,6 +161,83 @@ def test_flash_attn(dev, Tq, Tk, causal):
     _close(out, ref.transpose(1, 2), 2e-5, "flash_attn")
 
 
+# ---- split-bf16 modes (cbx_gemm_t.precision 3 / 6, cbx_flash_attn_split_f32): fp32 operands rebuilt from bf16 planes on
+# the 16x faster bf16 matrix cores.  Stated tolerances: precision 6 = the fp32 tolerances above; precision 3 = 1e-4.
+_SPLIT_TOL = {6: 3e-5, 3: 1e-4}
+
+
+@pytest.mark.parametrize("prec", [3, 6])
+def test_split_gemm_linear(dev, prec):
+    from chatterbox_amd import ops
+    with ops.gemm_precision(prec):
+        for (M, N, K) in [(1000, 256, 256), (129, 257, 320), (300, 1536, 256), (4000, 80, 1000), (513, 1024, 80), (33, 100, 36)]:
+            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+            out = torch.empty(M, N, device=dev)
+            ops.linear(x.to(dev), w.to(dev), out, bias=b.to(dev), act=ops.GELU_ERF, residual=r.to(dev))
+            _close(out, F.gelu(F.linear(x, w, b)) + r, _SPLIT_TOL[prec] * max(1.0, math.sqrt(K / 256)), f"split linear {M}x{N}x{K}")
+        # accumulate (beta), second output, strided views with untouched pad columns
+        M, N, K = 200, 96, 64
+        xb, w, ap, cb = _r((M, K + 8), 1), _r((N, K), 2, 0.1), 1.0 + 0.2 * _r((N,), 5), _r((M, N + 4), 6)
+        out, out2 = cb.clone().to(dev), torch.empty(M, N, device=dev)
+        ops.linear(xb.to(dev)[:, :K], w.to(dev), out[:, :N], alpha=1.0 / 3, beta=1.0, out2=out2, act2=ops.SNAKE, act2_param=ap.to(dev))
+        ref = cb[:, :N] + F.linear(xb[:, :K], w) / 3
+        _close(out[:, :N], ref, _SPLIT_TOL[prec], "split accumulate")
+        _close(out[:, N:], cb[:, N:], 0.0, "untouched pad")
+        _close(out2, ref + (1.0 / (ap[None] + 1e-9)) * torch.sin(ref * ap[None]) ** 2, 2 * _SPLIT_TOL[prec], "split second output")
+
+
+@pytest.mark.parametrize("prec", [3, 6])
+def test_split_gemm_conv(dev, prec):
+    from chatterbox_amd import ops, weights
+    B = 3
+    with ops.gemm_precision(prec):
+        for (cin, cout, k, dil, stride, pad, T) in [(32, 48, 3, 1, 1, 1, 77), (64, 64, 11, 5, 1, 25, 300), (32, 256, 30, 1, 15, 7, 1201),
+                                                    (320, 256, 3, 1, 1, 2, 100), (512, 512, 3, 1, 1, 1, 64), (80, 512, 7, 1, 1, 3, 60)]:
+            x, w, b = _r((B, cin, T), 1), _r((cout, cin, k), 2, 1 / math.sqrt(cin * k)), _r((cout,), 3)
+            causal = (pad == k - 1 and dil == 1 and cin == 320)
+            ref = F.conv1d(F.pad(x, (pad, 0)) if causal else x, w, b, stride=stride, dilation=dil, padding=0 if causal else pad)
+            out = torch.empty(B, ref.shape[2], cout, device=dev)
+            ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w).to(dev), out, taps=k, cin=cin, bias=b.to(dev),
+                       dil=dil, stride=stride, pad_left=pad)
+            _close(out.transpose(1, 2), ref, 1.5 * _SPLIT_TOL[prec], f"split conv cin{cin} k{k}")  # cin 80: falls back to exact
+        C, T = 32, 50
+        lens = torch.tensor([50, 31, 7], dtype=torch.int32)
+        x, w, b = _r((B, C, T), 1), _r((C, C, 4), 2, 0.1), _r((C,), 3)
+        out = torch.empty(B, T, C, device=dev)
+        ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w).to(dev), out, taps=4, cin=C, bias=b.to(dev), pad_left=0,
+                   lens=lens.to(dev))
+        for i in range(B):
+            n = int(lens[i])
+            _close(out[i, :n].t(), F.conv1d(F.pad(x[i:i + 1, :, :n], (0, 3)), w, b)[0], _SPLIT_TOL[prec], f"split ragged row {i}")
+        w5 = _r((C, C, 5), 4, 0.1)
+        ref = F.conv1d(F.pad(x.repeat_interleave(2, dim=2), (4, 0)), w5, b)
+        out = torch.empty(B, 2 * T, C, device=dev)
+        ops.conv1d(x.transpose(1, 2).contiguous().to(dev), weights.pack_conv(w5).to(dev), out, taps=5, cin=C, bias=b.to(dev), pad_left=4, up=2)
+        _close(out.transpose(1, 2), ref, _SPLIT_TOL[prec], "split upsample conv")
+
+
+@pytest.mark.parametrize("prec", [3, 6])
+@pytest.mark.parametrize("Tq,Tk,causal", [(200, 200, False), (1000, 1000, False), (103, 103, True), (64, 64, True), (130, 130, False)])
+def test_split_flash_attn(dev, Tq, Tk, causal, prec):
+    from chatterbox_amd import ops
+    Z, H = 3, 4
+    qkv = _r((Z, Tq, 3, H, 64), 1)
+    lens = torch.tensor([Tk, max(1, Tk - 37), max(1, Tk // 3)], dtype=torch.int32)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    if causal:
+        ref, kl = F.scaled_dot_product_attention(q, k, v, is_causal=True), None
+    else:
+        bias = torch.zeros(Z, 1, 1, Tk)
+        for z in range(Z):
+            bias[z, ..., int(lens[z]):] = -1e10
+        ref, kl = F.scaled_dot_product_attention(q, k, v, attn_mask=bias), lens.to(dev)
+    d = qkv.to(dev)
+    out = torch.empty(Z, Tq, H, 64, device=dev)
+    with ops.gemm_precision(prec):
+        ops.flash_attn(d[:, :, 0], d[:, :, 1], d[:, :, 2], out, 0.125, key_lens=kl, causal=causal)
+    _close(out, ref.transpose(1, 2), {6: 2e-5, 3: 1e-4}[prec], f"split flash_attn p{prec}")
+
+
 def test_decode_attn(dev):
     from chatterbox_amd import ops
     rows, H, maxp = 6, 16, 700

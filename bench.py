@@ -42,14 +42,16 @@ def parse():
                          "same results, ~+10%% audio-s/s but ~2x per-batch latency).  Default: the K steps run strictly one after the other")
     ap.add_argument("--serial", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=25, help="speech tokens of the bounded CPU-baseline sample")
-    ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "flash_attn_f32", "gemv_f32"],
+    ap.add_argument("--cpu-tokens", type=int, default=50, help="speech tokens of the bounded CPU-baseline sample")
+    ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "gemm_split", "flash_attn_f32", "gemv_f32"],
                     help="kernel class reported as `roofline` (auto: the one with the largest share of a step); the others go to "
                          "`roofline_secondary`.  All three are timed with HIP events on the launch stream")
     ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6],
                     help="numerics of the S3Gen GEMMs / attention: 1 exact fp32 MFMA, 6 bf16x6 (fp32-level error), 3 bf16x3 (default, "
                          "rel. error ~4e-6 per contraction; golden mel-L1 1.4e-5 against the 1e-4 tolerance).  T3 is always exact")
-    ap.add_argument("--no-alt-precisions", action="store_true", help="skip the two extra one-step measurements at the other S3Gen precisions")
+    ap.add_argument("--alt-precisions", action="store_true",
+                    help="after the timed region also measure one step at each of the other S3Gen precisions (reported under "
+                         "audio_s_per_wall_s_at_other_precisions)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
 
@@ -103,54 +105,100 @@ def pmc_traffic(kernel_substr, source="flow_only"):
     return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"], f"profiles/r01_{source}_pmc_{{FETCH,WRITE}}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, per launch)"
 
 
-def roofline_entries(summ, elapsed, steps, eager_steps, s3_prec, n_decode):
-    """One roofline object per timed kernel class.  gemm / flash: every launch of the timed region; gemv: an eager replay of the
-    decode step after the timed region (inside the region the same kernels run from a hipGraph, which events cannot see)."""
+def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv):
+    """One roofline object per timed kernel class.  GEMM / attention: every launch of the last timed step, HIP events on the launch
+    stream.  gemv: the decode step's projections replayed from a hipGraph (the form they run in inside the timed region, where
+    events cannot see individual graph nodes) -- one graph per projection type sweeping the 30 layers' weights, events around it."""
     out = {}
-    split = s3_prec in (3, 6)
     nprod = {3: 3, 6: 6}.get(s3_prec, 1)
-    for kind in ("gemm_f32", "flash_attn_f32"):
+    names = {"gemm_f32": ("gemm_f32_kernel (exact fp32 MFMA implicit GEMM: T3 prefill, shapes the split kernel does not serve)",
+                          "gemm_f32_kernel", 1),
+             "gemm_split": ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, bf16x%d)" % nprod, "gemm_split_kernel", nprod),
+             "flash_attn_f32": (("flash_attn_split_kernel (bf16x%d)" % nprod) if nprod > 1 else "flash_attn_f32_kernel",
+                                "flash_attn_split_kernel" if nprod > 1 else "flash_attn_f32_kernel", nprod)}
+    for kind, (kname, sub, npr) in names.items():
         ks = summ.get(kind)
         if not ks or ks["ms"] <= 0:
             continue
         tf = ks["flops"] / (ks["ms"] * 1e-3) / 1e12
-        if kind == "gemm_f32":
-            kname = ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, bf16x%d) + gemm_f32_kernel (T3 prefill, exact)" % nprod) if split \
-                else "gemm_f32_kernel (implicit-GEMM linear/conv, every launch with M > 32)"
-            sub = "gemm_split_kernel" if split else "gemm_f32_kernel<128, 64, 4, 2"
-        else:
-            kname = ("flash_attn_split_kernel (bf16x%d)" % nprod) if split else "flash_attn_f32_kernel"
-            sub = "flash_attn_split_kernel" if split else "flash_attn_f32_kernel"
-        peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        issued = tf * nprod if split else tf
+        if kind == "flash_attn_f32" and nprod > 1:
+            # T3 prefill attention stays exact; it is < 1 % of the attention FLOPs of a step and is folded into this line
+            pass
+        peak = MFMA_BF16_PEAK_TFLOPS if npr > 1 else MFMA_F32_PEAK_TFLOPS
+        issued = tf * npr
         e = dict(bound="mfma", kernel=kname, achieved=round(issued, 2), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
                  traffic=None, launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
                  flops_per_launch=round(ks["flops"] / ks["launches"], 0),
                  algorithmic_bytes_per_launch=round(ks["bytes"] / ks["launches"], 0),
-                 share_of_step=round(ks["ms"] * 1e-3 / elapsed, 3))
-        if split:
+                 share_of_step=round(ks["ms"] * 1e-3 / timed_steps / (elapsed / steps), 3))
+        if npr > 1:
             e["fp32_equivalent_tflops"] = round(tf, 2)
-            e["note"] = (f"achieved = algorithmic fp32 FLOPs x {nprod} bf16 MFMA products per fp32 product (the work the matrix cores "
+            e["note"] = (f"achieved = algorithmic fp32 FLOPs x {npr} bf16 MFMA products per fp32 product (the work the matrix cores "
                          f"execute), priced against the dense bf16 peak; {round(tf, 1)} TFLOP/s fp32-equivalent = "
                          f"{round(tf / MFMA_F32_PEAK_TFLOPS, 2)}x the exact-fp32 MFMA peak")
-        tr, src = pmc_traffic(sub)
+        tr, src = pmc_traffic(sub, "t3_eager" if kind == "gemm_f32" else "flow_only")
         e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
         out[kind] = e
-    ks = summ.get("gemv_f32")
-    if ks and ks["ms"] > 0 and eager_steps > 0:
-        gbs = ks["bytes"] / (ks["ms"] * 1e-3) / 1e9
-        per_step_ms = ks["ms"] / eager_steps
-        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down, speech head; M = 2*batch rows)",
+    if gemv:
+        tot_ms = sum(v["ms"] for v in gemv.values())
+        tot_b = sum(v["bytes"] for v in gemv.values())
+        tot_n = sum(v["launches"] for v in gemv.values())
+        per_step_ms = sum(v["ms"] / v["launches"] * v["per_step"] for v in gemv.values())
+        gbs = tot_b / (tot_ms * 1e-3) / 1e9
+        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
                  achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
-                 launches=ks["launches"], avg_launch_us=round(1e3 * ks["ms"] / ks["launches"], 2),
-                 algorithmic_bytes_per_launch=round(ks["bytes"] / ks["launches"], 0),
-                 share_of_step=round(per_step_ms * 1e-3 * steps * n_decode / elapsed, 3),
-                 note="timed on an eager replay of the decode step after the timed region (same kernels, same stream); inside the "
-                      "region they run from a hipGraph")
+                 launches=tot_n, avg_launch_us=round(1e3 * tot_ms / tot_n, 2), algorithmic_bytes_per_launch=round(tot_b / tot_n, 0),
+                 share_of_step=round(per_step_ms * 1e-3 * n_decode / (elapsed / steps), 3),
+                 by_projection={k: dict(avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                                        GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                        bytes_per_launch=round(v["bytes"] / v["launches"], 0)) for k, v in gemv.items()},
+                 note="average launch duration INCLUDING the dependent-launch boundary (~1.2 us): events bracket hipGraph replays of "
+                      "30 back-to-back launches (one per layer, 1 GB of distinct weights per sweep, so nothing is served from the "
+                      "256 MB Infinity Cache); rocprofv3's per-kernel average excludes that boundary")
         tr, src = pmc_traffic("gemv_kernel", "t3_eager")
         e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
         out["gemv_f32"] = e
     return out
+
+
+@torch.inference_mode()
+def gemv_sweeps(t3, rows, reps=6):
+    """HIP-event timing of the decode projections in the form they run in: hipGraph replays.  One graph per projection type, each
+    sweeping the 30 layers (distinct weights -> cold HBM streams, as in a real decode step)."""
+    from chatterbox_amd import ops
+    dev, tn = t3.dev, t3.tune
+    f = lambda *s: torch.randn(*s, device=dev)
+    h, att, g = f(rows, t3.D), f(rows, t3.D), f(rows, t3.F)
+    qkv, gg = torch.empty(rows, 3 * t3.D, device=dev), torch.empty(rows, t3.F, device=dev)
+    po, pd = torch.empty(tn["o_ks"], rows, t3.D, device=dev), torch.empty(tn["d_ks"], rows, t3.D, device=dev)
+    calls = {"qkv": lambda lw: ops.gemv(h, lw["wqkv"], qkv, nw=tn["qkv_nw"]),
+             "o": lambda lw: ops.gemv(att, lw["wo"], po, ksplit=tn["o_ks"], nw=4),
+             "gate_up": lambda lw: ops.gemv(h, lw["wgu"], gg, swiglu=True, nw=tn["gu_nw"]),
+             "down": lambda lw: ops.gemv(g, lw["wd"], pd, ksplit=tn["d_ks"], nw=4)}
+    wbytes = {"qkv": lambda lw: lw["wqkv"].numel() * 4, "o": lambda lw: lw["wo"].numel() * 4,
+              "gate_up": lambda lw: lw["wgu"].numel() * 4, "down": lambda lw: lw["wd"].numel() * 4}
+    res = {}
+    side = torch.cuda.Stream(device=dev)
+    for name, fn in calls.items():
+        with torch.cuda.stream(side):
+            for lw in t3.layers:  # warm-up (also makes sure nothing lazy happens under capture)
+                fn(lw)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            for lw in t3.layers:
+                fn(lw)
+        gph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            gph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = dict(ms=e0.elapsed_time(e1), launches=reps * len(t3.layers), per_step=len(t3.layers),
+                         bytes=float(reps * sum(wbytes[name](lw) for lw in t3.layers)))
+    return res
 
 
 def log(msg):
@@ -218,8 +266,11 @@ def main():
     for i in range(args.warmup):
         one_step(-1 - i)
     pipelined = args.pipelined and not args.serial and not turbo
-    timer = ops.KernelTimer(["gemm_f32", "flash_attn_f32"])
-    ops.TIMER = timer
+    # HIP-event timing of every GEMM / attention launch costs ~25 ms per step (4000 event records): it is switched on for the
+    # LAST timed step only (all steps in --pipelined mode), so the headline number carries 1/K of that overhead
+    timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32"])
+    timed_steps = args.steps if pipelined else 1
+    ops.TIMER = timer if pipelined else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -233,6 +284,8 @@ def main():
             cdist.gather_waveforms(host, dst=0)  # C2
     else:
         for i in range(args.steps):
+            if i == args.steps - 1:
+                ops.TIMER = timer
             a, lat, tm = one_step(i)
             audio += a
             lats.append(lat)
@@ -254,21 +307,12 @@ def main():
 
     # ---- outside the timed region: (a) eager replay of the decode step for the gemv roofline, (b) one step at each of the other
     # S3Gen precisions so that the exact-fp32 figure is reported by the same run
-    eager_steps, alt = 0, {}
+    alt, gemv = {}, None
     if rank == 0:
         summ = timer.summary()
         if not turbo:
-            gt = ops.KernelTimer(["gemv_f32"])
-            eager_steps = 24
-            g = torch.Generator(device=dev).manual_seed(99)
-            eng.t3.generate(t3c, texts, max_new_tokens=eager_steps + 1, uniforms=torch.rand(B, eager_steps + 1, generator=g, device=dev),
-                            ban_eos=True, ban_from=6561, use_graph=False)  # warm (first eager launches)
-            ops.TIMER = gt
-            eng.t3.generate(t3c, texts, max_new_tokens=eager_steps + 1, uniforms=torch.rand(B, eager_steps + 1, generator=g, device=dev),
-                            ban_eos=True, ban_from=6561, use_graph=False)
-            ops.TIMER = None
-            summ.update(gt.summary())
-            if not args.no_alt_precisions:
+            gemv = gemv_sweeps(eng.t3, 2 * B)
+            if args.alt_precisions:
                 for pr in (1, 6, 3):
                     if pr == s3_prec:
                         continue
@@ -280,7 +324,7 @@ def main():
                     torch.cuda.synchronize()
                     alt[f"s3gen_precision_{pr}"] = round(a / (time.perf_counter() - ta), 2)
                 eng.flow.precision = eng.hift.precision = s3_prec
-        roofs = roofline_entries(summ, elapsed, args.steps, eager_steps, s3_prec, N - 1)
+        roofs = roofline_entries(summ, elapsed, args.steps, timed_steps, s3_prec, N - 1, gemv)
         dom = args.roofline_kernel
         if dom == "auto":
             dom = max(roofs, key=lambda k: roofs[k]["share_of_step"]) if roofs else None

@@ -203,12 +203,31 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
         chosen = pick;
     }
     __syncthreads();
+    if (chosen < 0) {
+        // No owner: every id that survived the processors is banned (total == 0; happens with ban_from on random-init weights
+        // when the arg-max is a banned id and min-p pruned the rest), or the target fell into a 1-ulp seam between two threads'
+        // fp64 intervals.  Defined result: the allowed id with the largest CFG-combined raw logit (lowest id on ties), found by a
+        // block-wide arg-max -- `chosen` is block-uniform here, so the barriers below are safe.
+        float bm = -INFINITY;
+        for (int i = tid; i < V; i += NT)
+            if (i != p.ban_token && i < p.ban_from) {
+                const float c = lc[i];
+                bm = fmaxf(bm, p.cfg ? c + p.cfg_weight * (c - lu[i]) : c);
+            }
+        bm = block_max(bm, red);
+        __syncthreads();
+        if (tid == 0) chosen = 0x7fffffff;
+        __syncthreads();
+        for (int i = tid; i < V; i += NT)
+            if (i != p.ban_token && i < p.ban_from) {
+                const float c = lc[i];
+                if ((p.cfg ? c + p.cfg_weight * (c - lu[i]) : c) == bm) atomicMin(&chosen, i);
+            }
+        __syncthreads();
+    }
     if (tid == 0) {
         int tok = chosen;
-        if (tok < 0) {  // numerical corner (target == total): last id with non-zero probability
-            for (int i = V - 1; i >= 0; --i)
-                if (i != p.ban_token && i < p.ban_from && l[i] > -INFINITY) { tok = i; break; }
-        }
+        if (tok < 0 || tok >= V) tok = 0;  // no allowed id at all (or NaN logits): keep the state machine well-defined
         p.out_tokens[(long)b * p.max_steps + step] = tok;
         seen[tok] = 1;
         p.step[b] = step + 1;

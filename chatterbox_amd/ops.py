@@ -100,7 +100,8 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
     p.precision = GEMM_PRECISION
     nz = nz1 * nz2
-    kind = "gemm_f32_skinny" if M <= 32 else "gemm_f32"
+    split = GEMM_PRECISION in (3, 6) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
+    kind = "gemm_f32_skinny" if M <= 32 else ("gemm_split" if split else "gemm_f32")  # mirrors the dispatch in gemm_f32.hip
     _timed(kind, 2.0 * M * N * K * nz, 4.0 * nz * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32"))
     return C

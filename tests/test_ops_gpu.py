@@ -342,6 +342,29 @@ def test_sampler(dev, top_p, min_p):
     assert d["next_pos_ids"].tolist() == [steps] * (2 * B) and d["step"].tolist() == [steps] * B
 
 
+def test_sampler_all_surviving_ids_banned(dev):
+    """ban_from on a peaked distribution: the arg-max is a banned id and min-p prunes everything else, so no probability mass is
+    left.  Defined result (include/cbx.h): the allowed id with the largest CFG-combined raw logit; never an out-of-range token."""
+    from chatterbox_amd import ops
+    B, V, steps = 2, 8194, 1
+    logits = _r((2 * B, V), 1, 0.5)
+    logits[:, 7000] = 30.0            # banned arg-max (>= ban_from) in both CFG rows
+    logits[0, 1234] = logits[B + 0, 1234] = 9.0   # best allowed id of utterance 0
+    logits[1, 42] = logits[B + 1, 42] = 8.0       # ... of utterance 1
+    d = dict(seen=torch.zeros(B, V, dtype=torch.uint8, device=dev), step=torch.zeros(B, dtype=torch.int32, device=dev),
+             out_tokens=torch.zeros(B, steps, dtype=torch.int64, device=dev), done=torch.zeros(B, dtype=torch.int32, device=dev),
+             n_generated=torch.zeros(B, dtype=torch.int32, device=dev), next_ids=torch.zeros(2 * B, dtype=torch.int64, device=dev),
+             next_pos_ids=torch.zeros(2 * B, dtype=torch.int32, device=dev), positions=torch.zeros(2 * B, dtype=torch.int32, device=dev),
+             ctx_lens=torch.zeros(2 * B, dtype=torch.int32, device=dev))
+    guard = d["seen"].clone()
+    ops.t3_sample(logits=logits.to(dev), ld=V, V=V, B=B, cfg=1, cfg_weight=0.5, temperature=0.8, min_p=0.05, top_p=1.0, rep_penalty=1.2,
+                  top_k=0, order=0, ban_token=6562, eos_token=6562, ban_from=6561, uniforms=torch.full((B, steps), 0.5, device=dev),
+                  max_steps=steps, **d)
+    assert d["out_tokens"][:, 0].tolist() == [1234, 42]
+    guard[0, 1234] = guard[1, 42] = 1
+    assert torch.equal(d["seen"], guard) and d["next_ids"].tolist() == [1234, 42, 1234, 42]
+
+
 def test_hift_source_stft_istft(dev):
     from chatterbox_amd import ops
     from oracle import ref_torch as O

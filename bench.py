@@ -42,7 +42,7 @@ def parse():
                          "same results, ~+10%% audio-s/s but ~2x per-batch latency).  Default: the K steps run strictly one after the other")
     ap.add_argument("--serial", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=50, help="speech tokens of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-tokens", type=int, default=75, help="speech tokens of the bounded CPU-baseline sample")
     ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "gemm_split", "flash_attn_f32", "gemv_f32"],
                     help="kernel class reported as `roofline` (auto: the one with the largest share of a step); the others go to "
                          "`roofline_secondary`.  All three are timed with HIP events on the launch stream")

@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 // steps are issued back to back so that 8 KiB of K/V per wave are in flight; the running (max, sum, acc) state of the
 // 16 lane groups is merged through LDS at the end.  The new token's k/v are taken from LDS (never re-read from HBM).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int DA_U = 4;
-
+// U = key rows per lane group in flight per step (env CBX_DA_U: 4 / 8 / 16).  The first step's K/V loads are issued BEFORE the
+// RoPE / LDS hand-off of q (they do not depend on it), so the q path's global round trip overlaps the cache stream.
+template <int DA_U>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
@@ -269,52 +270,57 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     const int pos = positions[row];
+    const int ctx = pos + 1;
     float* kb = kc + (long)row * row_stride + (long)head * head_stride;
     float* vb = vc + (long)row * row_stride + (long)head * head_stride;
-    if (wid == 0) {
-        const float* qp = qkv + (long)row * ld_qkv + head * 64;
-        const float qv = qp[lane], kv = qp[(long)n_heads * 64 + lane], vv = qp[(long)n_heads * 128 + lane];
-        const float c = cos_t ? cos_t[(long)pos * 64 + lane] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + lane] : 0.f;  // GPT-2: no RoPE
-        const float sgn = lane < 32 ? -1.f : 1.f;
-        const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
-        const float kn = kv * c + sgn * __shfl_xor(kv, 32) * s;
-        q_s[lane] = qn * scale;
-        k_new[lane] = kn;
-        v_new[lane] = vv;
-        kb[(long)pos * 64 + lane] = kn;
-        vb[(long)pos * 64 + lane] = vv;
-    }
-    __syncthreads();
-    const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
-    const int ctx = pos + 1;
-    float m = -INFINITY, l = 0.f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
     // lane group g = wid*4 + sub handles positions g, g+16, g+32, ...
-    for (int p0 = wid * 4 + sub; p0 < ctx + 16 * (DA_U - 1); p0 += 16 * DA_U) {
-        f32x4 kv[DA_U], vv[DA_U];
-        bool ok[DA_U];
+    f32x4 kv[DA_U], vv[DA_U];
+    auto load_chunk = [&](int p0) {
 #pragma unroll
         for (int u = 0; u < DA_U; ++u) {
             const int p = p0 + 16 * u;
-            ok[u] = p < ctx;
-            const int pc = ok[u] ? (p < pos ? p : 0) : 0;  // clamped: loads are unconditional (never the new position)
+            const int pc = p < pos ? p : 0;  // clamped: loads are unconditional (never the new position, never past the end)
             kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
             vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
-            if (p == pos) {
-                kv[u] = *reinterpret_cast<const f32x4*>(&k_new[l16 * 4]);
-                vv[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
-            }
         }
+    };
+    int p0 = wid * 4 + sub;
+    load_chunk(p0);
+
+    if (wid == 0) {
+        const float* qp = qkv + (long)row * ld_qkv + head * 64;
+        const float qv = qp[lane], kn0 = qp[(long)n_heads * 64 + lane], vn0 = qp[(long)n_heads * 128 + lane];
+        const float c = cos_t ? cos_t[(long)pos * 64 + lane] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + lane] : 0.f;  // GPT-2: no RoPE
+        const float sgn = lane < 32 ? -1.f : 1.f;
+        const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
+        const float kn = kn0 * c + sgn * __shfl_xor(kn0, 32) * s;
+        q_s[lane] = qn * scale;
+        k_new[lane] = kn;
+        v_new[lane] = vn0;
+        kb[(long)pos * 64 + lane] = kn;
+        vb[(long)pos * 64 + lane] = vn0;
+    }
+    __syncthreads();
+    const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    while (true) {
         float d[DA_U];
         float mt = m;
 #pragma unroll
         for (int u = 0; u < DA_U; ++u) {
+            const int p = p0 + 16 * u;
+            if (p == pos) {  // the new token's k/v come from LDS, never from HBM
+                kv[u] = *reinterpret_cast<const f32x4*>(&k_new[l16 * 4]);
+                vv[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
+            }
             float t = kv[u][0] * qv4[0] + kv[u][1] * qv4[1] + kv[u][2] * qv4[2] + kv[u][3] * qv4[3];
             t += __shfl_xor(t, 8);
             t += __shfl_xor(t, 4);
             t += __shfl_xor(t, 2);
             t += __shfl_xor(t, 1);
-            d[u] = ok[u] ? t : -INFINITY;
+            d[u] = p < ctx ? t : -INFINITY;
             mt = fmaxf(mt, d[u]);
         }
         if (mt > -INFINITY) {
@@ -329,6 +335,9 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             }
             m = mt;
         }
+        p0 += 16 * DA_U;
+        if (p0 >= ctx) break;
+        load_chunk(p0);
     }
     const int g = wid * 4 + sub;
     *reinterpret_cast<f32x4*>(&st_acc[g][l16 * 4]) = acc;
@@ -425,8 +434,17 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
     CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
-    hipLaunchKernelGGL(decode_attn_rope_kernel, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
+    static const int da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : 4;  // 4, 8, 16 measured equal (1.42 ms/step): the step is bound by its 212 dependent launches
+    if (da_u == 8) {
+        hipLaunchKernelGGL(decode_attn_rope_kernel<8>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
                        kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
+    } else if (da_u == 16) {
+        hipLaunchKernelGGL(decode_attn_rope_kernel<16>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
+                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
+    } else {
+        hipLaunchKernelGGL(decode_attn_rope_kernel<4>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
+                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
+    }
     return cbx_check_launch("decode_attn_rope");
 }
 

@@ -1,5 +1,6 @@
 // LayerNorm / RMSNorm with fused activation: one 64-lane wavefront per row, row held in registers,
 // two-pass statistics by wave shuffles (no LDS, no atomics).  HBM-bound: one read + one write per element.
+#include <stdlib.h>
 #include "cbx_common.h"
 
 namespace {
@@ -69,6 +70,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Narrow rows (C = 64*NV floats, NV = 4: the 256-channel LayerNorms of the CFM estimator -- 1500 launches per utterance
+// batch): 16 lanes per row, 4 rows per wave, NV float4 per lane all in flight at once (a wave streams 4 KiB instead of 1 KiB
+// per round trip), statistics by 4 xor-shuffles inside the 16-lane group.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               const float* __restrict__ post_add, long rows, long ldx, long ldy,
+                                                               float eps, int rms, int act, float out_scale) {
+    constexpr int C = 64 * NV;
+    const int l16 = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < rows;
+    const float* xr = x + (live ? row : rows - 1) * ldx;  // unconditional loads on a clamped row
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 16 + l16) * 4);
+    auto group_sum = [](float t) {
+        t += __shfl_xor(t, 8);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 1);
+        return t;
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        s += rms ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
+                 : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+    s = group_sum(s);
+    float mean = 0.f, rstd;
+    if (rms) {
+        rstd = rsqrtf(s / C + eps);
+    } else {
+        mean = s / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        q = group_sum(q);
+        rstd = rsqrtf(q / C + eps);
+    }
+    float* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 16 + l16) * 4;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
+        if (b) bv = *reinterpret_cast<const f32x4*>(b + c);
+        if (post_add) pv = *reinterpret_cast<const f32x4*>(post_add + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+            t = cbx_act(t, act, 0.f, 0.f);
+            o[e] = t * out_scale + pv[e];
+        }
+        if (live) *reinterpret_cast<f32x4*>(yr + c) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const float* b, const float* post_add,
@@ -77,6 +142,12 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     CBX_REQUIRE(x && y && w, "layernorm: null operand");
     CBX_REQUIRE(C % 4 == 0 && C <= 4096 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: C=%d ldx=%ld ldy=%ld", C, ldx, ldy);
     if (rows <= 0) return 0;
+    static const int narrow = getenv("CBX_LN_NARROW") ? atoi(getenv("CBX_LN_NARROW")) : 1;
+    if (narrow && C == 256 && rows >= 64) {
+        hipLaunchKernelGGL(layernorm_narrow_kernel<4>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+                           b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
+        return cbx_check_launch("layernorm");
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b,
                        post_add, rows, C, ldx, ldy, eps, rms, act, out_scale);
     return cbx_check_launch("layernorm");

@@ -1,0 +1,24 @@
+"""Wall time of the S3Gen flow + HiFT pass at the bench shape (default precision), 5 passes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from chatterbox_amd import synth
+from chatterbox_amd.hift import HiFTEngine
+from chatterbox_amd.s3gen import FlowEngine
+dev = torch.device("cuda:0")
+sd = synth.s3gen_state_dict(0)
+flow, hift = FlowEngine(sd, dev), HiFTEngine(sd, dev)
+B, N = 8, 250
+toks = torch.stack([synth.speech_tokens(N, seed=b) for b in range(B)]).to(dev)
+lens = torch.full((B,), N, dtype=torch.int32, device=dev)
+ref = synth.s3gen_ref()
+z = synth.randn((B, 2 * (250 + N), 80), seed=9).to(dev)
+ts = []
+for it in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mel = flow.inference(toks, lens, ref, z=z)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    wav, _ = hift.inference(mel)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    ts.append((1e3 * (t1 - t0), 1e3 * (t2 - t1)))
+print(os.environ.get("TAG", ""), " ".join(f"{a:.1f}/{b:.1f}" for a, b in ts), flush=True)

@@ -16,6 +16,9 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
+ABI_VERSION = 2  # include/cbx.h CBX_ABI_VERSION
+
+
 class GemmParams(ctypes.Structure):
     _fields_ = [
         ("A", c_f), ("W", c_f), ("C", c_f), ("bias", c_f), ("R", c_f), ("C2", c_f),
@@ -93,7 +96,7 @@ def _load():
             raise ImportError(f"libcbx_hip.so does not export {name} (stale build?)") from e
         fn.argtypes = args
         fn.restype = res
-    if lib.cbx_abi_version() != 1:
+    if lib.cbx_abi_version() != ABI_VERSION:
         raise ImportError("libcbx_hip.so ABI version mismatch")
     return lib
 

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 1
+#define CBX_ABI_VERSION 2  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32 */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */

@@ -312,7 +312,7 @@ def main():
         summ = timer.summary()
         if not turbo:
             gemv = gemv_sweeps(eng.t3, 2 * B)
-            if args.alt_precisions:
+            if args.alt_precisions and world == 1:  # one_step() contains the C2 collective: single-rank runs only
                 for pr in (1, 6, 3):
                     if pr == s3_prec:
                         continue
@@ -351,7 +351,7 @@ def main():
         }
         if alt:
             out["audio_s_per_wall_s_at_other_precisions"] = alt
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)
         print(json.dumps(out), flush=True)

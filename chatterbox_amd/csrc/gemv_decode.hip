@@ -55,36 +55,49 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     constexpr int DEPTH = (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
+    // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
+    // start while blocks d+1.. are still in flight.
     for (int it0 = 0; it0 < nit; it0 += DEPTH) {
         f32x4 wv[DEPTH][2], uv[DEPTH][2], xv[DEPTH][MT][2];
+        bool on[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const bool on = (it0 + d) < nit;
-            const int off = (it0 + d) * 32;
-            wv[d][0] = (on && wok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off)) : zero4;
-            wv[d][1] = (on && wok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + 4)) : zero4;
+            on[d] = (it0 + d) < nit;
+            const int off = on[d] ? (it0 + d) * 32 : 0;
+            wv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off));
+            wv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + 4));
             if constexpr (SWIGLU) {
-                uv[d][0] = (on && wok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off)) : zero4;
-                uv[d][1] = (on && wok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + 4)) : zero4;
+                uv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off));
+                uv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + 4));
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                xv[d][t][0] = (on && xok[t]) ? *reinterpret_cast<const f32x4*>(xp[t] + off) : zero4;
-                xv[d][t][1] = (on && xok[t]) ? *reinterpret_cast<const f32x4*>(xp[t] + off + 4) : zero4;
+                xv[d][t][0] = *reinterpret_cast<const f32x4*>(xp[t] + off);
+                xv[d][t][1] = *reinterpret_cast<const f32x4*>(xp[t] + off + 4);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the issue order block by block, so block d's wait is vmcnt(later blocks)
         }
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
+        for (int d = 0; d < DEPTH; ++d) {
+            const bool won = on[d] && wok;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 wq = won ? wv[d][h] : zero4;
+                f32x4 uq = zero4;
+                if constexpr (SWIGLU) uq = won ? uv[d][h] : zero4;
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int t = 0; t < MT; ++t) {
+                    const f32x4 xq = (on[d] && xok[t]) ? xv[d][t][h] : zero4;
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[d][t][h][s], wv[d][h][s], acc[t], 0, 0, 0);
-                        if constexpr (SWIGLU)
-                            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[d][t][h][s], uv[d][h][s], acc2[t], 0, 0, 0);
+                    for (int s = 0; s < 4; ++s) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[s], wq[s], acc[t], 0, 0, 0);
+                        if constexpr (SWIGLU) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[s], uq[s], acc2[t], 0, 0, 0);
                     }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- fixed-order reduction over the NW K-slices of this workgroup.  D map: row = q*4 + r, col = c.

@@ -158,7 +158,10 @@ typedef struct cbx_sampler_t {
     int ban_token;             /* probability forced to 0 (EOS ban for fixed-length runs) or -1 */
     int eos_token;
     int ban_from;              /* ids >= ban_from (EOS included) get probability 0; 0 = off.  Synthetic random-weight
-                                  fixed-length runs use 6561 so that only valid S3 tokens are emitted */
+                                  fixed-length runs use 6561 so that only valid S3 tokens are emitted.  Bans act AFTER the
+                                  processors (like zeroing softmax entries); if no probability mass is left (the arg-max is
+                                  banned and min-p / top-k pruned the rest) the result is the allowed id with the largest
+                                  CFG-combined raw logit, lowest id on ties */
     unsigned char* seen;       /* [B][V] 0/1 map of generated ids (repetition penalty) */
     const float* uniforms;     /* [B][max_steps] U[0,1): the injected RNG of torch.multinomial */
     int max_steps;

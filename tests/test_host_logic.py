@@ -25,6 +25,43 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 2
 
 
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirrors of cbx_gemm_t / cbx_gemv_t / cbx_sampler_t must have the size and field offsets the C compiler gives
+    include/cbx.h (a mismatch would silently shift every later argument)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from chatterbox_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams, "cbx_sampler_t": _lib.SamplerParams}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cbx.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_gemm_precision_scope_nests_and_restores():
+    from chatterbox_amd import ops
+    assert ops.GEMM_PRECISION == 0
+    with ops.gemm_precision(3):
+        assert ops.GEMM_PRECISION == 3
+        with ops.gemm_precision(1):
+            assert ops.GEMM_PRECISION == 1
+        assert ops.GEMM_PRECISION == 3
+    assert ops.GEMM_PRECISION == 0
+
+
 def test_ops_fail_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
@@ -130,3 +167,30 @@ def test_shard_range():
             spans = [shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_bench_roofline_assembly_is_pure_and_consistent():
+    """bench.py's roofline objects from synthetic timer summaries (no GPU): fractions, per-launch figures, PMC lookup."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    summ = {"gemm_split": dict(launches=100, ms=5.0, flops=100 * 8e9, bytes=100 * 8e7),
+            "flash_attn_f32": dict(launches=10, ms=1.3, flops=10 * 3.1e10, bytes=10 * 1.2e8),
+            "gemm_f32": dict(launches=4, ms=0.8, flops=4 * 1.2e10, bytes=4 * 5e7)}
+    gemv = {"qkv": dict(ms=0.42, launches=60, per_step=30, bytes=60 * 12582912.0),
+            "gate_up": dict(ms=0.72, launches=60, per_step=30, bytes=60 * 33554432.0)}
+    r = bench.roofline_entries(summ, elapsed=2.0, steps=3, timed_steps=1, s3_prec=3, n_decode=249, gemv=gemv)
+    assert set(r) == {"gemm_split", "flash_attn_f32", "gemm_f32", "gemv_f32"}
+    g = r["gemm_split"]
+    assert g["bound"] == "mfma" and g["peak"] == bench.MFMA_BF16_PEAK_TFLOPS and abs(g["fp32_equivalent_tflops"] - 160.0) < 1e-6
+    assert abs(g["achieved"] - 480.0) < 1e-6 and abs(g["frac"] - 0.192) < 1e-9 and g["avg_launch_us"] == 50.0
+    assert r["gemm_f32"]["peak"] == bench.MFMA_F32_PEAK_TFLOPS
+    v = r["gemv_f32"]
+    assert v["bound"] == "hbm" and v["unit"] == "GB/s" and abs(v["achieved"] - (60 * 12582912.0 + 60 * 33554432.0) / 1.14e-3 / 1e9) < 0.1
+    assert abs(v["frac"] - v["achieved"] / 8000.0) < 1e-4 and set(v["by_projection"]) == {"qkv", "gate_up"}
+    # exact mode prices the same classes against the fp32 MFMA peak
+    r1 = bench.roofline_entries({"gemm_f32": summ["gemm_f32"], "flash_attn_f32": summ["flash_attn_f32"]}, 2.0, 3, 1, 1, 249, None)
+    assert r1["flash_attn_f32"]["peak"] == bench.MFMA_F32_PEAK_TFLOPS and "fp32_equivalent_tflops" not in r1["flash_attn_f32"]
+    tr, src = bench.pmc_traffic("gemm_split_kernel")
+    assert tr is None or (tr > 1e6 and "profiles/" in src)

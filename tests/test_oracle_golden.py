@@ -75,3 +75,34 @@ def test_sampler_semantics_match_hf_processors():
         assert torch.equal(torch.isinf(mine), torch.isinf(l[0]))
         keep = ~torch.isinf(mine)
         assert torch.allclose(mine[keep], l[0][keep], atol=1e-6)
+
+
+TURBO = dict(temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
+
+
+@pytest.mark.parametrize("name", ["turbo_l2", "nano_l12"])
+def test_turbo_oracle_matches_reference(name):
+    """GPT-2 backbone T3 (Turbo d = 1024 / Nano d = 768): the oracle against the reference's own `inference_turbo` run."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    L, d, steps, n_text = int(g["n_layers"]), int(g["d"]), int(g["steps"]), int(g["n_text"])
+    sd = synth.t3_turbo_state_dict(L, d, 0)
+    np.testing.assert_allclose(_fp(sd), g["fp"], rtol=1e-9)
+    with torch.inference_mode():
+        toks, logits = O.t3_inference_turbo(sd, L, 16 if d == 1024 else 12, synth.t3_cond(prompt_len=375), synth.turbo_text_tokens(n_text),
+                                            steps, torch.from_numpy(g["uniforms"]), ban_eos=True, return_logits=True, **TURBO)
+    idx = torch.from_numpy(g["logit_idx"]).long()
+    err = (logits[:, idx] - torch.from_numpy(g["logits_sub"])).abs().max().item()
+    assert err < 1e-4, err
+    assert toks.tolist() == g["tokens"].tolist()
+
+
+def test_meanflow_oracle_matches_reference():
+    """2-step meanflow CFM (no CFG) of Turbo / Nano against the reference's golden mel."""
+    g = np.load(os.path.join(GOLD, "meanflow_small.npz"))
+    P, N = int(g["P"]), int(g["N"])
+    sd = synth.s3gen_state_dict(0, meanflow=True)
+    np.testing.assert_allclose(_fp(sd), g["fp"], rtol=1e-9)
+    z = synth.randn((1, 80, 2 * (P + N)), seed=5)
+    with torch.inference_mode():
+        mel = O.flow_inference(sd, synth.speech_tokens(N, seed=1)[None], torch.tensor([N]), synth.s3gen_ref(n_prompt_tokens=P), z, 2, meanflow=True)
+    assert (mel[0] - torch.from_numpy(g["mel"])).abs().mean() < 1e-5

@@ -5,6 +5,7 @@ speech tokens are stripped of SOS/EOS (`drop_invalid_tokens`, s3tokenizer/__init
 on the padded batch, and each waveform is cut to its own length (the multilingual path also drops the last
 token's 40 ms, mtl_tts.py:348-352).
 """
+import os
 import time
 
 import torch
@@ -35,6 +36,7 @@ class ChatterboxEngine:
         self.flow = FlowEngine(s3gen_sd, self.dev, meanflow=meanflow)
         self.hift = HiFTEngine(s3gen_sd, self.dev)
         self.last_timing = {}
+        self.t3_streams = int(os.environ.get("CBX_T3_STREAMS", "1"))  # > 1: T3Engine.generate_streams (experimental)
 
     @torch.inference_mode()
     def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True):
@@ -71,9 +73,10 @@ class ChatterboxEngine:
                    noise=None, n_cfm_timesteps=10, drop_last_token=True):
         """Full hot path for B utterances.  Returns (wavs: list of 1-D device tensors, speech_tokens: list)."""
         t0 = time.perf_counter()
-        toks = self.t3.generate(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
-                                min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms,
-                                ban_eos=ban_eos, ban_from=ban_from)
+        gen = self.t3.generate if self.t3_streams <= 1 else (lambda *a, **k: self.t3.generate_streams(*a, n_streams=self.t3_streams, **k))
+        toks = gen(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
+                   min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms,
+                   ban_eos=ban_eos, ban_from=ban_from)
         torch.cuda.synchronize()
         self.last_timing = dict(t3_s=time.perf_counter() - t0)
         st = [drop_invalid_tokens(t) for t in toks]

@@ -160,11 +160,12 @@ class T3Engine:
                       positions=st["positions"], ctx_lens=st["ctx_lens"])
 
     # ------------------------------------------------------------------ state / workspaces
-    def _get_state(self, B, max_ctx, max_steps):
-        key = (B, max_ctx, max_steps)
+    def _get_state(self, B, max_ctx, max_steps, slot=0):
+        key = (B, max_ctx, max_steps, slot)
         if key in self._state:
             return self._state[key]
-        self._state.clear()  # one live configuration at a time (the KV cache dominates memory)
+        for k in [k for k in self._state if k[3] == slot]:  # one live configuration per slot (the KV cache dominates memory)
+            del self._state[k]
         dev, rows = self.dev, 2 * B
         f = lambda *s: torch.empty(*s, device=dev)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
@@ -181,6 +182,36 @@ class T3Engine:
         self._state[key] = st
         return st
 
+    @torch.inference_mode()
+    def generate_streams(self, conds, text_tokens, n_streams=2, uniforms=None, **kw):
+        """EXPERIMENTAL (opt-in, CBX_T3_STREAMS): the batch is cut into `n_streams` contiguous sub-batches that decode
+        concurrently on separate HIP streams, each with its own KV cache and decode graph.  A decode step is a chain of 212
+        dependent, latency-bound launches that leaves most of the chip idle (2.2 of 8 TB/s); two independent chains overlap their
+        round trips at the price of streaming the weights once per chain.  Rows never interact inside T3, so the tokens are the
+        same as generate()'s.  Runs every chain for the full max_new_tokens (no EOS polling)."""
+        B = len(text_tokens)
+        n = max(1, min(int(n_streams), B))
+        if n == 1:
+            return self.generate(conds, text_tokens, uniforms=uniforms, **kw)
+        if len(getattr(self, "_streams", ())) < n:
+            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
+        cur = torch.cuda.current_stream(self.dev)
+        u = None if uniforms is None else torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)
+        handles = []
+        for i in range(n):
+            lo, hi = (B * i) // n, (B * (i + 1)) // n
+            s = self._streams[i]
+            s.wait_stream(cur)  # inputs produced on the caller's stream
+            with torch.cuda.stream(s):
+                handles.append(self.generate(conds if isinstance(conds, dict) else conds[lo:hi], text_tokens[lo:hi],
+                                             uniforms=None if u is None else u[lo:hi], async_mode=True, slot=i, **kw))
+        out = []
+        for i, h in enumerate(handles):
+            with torch.cuda.stream(self._streams[i]):
+                out += self.collect(h)
+            cur.wait_stream(self._streams[i])
+        return out
+
     def collect(self, handle):
         """Fetch the tokens of an (async) generate() call.  Must run on the stream the call was enqueued on."""
         st, B = handle["st"], handle["B"]
@@ -192,9 +223,10 @@ class T3Engine:
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
                  repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16,
-                 return_prefill_logits=False, debug_logits=False, async_mode=False):
+                 return_prefill_logits=False, debug_logits=False, async_mode=False, slot=0):
         """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
-        carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled)."""
+        carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled).
+        `slot` selects an independent set of workspaces / KV cache / decode graph (see generate_streams)."""
         dev, B = self.dev, len(text_tokens)
         rows = 2 * B
         if isinstance(conds, dict):
@@ -206,7 +238,7 @@ class T3Engine:
         S = max(s0)
         max_ctx = (S + max_new_tokens + 63) // 64 * 64
         assert max_ctx <= self.max_pos, "context exceeds the RoPE table"
-        st = self._get_state(B, max_ctx, max_new_tokens)
+        st = self._get_state(B, max_ctx, max_new_tokens, slot)
         samp = dict(temperature=float(temperature), top_p=float(top_p), min_p=float(min_p),
                     repetition_penalty=float(repetition_penalty), cfg_weight=float(cfg_weight), ban_eos=bool(ban_eos), ban_from=int(ban_from))
         if st["samp"] != samp:

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 2  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 3  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -43,6 +43,12 @@ class GemvParams(ctypes.Structure):
                 ("part_stride", c_long)]
 
 
+class GemvNormParams(ctypes.Structure):
+    _fields_ = [("res", c_f), ("part", c_f), ("norm_w", c_f), ("W", c_f), ("out", c_f), ("res_out", c_f),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("ks_in", c_int), ("swiglu", c_int), ("eps", c_float),
+                ("ldr", c_long), ("ldp", c_long), ("part_stride", c_long), ("ldw", c_long), ("ldo", c_long), ("ldro", c_long)]
+
+
 class SamplerParams(ctypes.Structure):
     _fields_ = [
         ("logits", c_f), ("ld", c_long), ("V", c_int), ("B", c_int), ("cfg", c_int),
@@ -59,6 +65,7 @@ _SIGS = {
     "cbx_last_error": ([], ctypes.c_char_p),
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
+    "cbx_gemv_norm_f32": ([ctypes.POINTER(GemvNormParams), c_f], c_int),
     "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),

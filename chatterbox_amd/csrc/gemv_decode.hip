@@ -134,7 +134,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 template <int MT, bool SWIGLU>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     dim3 grid((p.N + 15) / 16, p.ksplit);
-    if (p.nw == 8) {
+    if constexpr (MT == 1 && !SWIGLU) {
+        if (p.nw == 16) {  // 16 K-slices per workgroup: the ksplit <= 2 form of the K = 4096 down-projection (experimental fused-norm path)
+            hipLaunchKernelGGL((gemv_kernel<1, 16, false>), grid, dim3(1024), 0, st, p);
+            return cbx_check_launch("gemv");
+        }
+    }
+    if (p.nw >= 8) {
         hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU>), grid, dim3(512), 0, st, p);
     } else {
         hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU>), grid, dim3(256), 0, st, p);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float*
 extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     cbx_gemv_t p = *pp;
     if (p.ksplit < 1) p.ksplit = 1;
-    if (p.nw != 8) p.nw = 4;
+    if (p.nw != 8 && p.nw != 16) p.nw = 4;
     CBX_REQUIRE(p.x && p.W && p.out, "gemv: null operand");
     CBX_REQUIRE(p.M >= 1 && p.M <= 64 && p.N > 0 && p.K > 0, "gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);

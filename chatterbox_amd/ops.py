@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from ._lib import GemmParams, GemvParams, SamplerParams, check, lib
+from ._lib import GemvNormParams, GemmParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -161,6 +161,23 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
         p.ldo, p.part_stride = out.stride(0), 0
     _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
            lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
+    return out
+
+
+def gemv_norm(res, part, norm_w, w, out, *, res_out=None, swiglu=False, eps=1e-5, N=None):
+    """EXPERIMENTAL fused decode GEMV (cbx_gemv_norm_f32): out = RMSNorm(res + sum_j part[j]) @ w^T, h -> res_out.
+    res (M<=32, K), part (ks<=2, M, K) or None, w (N, K) [swiglu: packed (2N, K)], out (M, N)."""
+    M, K = res.shape
+    N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
+    p = GemvNormParams()
+    p.res, p.part, p.norm_w, p.W, p.out, p.res_out = _p(_f32(res, "res")), _p(part), _p(_f32(norm_w, "norm_w")), _p(_f32(w, "w")), \
+        _p(_f32(out, "out")), _p(res_out)
+    p.M, p.N, p.K, p.ks_in, p.swiglu, p.eps = M, N, K, 0 if part is None else part.shape[0], int(swiglu), eps
+    p.ldr, p.ldw, p.ldo = res.stride(0), w.stride(0), out.stride(0)
+    p.ldp, p.part_stride = (0, 0) if part is None else (part.stride(1), part.stride(0))
+    p.ldro = 0 if res_out is None else res_out.stride(0)
+    _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
+           lambda: check(lib.cbx_gemv_norm_f32(ctypes.byref(p), _stream()), "cbx_gemv_norm_f32"))
     return out
 
 

@@ -12,6 +12,8 @@ the decode steps then overwrite it in the KV cache at each row's own position.
 """
 import math
 
+import os
+
 import torch
 
 from . import ops, weights
@@ -74,6 +76,8 @@ class T3Engine:
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
         self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4)
+        # EXPERIMENTAL (CBX_T3_FUSED=1, not yet run on hardware): add + RMSNorm folded into the consumer GEMVs (5 launches per layer)
+        self.fused_norm = os.environ.get("CBX_T3_FUSED", "0") == "1"
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -145,8 +149,36 @@ class T3Engine:
         ops.add_rmsnorm(x, part, self.norm, h)
         ops.gemv(h, self.head, st["logits"], nw=tn["head_nw"])
 
+    def _forward_decode_fused(self, st):
+        """Same arithmetic as _forward_decode with `x += partials; h = RMSNorm(x)` moved into the prologue of the GEMV that consumes
+        h (ops.gemv_norm): the residual stream ping-pongs between x and x2, the o / down projections keep a 2-way split-K."""
+        ws = st["dws"]
+        if "x2" not in ws:
+            ws["x2"] = torch.empty_like(ws["x"])
+        cur, nxt = ws["x"], ws["x2"]
+        qkv, att, g, po, pd = ws["qkv"], ws["att"], ws["g"], ws["po"][:2], ws["pd"][:2]
+        ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.speech_pos, ids2=st["next_pos_ids"])
+        part = None
+        for i, lw in enumerate(self.layers):
+            ops.gemv_norm(cur, part, lw["ln1"], lw["wqkv"], qkv, res_out=None if part is None else nxt)
+            if part is not None:
+                cur, nxt = nxt, cur
+            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125)
+            ops.gemv(att, lw["wo"], po, ksplit=2, nw=8)
+            ops.gemv_norm(cur, po, lw["ln2"], lw["wgu"], g, res_out=nxt, swiglu=True)
+            cur, nxt = nxt, cur
+            ops.gemv(g, lw["wd"], pd, ksplit=2, nw=16)
+            part = pd
+        ops.gemv_norm(cur, part, self.norm, self.head, st["logits"])
+
+    def _forward(self, st):
+        if self.fused_norm and st["rows"] <= 32:
+            self._forward_decode_fused(st)
+        else:
+            self._forward_decode(st)
+
     def _decode_step(self, st):
-        self._forward_decode(st)
+        self._forward(st)
         self._sample(st)
 
     def _sample(self, st):
@@ -298,7 +330,7 @@ class T3Engine:
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
             elif debug_logits:  # forward and sampler split so that the raw logits of every step can be inspected
-                self._forward_decode(st)
+                self._forward(st)
                 step_logits.append(st["logits"].clone())
                 self._sample(st)
             else:

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 2  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32 */
+#define CBX_ABI_VERSION 3  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 3: cbx_gemv_norm_f32 (experimental) */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -79,6 +79,22 @@ typedef struct cbx_gemv_t {
     long ldx, ldw, ldo, part_stride;
 } cbx_gemv_t;
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
+/* EXPERIMENTAL (ABI v3, opt-in, not yet run on hardware): decode GEMV with the residual add + split-K reduce + LlamaRMSNorm of
+ * its INPUT folded into its prologue -- removes the two cbx_add_rmsnorm_f32 launches of a Llama layer (t3.py:378-386 hot loop).
+ *   h = res + sum_{j < ks_in} part[j]  (fixed order);   out[m][n] = rstd[m] * sum_k (h[m][k] * norm_w[k]) * W[n][k]
+ * res_out (optional, must not alias res) receives h; swiglu as in cbx_gemv_t.  M <= 32, K in {256,512,768,1024}, ks_in <= 2. */
+typedef struct cbx_gemv_norm_t {
+    const float* res;         /* [M][ldr] residual stream */
+    const float* part;        /* [ks_in][M][ldp] split-K partials of the producing projection, or NULL */
+    const float* norm_w;      /* [K] */
+    const float* W;           /* [N][ldw]  (swiglu: packed [32 gate | 32 up] image, N = #features) */
+    float* out;               /* [M][ldo] */
+    float* res_out;           /* [M][ldro] or NULL */
+    int M, N, K, ks_in, swiglu;
+    float eps;
+    long ldr, ldp, part_stride, ldw, ldo, ldro;
+} cbx_gemv_norm_t;
+int cbx_gemv_norm_f32(const cbx_gemv_norm_t* p, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
                         int rows, int C, long ldx, long ldh, float eps, void* stream);

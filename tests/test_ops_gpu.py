@@ -457,3 +457,34 @@ def test_decode_attn_rope_fused(dev):
         _close(kc[r, :, n], kr[r], 1e-6, "k appended")
         _close(vc[r, :, n], v[r], 0.0, "v appended")
         _close(kc[r, :, :n], kc0[r, :, :n], 0.0, "cache untouched")
+
+
+import os as _os
+
+_EXPERIMENTAL = _os.environ.get("CBX_TEST_EXPERIMENTAL") == "1"
+
+
+@pytest.mark.skipif(not _EXPERIMENTAL, reason="opt-in kernel written after the round's GPU budget was spent: CBX_TEST_EXPERIMENTAL=1 runs it")
+@pytest.mark.parametrize("M,N,K,ks,swiglu", [(16, 3072, 1024, 0, False), (16, 3072, 1024, 2, False), (16, 4096, 1024, 2, True),
+                                             (16, 8194, 1024, 2, False), (6, 96, 768, 1, False), (32, 1024, 1024, 2, True), (30, 64, 256, 1, False)])
+def test_gemv_norm_fused(dev, M, N, K, ks, swiglu):
+    """cbx_gemv_norm_f32: RMSNorm(res + sum part) @ W^T (+ SwiGLU), residual written back -- against torch fp32."""
+    from chatterbox_amd import ops, weights
+    from oracle import ref_torch as O
+    res, nw = _r((M, K), 1), 1 + 0.1 * _r((K,), 2)
+    part = _r((ks, M, K), 3, 0.3) if ks else None
+    h = res + (part.sum(0) if ks == 1 else (part[0] + part[1]) if ks == 2 else 0)
+    hn = O.rms_norm(h, nw)
+    out = torch.empty(M, N, device=dev)
+    res_out = torch.full((M, K), 7.0, device=dev)
+    if swiglu:
+        g, u = _r((N, K), 4, 1 / math.sqrt(K)), _r((N, K), 5, 1 / math.sqrt(K))
+        ops.gemv_norm(res.to(dev), None if part is None else part.to(dev), nw.to(dev), weights.pack_swiglu(g, u).to(dev), out,
+                      res_out=res_out, swiglu=True)
+        ref = F.silu(F.linear(hn, g)) * F.linear(hn, u)
+    else:
+        w = _r((N, K), 4, 1 / math.sqrt(K))
+        ops.gemv_norm(res.to(dev), None if part is None else part.to(dev), nw.to(dev), w.to(dev), out, res_out=res_out)
+        ref = F.linear(hn, w)
+    _close(out, ref, 3e-5 * max(1.0, math.sqrt(K / 256)), "gemv_norm")
+    _close(res_out, h, 1e-6, "residual write-back")

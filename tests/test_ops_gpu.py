@@ -488,3 +488,15 @@ def test_gemv_norm_fused(dev, M, N, K, ks, swiglu):
         ref = F.linear(hn, w)
     _close(out, ref, 3e-5 * max(1.0, math.sqrt(K / 256)), "gemv_norm")
     _close(res_out, h, 1e-6, "residual write-back")
+
+
+@pytest.mark.skipif(not (_EXPERIMENTAL and _os.environ.get("CBX_SPLIT_AK") == "1"),
+                    reason="A-stationary K=256 split GEMM (gemm_split_ak.hip) is opt-in: CBX_TEST_EXPERIMENTAL=1 CBX_SPLIT_AK=1 runs it")
+def test_split_gemm_ak_shapes(dev):
+    from chatterbox_amd import ops
+    with ops.gemm_precision(3):
+        for (M, N, K) in [(4000, 1536, 256), (2048, 1024, 256), (1027, 520, 256)]:
+            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+            out = torch.empty(M, N, device=dev)
+            ops.linear(x.to(dev), w.to(dev), out, bias=b.to(dev), act=ops.GELU_ERF, residual=r.to(dev))
+            _close(out, F.gelu(F.linear(x, w, b)) + r, _SPLIT_TOL[3], f"split-ak linear {M}x{N}x{K}")

@@ -49,8 +49,6 @@ def parse():
     ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6],
                     help="numerics of the S3Gen GEMMs / attention: 1 exact fp32 MFMA, 6 bf16x6 (fp32-level error), 3 bf16x3 (default, "
                          "rel. error ~4e-6 per contraction; golden mel-L1 1.4e-5 against the 1e-4 tolerance).  T3 is always exact")
-    ap.add_argument("--t3-streams", type=int, default=None,
-                    help="EXPERIMENTAL: decode the batch as N concurrent sub-batches on separate HIP streams (T3Engine.generate_streams)")
     ap.add_argument("--alt-precisions", action="store_true",
                     help="after the timed region also measure one step at each of the other S3Gen precisions (reported under "
                          "audio_s_per_wall_s_at_other_precisions)")
@@ -238,8 +236,6 @@ def main():
     if args.s3gen_precision is not None:
         eng.flow.precision = eng.hift.precision = args.s3gen_precision
     s3_prec = eng.flow.precision
-    if args.t3_streams is not None and not turbo:
-        eng.t3_streams = args.t3_streams
     build_s = time.perf_counter() - t_build
     log(f"model built in {build_s:.1f}s")
 
@@ -349,8 +345,7 @@ def main():
                                     f"batch {B}/GPU, {N} speech tokens (NOT the headline metric's config)"),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1),
-                       "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial") +
-                                   (f", T3 decode as {eng.t3_streams} concurrent sub-batches" if getattr(eng, "t3_streams", 1) > 1 else "")},
+                       "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial")},
             "roofline": roof,
             "roofline_secondary": list(roofs.values()),
         }

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 3  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 4  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -40,13 +40,8 @@ class GemmParams(ctypes.Structure):
 class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
-                ("part_stride", c_long)]
-
-
-class GemvNormParams(ctypes.Structure):
-    _fields_ = [("res", c_f), ("part", c_f), ("norm_w", c_f), ("W", c_f), ("out", c_f), ("res_out", c_f),
-                ("M", c_int), ("N", c_int), ("K", c_int), ("ks_in", c_int), ("swiglu", c_int), ("eps", c_float),
-                ("ldr", c_long), ("ldp", c_long), ("part_stride", c_long), ("ldw", c_long), ("ldo", c_long), ("ldro", c_long)]
+                ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("out_packed", c_int), ("reserved0", c_int),
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("reserved1", c_int)]
 
 
 class SamplerParams(ctypes.Structure):
@@ -65,14 +60,15 @@ _SIGS = {
     "cbx_last_error": ([], ctypes.c_char_p),
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
-    "cbx_gemv_norm_f32": ([ctypes.POINTER(GemvNormParams), c_f], c_int),
+    "cbx_pack_gemv_weight_f32": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
     "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),
     "cbx_flash_attn_split_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
-    "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
+    "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_float, c_f], c_int),
+    "cbx_set_decode_attn_unroll": ([c_int], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
     "cbx_axpby_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_float, c_f], c_int),

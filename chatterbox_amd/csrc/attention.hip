@@ -261,8 +261,8 @@ template <int DA_U>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
-                                                               int n_heads, long ld_qkv, long o_ld, long row_stride, long head_stride,
-                                                               float scale) {
+                                                               int n_heads, long ld_qkv, long o_ld, int o_packed, long row_stride,
+                                                               long head_stride, float scale) {
     __shared__ __attribute__((aligned(16))) float q_s[64], k_new[64], v_new[64];
     __shared__ __attribute__((aligned(16))) float st_acc[16][64];
     __shared__ float st_m[16], st_l[16];
@@ -357,7 +357,12 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             num += f * st_acc[i][tid];
             den += f * st_l[i];
         }
-        o[(long)row * o_ld + head * 64 + tid] = num / den;
+        long oi = (long)row * o_ld + head * 64 + tid;
+        if (o_packed) {  // operand layout of the o-projection GEMV (include/cbx.h "packed GEMV weight layout", K = n_heads * 64)
+            const int n = head * 64 + tid;
+            oi = (((long)(row >> 4) * (n_heads * 2) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + (row & 15)) * 4 + (n & 3);
+        }
+        o[oi] = num / den;
     }
 }
 
@@ -429,22 +434,30 @@ extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float*
     return cbx_check_launch("decode_attn");
 }
 
+static int g_da_u = 0;  // 0: from the environment (CBX_DA_U) on first use, default 4
+extern "C" int cbx_set_decode_attn_unroll(int u) {
+    CBX_REQUIRE(u == 4 || u == 8 || u == 16, "decode_attn unroll must be 4, 8 or 16");
+    g_da_u = u;
+    return 0;
+}
+
 extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
-                                        float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld,
+                                        float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
     CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
-    static const int da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : 4;  // 4, 8, 16 measured equal (1.42 ms/step): the step is bound by its 212 dependent launches
-    if (da_u == 8) {
-        hipLaunchKernelGGL(decode_attn_rope_kernel<8>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
-                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
-    } else if (da_u == 16) {
-        hipLaunchKernelGGL(decode_attn_rope_kernel<16>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
-                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
-    } else {
-        hipLaunchKernelGGL(decode_attn_rope_kernel<4>, dim3(n_heads, rows), dim3(256), 0, (hipStream_t)stream, qkv, positions, cos_t, sin_t,
-                       kc, vc, o, n_heads, ld_qkv, o_ld, cache_row_stride, cache_head_stride, scale);
-    }
+    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : 4;  // key rows in flight per 16-lane group
+    const dim3 grid(n_heads, rows), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_da_u == 8)
+        hipLaunchKernelGGL(decode_attn_rope_kernel<8>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
+                           o_packed, cache_row_stride, cache_head_stride, scale);
+    else if (g_da_u == 16)
+        hipLaunchKernelGGL(decode_attn_rope_kernel<16>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
+                           o_packed, cache_row_stride, cache_head_stride, scale);
+    else
+        hipLaunchKernelGGL(decode_attn_rope_kernel<4>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
+                           o_packed, cache_row_stride, cache_head_stride, scale);
     return cbx_check_launch("decode_attn_rope");
 }
 

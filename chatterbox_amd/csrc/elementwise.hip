@@ -61,7 +61,7 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* y, long rows, i
 
 __global__ void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
                              const float* __restrict__ table2, const int* __restrict__ ids2, float* __restrict__ out,
-                             long rows, int C, long ld_out, float scale, int zero_if_neg) {
+                             long rows, int C, long ld_out, float scale, int flags) {
     const int c4n = C >> 2;
     const long total = rows * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -71,7 +71,10 @@ __global__ void embed_kernel(const long long* __restrict__ ids, const float* __r
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (id >= 0) v = *reinterpret_cast<const f32x4*>(table + id * C + c) * scale;
         if (table2 && ids2 && ids2[r] >= 0) v += *reinterpret_cast<const f32x4*>(table2 + (long)ids2[r] * C + c);
-        *reinterpret_cast<f32x4*>(out + r * ld_out + c) = v;
+        long o = r * ld_out + c;
+        if (flags & 2)  // packed GEMV operand layout (cbx.h): one float4 of the row = one float4 of the image
+            o = ((((r >> 4) * (C >> 5) + (c >> 5)) * 2 + ((c >> 2) & 1)) * 64 + (((c >> 3) & 3) << 4) + (r & 15)) * 4;
+        *reinterpret_cast<f32x4*>(out + o) = v;
     }
 }
 
@@ -140,11 +143,11 @@ extern "C" int cbx_axpby_f32(const float* x, float* y, long rows, int C, long ld
 }
 
 extern "C" int cbx_embed_f32(const long long* ids, const float* table, const float* table2, const int* ids2, float* out,
-                             long rows, int C, long ld_out, float scale, int zero_if_neg, void* stream) {
-    CBX_REQUIRE(ids && table && out && C % 4 == 0 && ld_out % 4 == 0, "embed: bad args");
+                             long rows, int C, long ld_out, float scale, int flags, void* stream) {
+    CBX_REQUIRE(ids && table && out && C % 4 == 0 && ld_out % 4 == 0 && (!(flags & 2) || C % 32 == 0), "embed: bad args");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(embed_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, ids, table, table2,
-                       ids2, out, rows, C, ld_out, scale, zero_if_neg);
+                       ids2, out, rows, C, ld_out, scale, flags);
     return cbx_check_launch("embed");
 }
 

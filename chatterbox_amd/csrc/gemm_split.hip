@@ -261,17 +261,11 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
 
 }  // namespace
 
-int cbx_gemm_split_ak_dispatch(const cbx_gemm_t& p, hipStream_t st);  // gemm_split_ak.hip (experimental, CBX_SPLIT_AK=1)
-
 // Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3) or 3 (bf16x6).  Returns -1 when the shape is not
 // served by this kernel (caller falls back to the exact fp32 MFMA kernel).
 int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     if (p.w_kn || p.swiglu) return -1;
     if (p.taps > 1 && p.Cin % SBK != 0) return -1;  // a K tile must not straddle two conv taps
-    if (planes == 2) {
-        const int rc = cbx_gemm_split_ak_dispatch(p, st);
-        if (rc != -1) return rc;
-    }
     static const int force = getenv("CBX_SPLIT_TILE") ? atoi(getenv("CBX_SPLIT_TILE")) : 0;
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
     // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by

@@ -14,9 +14,16 @@
 
 namespace {
 
-template <int MT, int NW, bool SWIGLU>
+// PK: W is the lane-ordered packed image (cbx.h "packed GEMV weight layout"): the 2 KiB of a (16-row tile, 32-deep K block) are stored
+// as [h][lane][4 floats], so every wave-level load instruction reads 1 KiB of CONTIGUOUS memory (8 full 128-B lines) instead of
+// 16-B pieces of 16 different rows.  XPK: the same layout for the x operand (written that way by the producing kernel).
+// RMS: LlamaRMSNorm of the x operand folded in: the lanes multiply their x values by norm_w[k] on the way to the MFMA, accumulate
+// sum_k x^2 per row as a by-product (every workgroup reads whole rows), and the per-row rstd -- a scalar that factors out of the
+// contraction -- is applied in the epilogue:  out[m][n] = rstd[m] * sum_k (x[m][k] * norm_w[k]) * W[n][k].  (ksplit must be 1.)
+template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
+    __shared__ float ssq[RMS ? NW * MT * 16 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, ks = blockIdx.y;
@@ -27,54 +34,78 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     // row of W streamed by this lane (swiglu: gate row, the matching up row is 32 rows further in the packed image)
     long wrow;
     bool wok;
-    if constexpr (SWIGLU) {
-        const int f = n0 + c;  // feature index
-        wok = f < p.N;
-        wrow = (long)(f >> 5) * 64 + (f & 31);
+    const float *wp, *wp2;
+    constexpr int WBLK = PK ? 512 : 32;  // floats between consecutive 32-deep K blocks of this lane's stream
+    constexpr int WHALF = PK ? 256 : 4;  // floats between the two 16-B halves of a block
+    if constexpr (PK) {
+        // packed image: tile-major [tile][K/32][2][64 lanes][4]; swiglu: feature tile f -> tiles 2f (gate), 2f+1 (up); N is padded
+        // to whole tiles by the packer, so every load is in range
+        const long kb = p.K >> 5;
+        const long tile = SWIGLU ? 2L * blockIdx.x : (long)blockIdx.x;
+        wok = true;
+        wp = p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
+        wp2 = wp + kb * 512;
     } else {
-        wok = (n0 + c) < p.N;
-        wrow = n0 + c;
+        if constexpr (SWIGLU) {
+            const int f = n0 + c;  // feature index
+            wok = f < p.N;
+            wrow = (long)(f >> 5) * 64 + (f & 31);
+        } else {
+            wok = (n0 + c) < p.N;
+            wrow = n0 + c;
+        }
+        wp = p.W + (wok ? wrow : 0) * p.ldw + kbeg + 8 * q;
+        wp2 = wp + 32 * p.ldw;
     }
-    const float* wp = p.W + (wok ? wrow : 0) * p.ldw + kbeg + 8 * q;
-    const float* wp2 = wp + 32 * p.ldw;
     const float* xp[MT];
     bool xok[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         int m = t * 16 + c;
         xok[t] = m < p.M;
-        xp[t] = p.x + (long)(xok[t] ? m : 0) * p.ldx + kbeg + 8 * q;
+        if constexpr (XPK)  // packed x: [row tile][K/32][2][64][4], rows padded to whole tiles (pad rows hold finite values)
+            xp[t] = p.x + ((long)t * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 4;
+        else
+            xp[t] = p.x + (long)(xok[t] ? m : 0) * p.ldx + kbeg + 8 * q;
     }
 
+    const float* nwp = RMS ? p.norm_w + kbeg + 8 * q : nullptr;  // this lane's k indices: kbeg + 32*blk + 8*q + 4*h + s
+    float ss[MT];
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ss[t] = 0.f;
     }
     constexpr int DEPTH = (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
     // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
     // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
     // start while blocks d+1.. are still in flight.
     for (int it0 = 0; it0 < nit; it0 += DEPTH) {
-        f32x4 wv[DEPTH][2], uv[DEPTH][2], xv[DEPTH][MT][2];
+        f32x4 wv[DEPTH][2], uv[DEPTH][2], xv[DEPTH][MT][2], nv[DEPTH][2];
         bool on[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             on[d] = (it0 + d) < nit;
-            const int off = on[d] ? (it0 + d) * 32 : 0;
+            const int blk = on[d] ? (it0 + d) : 0;
+            const int off = blk * WBLK;
             wv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off));
-            wv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + 4));
+            wv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + WHALF));
             if constexpr (SWIGLU) {
                 uv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off));
-                uv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + 4));
+                uv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + WHALF));
             }
+            const int xoff = blk * (XPK ? 512 : 32);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                xv[d][t][0] = *reinterpret_cast<const f32x4*>(xp[t] + off);
-                xv[d][t][1] = *reinterpret_cast<const f32x4*>(xp[t] + off + 4);
+                xv[d][t][0] = *reinterpret_cast<const f32x4*>(xp[t] + xoff);
+                xv[d][t][1] = *reinterpret_cast<const f32x4*>(xp[t] + xoff + (XPK ? 256 : 4));
+            }
+            if constexpr (RMS) {
+                nv[d][0] = *reinterpret_cast<const f32x4*>(nwp + blk * 32);
+                nv[d][1] = *reinterpret_cast<const f32x4*>(nwp + blk * 32 + 4);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the issue order block by block, so block d's wait is vmcnt(later blocks)
         }
@@ -88,7 +119,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                 if constexpr (SWIGLU) uq = won ? uv[d][h] : zero4;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const f32x4 xq = (on[d] && xok[t]) ? xv[d][t][h] : zero4;
+                    f32x4 xq = (on[d] && xok[t]) ? xv[d][t][h] : zero4;
+                    if constexpr (RMS) {
+                        ss[t] += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
+                        xq *= nv[d][h];
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[s], wq[s], acc[t], 0, 0, 0);
@@ -110,6 +145,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             r1[(w * MT + t) * 256 + (q * 4 + r) * 16 + c] = acc[t][r];
             if constexpr (SWIGLU) r2[(w * MT + t) * 256 + (q * 4 + r) * 16 + c] = acc2[t][r];
         }
+    if constexpr (RMS) {  // lanes (c, q = 0..3) hold the four q-parts of row c's sum over this wave's K slice
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float v = ss[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) ssq[(w * MT + t) * 16 + c] = v;
+        }
+    }
     __syncthreads();
     for (int e = tid; e < MT * 256; e += NW * 64) {
         const int t = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
@@ -121,40 +165,62 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             v += r1[(ww * MT + t) * 256 + rc];
             if constexpr (SWIGLU) v2 += r2[(ww * MT + t) * 256 + rc];
         }
+        if constexpr (RMS) {
+            float sq = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sq += ssq[(ww * MT + t) * 16 + row];
+            const float rstd = rsqrtf(sq / (float)p.K + p.eps);
+            v *= rstd;
+            v2 *= rstd;
+        }
         if constexpr (SWIGLU) {
             v = (v / (1.0f + __expf(-v))) * v2;
         } else {
             if (p.bias && ks == 0) v += p.bias[n];
             if (p.act) v = cbx_act(v, p.act, 0.f, 0.f);  // only meaningful with ksplit == 1
         }
-        p.out[(long)ks * p.part_stride + (long)m * p.ldo + n] = v;
+        long o;
+        if (p.out_packed)  // the consumer's lane-ordered operand layout (its K = this N): see cbx.h
+            o = (((long)t * (p.N >> 5) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + row) * 4 + (n & 3);
+        else
+            o = (long)ks * p.part_stride + (long)m * p.ldo + n;
+        if (p.res) v += p.res[o];  // residual stream in the same layout as out (in place is fine: one thread per element)
+        p.out[o] = v;
     }
 }
 
-template <int MT, bool SWIGLU>
+template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     dim3 grid((p.N + 15) / 16, p.ksplit);
-    if constexpr (MT == 1 && !SWIGLU) {
-        if (p.nw == 16) {  // 16 K-slices per workgroup: the ksplit <= 2 form of the K = 4096 down-projection (experimental fused-norm path)
-            hipLaunchKernelGGL((gemv_kernel<1, 16, false>), grid, dim3(1024), 0, st, p);
+    if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
+        if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
+            hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false>), grid, dim3(1024), 0, st, p);
             return cbx_check_launch("gemv");
         }
     }
     if (p.nw >= 8) {
-        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU>), grid, dim3(512), 0, st, p);
+        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU, PK, XPK, RMS>), grid, dim3(512), 0, st, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU, PK, XPK, RMS>), grid, dim3(256), 0, st, p);
     }
     return cbx_check_launch("gemv");
+}
+
+template <int MT, bool SWIGLU>
+int launch_pk(const cbx_gemv_t& p, hipStream_t st) {
+    if (p.norm_w) return launch_nw<MT, SWIGLU, true, true, true>(p, st);  // checked: w_packed && x_packed
+    if (p.w_packed && p.x_packed) return launch_nw<MT, SWIGLU, true, true, false>(p, st);
+    if (p.w_packed) return launch_nw<MT, SWIGLU, true, false, false>(p, st);
+    return launch_nw<MT, SWIGLU, false, false, false>(p, st);
 }
 
 template <bool SWIGLU>
 int launch_mt(const cbx_gemv_t& p, hipStream_t st) {
     switch ((p.M + 15) / 16) {
-        case 1: return launch_nw<1, SWIGLU>(p, st);
-        case 2: return launch_nw<2, SWIGLU>(p, st);
+        case 1: return launch_pk<1, SWIGLU>(p, st);
+        case 2: return launch_pk<2, SWIGLU>(p, st);
         case 3:
-        case 4: return launch_nw<4, SWIGLU>(p, st);
+        case 4: return launch_pk<4, SWIGLU>(p, st);
     }
     return cbx_set_error(CBX_EINVAL, "gemv: M=%d > 64", p.M);
 }
@@ -238,7 +304,43 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float*
     }
 }
 
+// one thread per float4 of the packed image (layout: include/cbx.h "Packed GEMV weight layout")
+__global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K,
+                                                               long ld, int swiglu, long n4) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const int lane = i4 & 63, h = (i4 >> 6) & 1;
+    const long tb = i4 >> 7;  // tile * KB + kb
+    const int KB = K >> 5;
+    const long tile = tb / KB;
+    const int kb = (int)(tb - tile * KB);
+    long r;
+    bool ok;
+    if (swiglu) {
+        const long f = (tile >> 1) * 16 + (lane & 15);
+        ok = f < N;
+        r = (tile & 1) * (long)N + f;
+    } else {
+        r = tile * 16 + (lane & 15);
+        ok = r < N;
+    }
+    const int k = kb * 32 + (lane >> 4) * 8 + h * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(src + r * ld + k);
+    *reinterpret_cast<f32x4*>(dst + i4 * 4) = v;
+}
+
 }  // namespace
+
+extern "C" int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream) {
+    CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight: bad args (K %% 32, ld %% 4)");
+    CBX_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "pack_gemv_weight: alignment");
+    const long tiles = (long)((N + 15) / 16) * (swiglu ? 2 : 1);
+    const long n4 = tiles * (K / 32) * 128;
+    hipLaunchKernelGGL(pack_gemv_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N, K,
+                       ld_src, swiglu, n4);
+    return cbx_check_launch("pack_gemv_weight");
+}
 
 extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     cbx_gemv_t p = *pp;
@@ -250,6 +352,11 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(p.ldx % 4 == 0 && p.ldw % 4 == 0 && (((uintptr_t)p.x | (uintptr_t)p.W) & 15) == 0, "gemv: alignment");
     CBX_REQUIRE(!p.swiglu || (p.ksplit == 1 && p.N % 32 == 0), "gemv: swiglu needs ksplit == 1 and N %% 32 == 0");
     CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
+    CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
+    CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && p.ksplit == 1), "gemv: norm_w needs w_packed, x_packed and ksplit == 1");
+    CBX_REQUIRE(!(p.res || p.out_packed) || p.ksplit == 1, "gemv: res / out_packed need ksplit == 1");
+    CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv: out_packed needs N %% 32 == 0");
+    CBX_REQUIRE(!(p.w_packed || p.x_packed) || p.K % 32 == 0, "gemv: packed operands need K %% 32 == 0");
     return p.swiglu ? launch_mt<true>(p, (hipStream_t)stream) : launch_mt<false>(p, (hipStream_t)stream);
 }
 

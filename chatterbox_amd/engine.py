@@ -36,7 +36,6 @@ class ChatterboxEngine:
         self.flow = FlowEngine(s3gen_sd, self.dev, meanflow=meanflow)
         self.hift = HiFTEngine(s3gen_sd, self.dev)
         self.last_timing = {}
-        self.t3_streams = int(os.environ.get("CBX_T3_STREAMS", "1"))  # > 1: T3Engine.generate_streams (experimental)
 
     @torch.inference_mode()
     def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True):
@@ -73,8 +72,7 @@ class ChatterboxEngine:
                    noise=None, n_cfm_timesteps=10, drop_last_token=True):
         """Full hot path for B utterances.  Returns (wavs: list of 1-D device tensors, speech_tokens: list)."""
         t0 = time.perf_counter()
-        gen = self.t3.generate if self.t3_streams <= 1 else (lambda *a, **k: self.t3.generate_streams(*a, n_streams=self.t3_streams, **k))
-        toks = gen(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
+        toks = self.t3.generate(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
                    min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms,
                    ban_eos=ban_eos, ban_from=ban_from)
         torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from ._lib import GemvNormParams, GemmParams, GemvParams, SamplerParams, check, lib
+from ._lib import GemmParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -146,14 +146,35 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
-def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE):
-    """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials."""
-    M, K = x.shape
+def pack_gemv_weight(w, swiglu=False):
+    """(N, K) fp32 weight [swiglu: (2F, K) = gate rows then up rows] -> lane-ordered packed image of cbx_gemv_f32 (w_packed = 1):
+    (ceil(N/16)*16, K) floats [swiglu: (2*ceil(F/16)*16, K)].  Done once at load (weights are constants)."""
+    w = _f32(w, "w").contiguous()
+    R, K = w.shape
+    N = R // 2 if swiglu else R
+    rows = (N + 15) // 16 * 16 * (2 if swiglu else 1)
+    out = torch.empty(rows, K, device=w.device)
+    check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
+    return out
+
+
+def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
+         norm_w=None, eps=1e-5, res=None, out_packed=False):
+    """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
+    w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
+    norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
+    out_packed: out is written in the packed operand layout of the next gemv."""
+    if x_packed:
+        assert w_packed and M is not None and K is not None
+    else:
+        M, K = x.shape
     N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
     p = GemvParams()
     p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
     p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu, p.act = M, N, K, ksplit, nw, int(swiglu), act
     p.ldx, p.ldw = x.stride(0), w.stride(0)
+    p.w_packed, p.x_packed = int(w_packed), int(x_packed)
+    p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     if ksplit > 1:
         assert out.dim() == 3 and out.shape[0] == ksplit
         p.ldo, p.part_stride = out.stride(1), out.stride(0)
@@ -161,23 +182,6 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
         p.ldo, p.part_stride = out.stride(0), 0
     _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
            lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
-    return out
-
-
-def gemv_norm(res, part, norm_w, w, out, *, res_out=None, swiglu=False, eps=1e-5, N=None):
-    """EXPERIMENTAL fused decode GEMV (cbx_gemv_norm_f32): out = RMSNorm(res + sum_j part[j]) @ w^T, h -> res_out.
-    res (M<=32, K), part (ks<=2, M, K) or None, w (N, K) [swiglu: packed (2N, K)], out (M, N)."""
-    M, K = res.shape
-    N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
-    p = GemvNormParams()
-    p.res, p.part, p.norm_w, p.W, p.out, p.res_out = _p(_f32(res, "res")), _p(part), _p(_f32(norm_w, "norm_w")), _p(_f32(w, "w")), \
-        _p(_f32(out, "out")), _p(res_out)
-    p.M, p.N, p.K, p.ks_in, p.swiglu, p.eps = M, N, K, 0 if part is None else part.shape[0], int(swiglu), eps
-    p.ldr, p.ldw, p.ldo = res.stride(0), w.stride(0), out.stride(0)
-    p.ldp, p.part_stride = (0, 0) if part is None else (part.stride(1), part.stride(0))
-    p.ldro = 0 if res_out is None else res_out.stride(0)
-    _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
-           lambda: check(lib.cbx_gemv_norm_f32(ctypes.byref(p), _stream()), "cbx_gemv_norm_f32"))
     return out
 
 
@@ -223,11 +227,12 @@ def decode_attn(q, kc, vc, out, ctx_lens, scale):
     return out
 
 
-def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale):
-    """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)."""
+def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False):
+    """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)
+    [out_packed: the packed operand image of the o-projection gemv, (ceil(rows/16)*16, H*64)]."""
     rows, H = kc.shape[0], kc.shape[1]
     check(lib.cbx_decode_attn_rope_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out), rows, H,
-                                       qkv.stride(0), out.stride(0), kc.stride(0), kc.stride(1), scale, _stream()),
+                                       qkv.stride(0), out.stride(0), int(out_packed), kc.stride(0), kc.stride(1), scale, _stream()),
           "cbx_decode_attn_rope_f32")
     return out
 
@@ -266,10 +271,11 @@ def axpby(x, y, a=1.0, b=0.0):
     return y
 
 
-def embed(ids, table, out, table2=None, ids2=None, scale=1.0):
-    rows, C = out.shape
+def embed(ids, table, out, table2=None, ids2=None, scale=1.0, out_packed=False):
+    """out_packed: out is the packed operand image (ceil(rows/16)*16, C) of a decode gemv; rows = len(ids)."""
+    rows, C = (ids.numel(), out.shape[1]) if out_packed else out.shape
     assert ids.dtype == torch.int64 and (ids2 is None or ids2.dtype == torch.int32)
-    check(lib.cbx_embed_f32(_p(ids), _p(table), _p(table2), _p(ids2), _p(out), rows, C, out.stride(0), scale, 1, _stream()),
+    check(lib.cbx_embed_f32(_p(ids), _p(table), _p(table2), _p(ids2), _p(out), rows, C, out.stride(0), scale, 3 if out_packed else 1, _stream()),
           "cbx_embed_f32")
     return out
 

@@ -56,11 +56,21 @@ class T3Engine:
                 wo=d(sd[p + "self_attn.o_proj.weight"]),
                 wgu=d(weights.pack_swiglu(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])),
                 wd=d(sd[p + "mlp.down_proj.weight"])))
+        # decode path: the same weights in the lane-ordered packed layout of cbx_gemv_f32 (every wave-level load is 1 KiB contiguous)
+        self.decode_mode = os.environ.get("CBX_T3_DECODE", "v2")
+        if self.decode_mode == "v2":
+            for i, lw in enumerate(self.layers):
+                p = f"tfmr.layers.{i}."
+                lw["wqkv_pk"] = ops.pack_gemv_weight(lw["wqkv"])
+                lw["wo_pk"] = ops.pack_gemv_weight(lw["wo"])
+                lw["wgu_pk"] = ops.pack_gemv_weight(d(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)), swiglu=True)
+                lw["wd_pk"] = ops.pack_gemv_weight(lw["wd"])
         self.norm = d(sd["tfmr.norm.weight"])
         self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
         self.text_pos, self.speech_pos = d(sd["text_pos_emb.emb.weight"]), d(sd["speech_pos_emb.emb.weight"])
         self.head = d(sd["speech_head.weight"])
         self.V = self.head.shape[0]
+        self.head_pk = ops.pack_gemv_weight(self.head) if self.decode_mode == "v2" else None
         c = "cond_enc."
         self.spkr_w, self.spkr_b = d(sd[c + "spkr_enc.weight"]), d(sd[c + "spkr_enc.bias"])
         self.emo_w = d(sd[c + "emotion_adv_fc.weight"].view(-1))
@@ -75,9 +85,7 @@ class T3Engine:
         self.max_pos = max_pos
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
-        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4)
-        # EXPERIMENTAL (CBX_T3_FUSED=1, not yet run on hardware): add + RMSNorm folded into the consumer GEMVs (5 launches per layer)
-        self.fused_norm = os.environ.get("CBX_T3_FUSED", "0") == "1"
+        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=16, d_nw2=16)
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -149,33 +157,27 @@ class T3Engine:
         ops.add_rmsnorm(x, part, self.norm, h)
         ops.gemv(h, self.head, st["logits"], nw=tn["head_nw"])
 
-    def _forward_decode_fused(self, st):
-        """Same arithmetic as _forward_decode with `x += partials; h = RMSNorm(x)` moved into the prologue of the GEMV that consumes
-        h (ops.gemv_norm): the residual stream ping-pongs between x and x2, the o / down projections keep a 2-way split-K."""
-        ws = st["dws"]
-        if "x2" not in ws:
-            ws["x2"] = torch.empty_like(ws["x"])
-        cur, nxt = ws["x"], ws["x2"]
-        qkv, att, g, po, pd = ws["qkv"], ws["att"], ws["g"], ws["po"][:2], ws["pd"][:2]
-        ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.speech_pos, ids2=st["next_pos_ids"])
-        part = None
+    def _forward_decode_v2(self, st):
+        """5 launches per layer, no split-K partials and no standalone norm kernels: every GEMV operand lives in the lane-ordered
+        packed layout (written that way by its producer), RMSNorm is folded into the q/k/v, gate/up and head GEMVs (x * norm_w on
+        the way to the MFMA, rstd in the epilogue), and the o / down projections add the residual in their epilogue (in place)."""
+        ws, tn = st["dws"], self.tune
+        rows = st["rows"]
+        x, qkv, att, g = ws["x_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"]
+        pk = dict(w_packed=True, x_packed=True, M=rows)
+        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"], out_packed=True)
         for i, lw in enumerate(self.layers):
-            ops.gemv_norm(cur, part, lw["ln1"], lw["wqkv"], qkv, res_out=None if part is None else nxt)
-            if part is not None:
-                cur, nxt = nxt, cur
-            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125)
-            ops.gemv(att, lw["wo"], po, ksplit=2, nw=8)
-            ops.gemv_norm(cur, po, lw["ln2"], lw["wgu"], g, res_out=nxt, swiglu=True)
-            cur, nxt = nxt, cur
-            ops.gemv(g, lw["wd"], pd, ksplit=2, nw=16)
-            part = pd
-        ops.gemv_norm(cur, part, self.norm, self.head, st["logits"])
+            ops.gemv(x, lw["wqkv_pk"], qkv, N=3 * self.D, K=self.D, nw=tn["qkv_nw"], norm_w=lw["ln1"], **pk)
+            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
+            ops.gemv(att, lw["wo_pk"], x, N=self.D, K=self.D, nw=tn["o_nw2"], res=x, out_packed=True, **pk)
+            ops.gemv(x, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
+            ops.gemv(g, lw["wd_pk"], x, N=self.D, K=self.F, nw=tn["d_nw2"], res=x, out_packed=True, **pk)
+        ops.gemv(x, self.head_pk, st["logits"], N=self.V, K=self.D, nw=tn["head_nw"], norm_w=self.norm, **pk)
 
     def _forward(self, st):
-        if self.fused_norm and st["rows"] <= 32:
-            self._forward_decode_fused(st)
-        else:
-            self._forward_decode(st)
+        if self.decode_mode == "v2" and st["rows"] <= 16:
+            return self._forward_decode_v2(st)
+        self._forward_decode(st)
 
     def _decode_step(self, st):
         self._forward(st)
@@ -209,40 +211,14 @@ class T3Engine:
                   done=i32(B), n_generated=i32(B), next_ids=torch.zeros(rows, dtype=torch.int64, device=dev),
                   next_pos_ids=i32(rows), positions=i32(rows), ctx_lens=i32(rows),
                   dws=dict(x=f(rows, self.D), h=f(rows, self.D), qkv=f(rows, 3 * self.D), att=f(rows, self.D), g=f(rows, self.F),
-                           po=f(8, rows, self.D), pd=f(8, rows, self.D)),
+                           po=f(8, rows, self.D), pd=f(8, rows, self.D),
+                           # packed operand images of the v2 decode path (rows padded to whole 16-row tiles, pad rows stay 0)
+                           x_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
+                           att_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
+                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
                   graph=None, samp=None)
         self._state[key] = st
         return st
-
-    @torch.inference_mode()
-    def generate_streams(self, conds, text_tokens, n_streams=2, uniforms=None, **kw):
-        """EXPERIMENTAL (opt-in, CBX_T3_STREAMS): the batch is cut into `n_streams` contiguous sub-batches that decode
-        concurrently on separate HIP streams, each with its own KV cache and decode graph.  A decode step is a chain of 212
-        dependent, latency-bound launches that leaves most of the chip idle (2.2 of 8 TB/s); two independent chains overlap their
-        round trips at the price of streaming the weights once per chain.  Rows never interact inside T3, so the tokens are the
-        same as generate()'s.  Runs every chain for the full max_new_tokens (no EOS polling)."""
-        B = len(text_tokens)
-        n = max(1, min(int(n_streams), B))
-        if n == 1:
-            return self.generate(conds, text_tokens, uniforms=uniforms, **kw)
-        if len(getattr(self, "_streams", ())) < n:
-            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
-        cur = torch.cuda.current_stream(self.dev)
-        u = None if uniforms is None else torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)
-        handles = []
-        for i in range(n):
-            lo, hi = (B * i) // n, (B * (i + 1)) // n
-            s = self._streams[i]
-            s.wait_stream(cur)  # inputs produced on the caller's stream
-            with torch.cuda.stream(s):
-                handles.append(self.generate(conds if isinstance(conds, dict) else conds[lo:hi], text_tokens[lo:hi],
-                                             uniforms=None if u is None else u[lo:hi], async_mode=True, slot=i, **kw))
-        out = []
-        for i, h in enumerate(handles):
-            with torch.cuda.stream(self._streams[i]):
-                out += self.collect(h)
-            cur.wait_stream(self._streams[i])
-        return out
 
     def collect(self, handle):
         """Fetch the tokens of an (async) generate() call.  Must run on the stream the call was enqueued on."""
@@ -258,7 +234,7 @@ class T3Engine:
                  return_prefill_logits=False, debug_logits=False, async_mode=False, slot=0):
         """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
         carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled).
-        `slot` selects an independent set of workspaces / KV cache / decode graph (see generate_streams)."""
+        `slot` selects an independent set of workspaces / KV cache / decode graph (pipelined serving keeps two alive)."""
         dev, B = self.dev, len(text_tokens)
         rows = 2 * B
         if isinstance(conds, dict):

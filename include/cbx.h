@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 3  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 3: cbx_gemv_norm_f32 (experimental) */
+#define CBX_ABI_VERSION 4  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32 */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -77,24 +77,25 @@ typedef struct cbx_gemv_t {
     int swiglu;
     int act;         /* CBX_ACT_* applied after the bias (ksplit == 1 only): gelu_new of GPT-2's c_fc */
     long ldx, ldw, ldo, part_stride;
+    /* ABI v4 */
+    int w_packed;    /* W is the lane-ordered packed image written by cbx_pack_gemv_weight_f32 (ldw ignored; swiglu: tiles
+                        2f = gate, 2f+1 = up of feature tile f) */
+    int x_packed;    /* x is in the same packed layout (rows padded to 16, ldx ignored); needs w_packed */
+    int out_packed;  /* out (and res) use the packed operand layout of the CONSUMING gemv (its K = this N; N % 32 == 0, ksplit 1) */
+    int reserved0;
+    const float* norm_w; /* [K] or NULL: LlamaRMSNorm(x) folded in (x * norm_w feeds the MFMAs, rstd applied in the epilogue);
+                            needs w_packed, x_packed, ksplit == 1 */
+    const float* res;    /* or NULL: out = res + x W^T, res in the same layout as out (in place allowed); ksplit == 1 */
+    float eps;           /* RMSNorm epsilon */
+    int reserved1;
 } cbx_gemv_t;
+/* Packed GEMV weight layout (decode path; the weights are constants, so they are laid out once for the MFMA lane order):
+ *   dst[(((tile * (K/32) + kb) * 2 + h) * 64 + lane) * 4 + s] = src[tile*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + h*4 + s]
+ * i.e. each (16-row tile, 32-deep K block) is 2 KiB of contiguous memory in exactly the order the 64 lanes of a wave load it
+ * (two 1-KiB instructions).  Rows are zero-padded to a multiple of 16.  swiglu = 1: src holds [gate (F rows); up (F rows)] and
+ * the tiles are interleaved gate/up per 16 features.  dst must hold ceil(N/16)*16*K floats. */
+int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
-/* EXPERIMENTAL (ABI v3, opt-in, not yet run on hardware): decode GEMV with the residual add + split-K reduce + LlamaRMSNorm of
- * its INPUT folded into its prologue -- removes the two cbx_add_rmsnorm_f32 launches of a Llama layer (t3.py:378-386 hot loop).
- *   h = res + sum_{j < ks_in} part[j]  (fixed order);   out[m][n] = rstd[m] * sum_k (h[m][k] * norm_w[k]) * W[n][k]
- * res_out (optional, must not alias res) receives h; swiglu as in cbx_gemv_t.  M <= 32, K in {256,512,768,1024}, ks_in <= 2. */
-typedef struct cbx_gemv_norm_t {
-    const float* res;         /* [M][ldr] residual stream */
-    const float* part;        /* [ks_in][M][ldp] split-K partials of the producing projection, or NULL */
-    const float* norm_w;      /* [K] */
-    const float* W;           /* [N][ldw]  (swiglu: packed [32 gate | 32 up] image, N = #features) */
-    float* out;               /* [M][ldo] */
-    float* res_out;           /* [M][ldro] or NULL */
-    int M, N, K, ks_in, swiglu;
-    float eps;
-    long ldr, ldp, part_stride, ldw, ldo, ldro;
-} cbx_gemv_norm_t;
-int cbx_gemv_norm_f32(const cbx_gemv_norm_t* p, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
                         int rows, int C, long ldx, long ldh, float eps, void* stream);
@@ -133,10 +134,13 @@ int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float*
 
 /* Fused per-token attention of the decode loop: HF apply_rotary_pos_emb on q,k of the fused qkv row (head_dim 64,
  * rotate_half form; cos_t == sin_t == NULL skips the rotation: GPT-2) + DynamicCache append at positions[row] + sdpa over
- * positions [0, positions[row]] (t3.py:378-384, 438-446). */
+ * positions [0, positions[row]] (t3.py:378-384, 438-446).
+ * o_packed: o is written in the packed operand layout of the o-projection GEMV (cbx_gemv_t.x_packed; o_ld ignored). */
 int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
-                             float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, long cache_row_stride,
-                             long cache_head_stride, float scale, void* stream);
+                             float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
+                             long cache_row_stride, long cache_head_stride, float scale, void* stream);
+/* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
+int cbx_set_decode_attn_unroll(int u);
 
 /* Row softmax over materialised scores with optional relative-position term and key mask
  * (RelPositionMultiHeadedAttention.forward, transformer/attention.py:249-330):
@@ -151,9 +155,11 @@ int cbx_act_f32(const float* x, float* y, const float* param, long rows, int C, 
                 float slope, void* stream);
 /* generic 2-D strided copy / scale-add: y = a*x + b*y */
 int cbx_axpby_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, float a, float b, void* stream);
-/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2 ? ids2[r] : pos0+r%period][:]]   (nn.Embedding gathers) */
+/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2[r]][:]]   (nn.Embedding gathers; negative ids give zeros).
+ * flags bit 1 (value 2): out is the packed operand image of a decode GEMV (cbx_gemv_t.x_packed, K = C % 32 == 0; ld_out ignored;
+ * rows of the last 16-row tile that are not written keep their previous contents). */
 int cbx_embed_f32(const long long* ids, const float* table, const float* table2, const int* ids2, float* out,
-                  long rows, int C, long ld_out, float scale, int zero_if_neg, void* stream);
+                  long rows, int C, long ld_out, float scale, int flags, void* stream);
 /* RoPE (HF apply_rotary_pos_emb, rotate_half form) on q,k rows of a fused qkv buffer + KV-cache append.
  * positions[r] gives the absolute position of row r; cos/sin tables are [max_pos][64] (cat(freqs,freqs)). */
 int cbx_rope_kv_f32(float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc, float* vc,

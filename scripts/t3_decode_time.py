@@ -1,0 +1,41 @@
+"""T3 stage time at the bench shape (B = 8, 64 text tokens, 250 speech tokens) for the decode variants (run on the GPU box)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from chatterbox_amd import ops, synth
+from chatterbox_amd.t3 import T3Engine
+
+dev = torch.device("cuda:0")
+sd = synth.t3_state_dict(30, 0)
+B, N = 8, 250
+texts = [synth.text_tokens(64, seed=b) for b in range(B)]
+u = synth.rand((B, N), seed=1)
+res = {}
+for mode, tune in (("v1", {}), ("v2", {}), ("v2", dict(o_nw2=8, d_nw2=8)), ("v2", dict(qkv_nw=4, gu_nw=4)), ("v2", dict(da_u=16)), ("v2", dict(da_u=8))):
+    os.environ["CBX_T3_DECODE"] = mode
+    eng = T3Engine(sd, dev)
+    da_u = tune.pop("da_u", 4)
+    ops.lib.cbx_set_decode_attn_unroll(da_u)
+    eng.tune.update(tune)
+    kw = dict(max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561)
+    toks = eng.generate(synth.t3_cond(), texts, **kw)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        toks = eng.generate(synth.t3_cond(), texts, **kw)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    key = f"{mode} {tune} da_u={da_u}"
+    res[key] = [t.tolist() for t in toks]
+    print(f"{key:50s} T3 stage {min(ts) * 1e3:7.1f} ms  ({min(ts) / (N - 1) * 1e3:.3f} ms/token incl. prefill)", flush=True)
+    del eng
+    torch.cuda.empty_cache()
+ks = list(res)
+for k in ks[1:]:
+    same = res[k] == res[ks[0]]
+    print(f"tokens {k} == {ks[0]}: {same}")

@@ -1,0 +1,214 @@
+"""Golden vectors AT THE SHAPES BASELINE.json NAMES, produced by the UNMODIFIED reference (authoring container only).
+
+    python tests/golden/make_golden_big.py [t3_l30_b8] [s3gen_t1000] [vc_t3500] [turbo_l24]
+
+  t3_l30_b8    configs[2]: 30-layer Llama T3, 8 utterances (64 text tokens each, different text / uniforms), 250 sampled
+               tokens each -- the reference is batch-1, so 8 `T3.inference` calls.  Stores all tokens and a strided subset of the
+               raw speech_head logits (every 8th step, every 32nd id) of both CFG rows.
+  s3gen_t1000  configs[2]: S3Gen at P = 250 prompt tokens, N = 250 generated tokens (T = 1000 mel frames), 10 Euler steps with
+               CFG, 2 utterances; stores the CFM mel and windows of the HiFT waveform (full waveform = 960 KB per utterance).
+  vc_t3500     configs[4]: 60 s voice conversion from the token boundary: N = 1500 tokens, P = 250 (T = 3500) through the
+               10-step-class CFG estimator (2 Euler steps bound the CPU time) + HiFT.
+  turbo_l24    configs[1]: GPT-2-medium T3 (24 layers), B = 1, 64 sampled tokens.
+
+Like make_golden.py: weights are regenerated from seeds by chatterbox_amd/synth.py (fingerprinted), RNG is injected.
+Each case also re-runs the CPU oracle on the same inputs and prints / asserts the oracle-vs-reference error, which is the
+measured noise floor the tolerances in DESIGN.md section 1 are derived from.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from chatterbox_amd import synth  # noqa: E402
+from oracle import ref_import, ref_torch as O  # noqa: E402
+from make_golden import fingerprint  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SAMP = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+WAV_WIN = 4800  # samples per stored waveform window
+
+
+def wav_windows(n_samples, n_win):
+    """Start offsets of `n_win` evenly spaced windows (the first one covers trim_fade's region)."""
+    return np.linspace(0, n_samples - WAV_WIN, n_win).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- configs[2]: T3, 30 layers x 250 tokens x B = 8
+
+
+def golden_t3_b8(name="t3_l30_b8", n_layers=30, steps=250, n_text=64, B=8, check_oracle=(0,)):
+    T3, T3Config, T3Cond, lc = ref_import.load_T3()
+    lc.LLAMA_CONFIGS["Llama_520M"]["num_hidden_layers"] = n_layers
+    sd = synth.t3_state_dict(n_layers, 0)
+    m = T3(T3Config.multilingual()).eval()
+    m.load_state_dict(sd, strict=True)
+    ci = synth.t3_cond()
+    step_idx = torch.arange(0, steps, 8)
+    logit_idx = torch.arange(0, 8194, 32)
+    all_tok, all_log, all_u, gaps = [], [], [], []
+    for b in range(B):
+        cond = T3Cond(speaker_emb=ci["speaker_emb"], cond_prompt_speech_tokens=ci["cond_prompt_speech_tokens"],
+                      emotion_adv=ci["emotion_adv"])
+        tt = synth.text_tokens(n_text, seed=1 + b)
+        u = synth.rand((steps,), seed=7 + b)
+        raw, step, gap = [], [0], []
+        hook = m.speech_head.register_forward_hook(lambda mod, i, o: raw.append(o[:, -1].detach().clone()))
+        orig = torch.multinomial
+
+        def fake_multinomial(probs, num_samples=1, **kw):
+            p = probs[0].clone()
+            p[O.STOP_SPEECH] = 0.0
+            tok = O.sample_inverse_cdf(p, u[step[0]])
+            # distance of the uniform to the nearest CDF edge: how much logit noise the sampled id tolerates
+            cdf = torch.cumsum(p.double() / p.double().sum(), 0)
+            gap.append(float((cdf - float(u[step[0]])).abs().min()))
+            step[0] += 1
+            return torch.tensor([[tok]])
+
+        torch.multinomial = fake_multinomial
+        t0 = time.time()
+        try:
+            toks = m.inference(t3_cond=cond, text_tokens=torch.stack([tt, tt]), max_new_tokens=steps, **SAMP)
+        finally:
+            torch.multinomial = orig
+            hook.remove()
+        raw = torch.stack(raw[:steps])  # (steps, 2, V)
+        print(f"[{name}] utt {b}: reference {time.time() - t0:.1f} s, min CDF gap {min(gap):.2e}, tokens[:8] {toks[0][:8].tolist()}", flush=True)
+        if b in check_oracle:
+            t0 = time.time()
+            ot, ol = O.t3_inference(sd, n_layers, ci, torch.stack([tt, tt]), steps, u, ban_eos=True, return_logits=True, **SAMP)
+            err = (ol - raw).abs().max().item()
+            print(f"[{name}] utt {b}: oracle {time.time() - t0:.1f} s, oracle-vs-reference logits max-abs {err:.3e}, "
+                  f"tokens equal {torch.equal(ot, toks[0])}", flush=True)
+            assert err < 2e-3 and torch.equal(ot, toks[0])
+        all_tok.append(toks[0].numpy())
+        all_log.append(raw[step_idx][:, :, logit_idx].numpy())
+        all_u.append(u.numpy())
+        gaps.append(np.array(gap))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, steps=steps, n_text=n_text, B=B,
+                        tokens=np.stack(all_tok), logits_sub=np.stack(all_log).astype(np.float32), step_idx=step_idx.numpy(),
+                        logit_idx=logit_idx.numpy(), uniforms=np.stack(all_u), cdf_gap=np.stack(gaps).astype(np.float32),
+                        fp=fingerprint(sd))
+
+
+# ----------------------------------------------------------------------------- configs[2] / configs[4]: S3Gen at full length
+
+
+def _run_ref_s3gen(m, toks, ref, z, phase, noise, n_steps):
+    import torch.distributions.uniform as U
+    o_rl, o_us = torch.randn_like, U.Uniform.sample
+    try:
+        torch.randn_like = lambda t, **kw: z.clone()
+        mel = m.flow_inference(toks, ref_dict=dict(ref), n_cfm_timesteps=n_steps, finalize=True)
+        torch.randn_like = lambda t, **kw: noise.clone() if t.shape == noise.shape else torch.zeros_like(t)
+        U.Uniform.sample = lambda self, sample_shape=torch.Size(): phase.clone()
+        wav, src = m.hift_inference(mel)
+    finally:
+        torch.randn_like, U.Uniform.sample = o_rl, o_us
+    wav = wav.clone()
+    wav[:, : len(m.trim_fade)] *= m.trim_fade
+    return mel, wav
+
+
+def golden_s3gen_full(name, P, N, n_steps, B, n_win, check_oracle=(0,)):
+    S3 = ref_import.load_S3Gen()
+    sd = synth.s3gen_state_dict(0)
+    m = S3().eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("tokenizer.", "speaker_encoder.")) for k in missing)
+    ref = synth.s3gen_ref(n_prompt_tokens=P)
+    T = 2 * (P + N)
+    mels, wins, rms = [], [], []
+    starts = wav_windows(960 * N, n_win)
+    for b in range(B):
+        toks = synth.speech_tokens(N, seed=1 + b)[None]
+        z = synth.randn((1, 80, T), seed=5 + 10 * b)
+        phase = (synth.rand((1, 9, 1), seed=6 + 10 * b) * 2 - 1) * np.pi
+        phase[:, 0] = 0
+        noise = synth.randn((1, 9, 960 * N), seed=6 + 10 * b)
+        t0 = time.time()
+        mel, wav = _run_ref_s3gen(m, toks, ref, z, phase, noise, n_steps)
+        print(f"[{name}] utt {b}: reference {time.time() - t0:.1f} s; mel std {mel.std():.3f}; wav rms {wav.pow(2).mean().sqrt():.4f}", flush=True)
+        if b in check_oracle:
+            t0 = time.time()
+            o_wav, o_mel = O.s3gen_inference(sd, toks, torch.tensor([N]), ref, z, phase, noise, n_steps)
+            o_wav2, _ = O.hift_inference(sd, mel, phase, noise)
+            e = (o_mel - mel).abs()
+            e2 = (O.trim_fade(o_wav2) - wav).pow(2).mean().sqrt().item()
+            e1 = (o_wav - wav).pow(2).mean().sqrt().item()
+            print(f"[{name}] utt {b}: oracle {time.time() - t0:.1f} s; oracle-vs-reference mel L1 {e.mean():.3e} max {e.max():.3e}; "
+                  f"wav RMSE same-mel {e2:.3e}, end-to-end {e1:.3e}", flush=True)
+            assert e.mean() < 1e-4
+        mels.append(mel[0].numpy())
+        wins.append(np.stack([wav[0, s:s + WAV_WIN].numpy() for s in starts]))
+        rms.append(float(wav.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), P=P, N=N, n_steps=n_steps, B=B, mel=np.stack(mels),
+                        wav_win=np.stack(wins), win_start=starts, wav_rms=np.array(rms), fp=fingerprint(sd))
+
+
+# ----------------------------------------------------------------------------- configs[1]: Turbo, 24 layers
+
+
+def golden_turbo_l24(name="turbo_l24", n_layers=24, d=1024, steps=64, n_text=64):
+    T3, T3Config, T3Cond, lc = ref_import.load_T3()
+    cfg_name = "GPT2_medium"
+    lc.LLAMA_CONFIGS[cfg_name]["n_layer"] = n_layers
+    hp = T3Config(text_tokens_dict_size=50276)
+    hp.llama_config_name, hp.speech_tokens_dict_size, hp.input_pos_emb = cfg_name, 6563, None
+    hp.speech_cond_prompt_len, hp.use_perceiver_resampler, hp.emotion_adv = 375, False, False
+    sd = synth.t3_turbo_state_dict(n_layers, d, 0, include_wte=True)
+    m = T3(hp).eval()
+    m.load_state_dict(sd, strict=True)
+    del m.tfmr.wte
+    ci = synth.t3_cond(prompt_len=375)
+    cond = T3Cond(speaker_emb=ci["speaker_emb"], cond_prompt_speech_tokens=ci["cond_prompt_speech_tokens"], emotion_adv=None)
+    tt = synth.turbo_text_tokens(n_text)
+    u = synth.rand((steps + 1,), seed=7)
+    raw, step = [], [0]
+    hook = m.speech_head.register_forward_hook(lambda mod, i, o: raw.append(o[:, -1].detach().clone()))
+    orig = torch.multinomial
+
+    def fake_multinomial(probs, num_samples=1, **kw):
+        p = probs[0].clone()
+        p[6562] = 0.0
+        tok = O.sample_inverse_cdf(p, u[step[0]])
+        step[0] += 1
+        return torch.tensor([[tok]])
+
+    torch.multinomial = fake_multinomial
+    try:
+        toks = m.inference_turbo(cond, tt[None], temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2, max_gen_len=steps)
+    finally:
+        torch.multinomial = orig
+        hook.remove()
+    raw = torch.stack(raw[: steps + 1])[:, 0]
+    o_toks, o_logits = O.t3_inference_turbo(sd, n_layers, d // 64, ci, tt, steps, u, ban_eos=True, return_logits=True)
+    err = (o_logits - raw).abs().max().item()
+    print(f"[{name}] ref tokens[:10] {toks[0][:10].tolist()}; oracle-vs-reference logits max-abs {err:.3e}; tokens equal {torch.equal(o_toks, toks[0])}")
+    assert err < 2e-3 and torch.equal(o_toks, toks[0])
+    idx = torch.arange(0, 6563, 13)
+    sidx = torch.arange(0, raw.shape[0], 4)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
+                        logits_sub=raw[sidx][:, idx].numpy(), logit_idx=idx.numpy(), step_idx=sidx.numpy(), uniforms=u.numpy(),
+                        fp=fingerprint({k: v for k, v in sd.items() if k != "tfmr.wte.weight"}))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["turbo_l24", "s3gen_t1000", "t3_l30_b8", "vc_t3500"]
+    with torch.inference_mode():
+        if "turbo_l24" in which:
+            golden_turbo_l24()
+        if "s3gen_t1000" in which:
+            golden_s3gen_full("s3gen_t1000", P=250, N=250, n_steps=10, B=2, n_win=6)
+        if "t3_l30_b8" in which:
+            golden_t3_b8()
+        if "vc_t3500" in which:
+            golden_s3gen_full("vc_t3500", P=250, N=1500, n_steps=2, B=1, n_win=12)

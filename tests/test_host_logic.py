@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -34,7 +34,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     from chatterbox_amd import _lib
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
-    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams, "cbx_gemv_norm_t": _lib.GemvNormParams,
+    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams,
                "cbx_sampler_t": _lib.SamplerParams}
     lines = []
     for cname, cls in structs.items():

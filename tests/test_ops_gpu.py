@@ -459,44 +459,77 @@ def test_decode_attn_rope_fused(dev):
         _close(kc[r, :, :n], kc0[r, :, :n], 0.0, "cache untouched")
 
 
-import os as _os
+def _unpack_operand(img, rows, K):
+    """Inverse of the packed GEMV operand layout (include/cbx.h): image (ceil(rows/16)*16, K) -> row-major (rows, K)."""
+    T = img.shape[0] // 16
+    v = img.view(T, K // 32, 2, 4, 16, 4)            # [tile][kb][h][q][c][s]
+    return v.permute(0, 4, 1, 3, 2, 5).reshape(T * 16, K)[:rows]  # [tile][c][kb][q][h][s]
 
-_EXPERIMENTAL = _os.environ.get("CBX_TEST_EXPERIMENTAL") == "1"
 
-
-@pytest.mark.skipif(not _EXPERIMENTAL, reason="opt-in kernel written after the round's GPU budget was spent: CBX_TEST_EXPERIMENTAL=1 runs it")
-@pytest.mark.parametrize("M,N,K,ks,swiglu", [(16, 3072, 1024, 0, False), (16, 3072, 1024, 2, False), (16, 4096, 1024, 2, True),
-                                             (16, 8194, 1024, 2, False), (6, 96, 768, 1, False), (32, 1024, 1024, 2, True), (30, 64, 256, 1, False)])
-def test_gemv_norm_fused(dev, M, N, K, ks, swiglu):
-    """cbx_gemv_norm_f32: RMSNorm(res + sum part) @ W^T (+ SwiGLU), residual written back -- against torch fp32."""
+@pytest.mark.parametrize("M,N,K,swiglu,nw", [(16, 3072, 1024, False, 8), (16, 4096, 1024, True, 8), (16, 8194, 1024, False, 4),
+                                             (6, 96, 768, False, 4), (32, 1024, 1024, True, 4), (50, 64, 256, False, 4)])
+def test_gemv_packed_rms_fused(dev, M, N, K, swiglu, nw):
+    """Packed-operand decode GEMV with LlamaRMSNorm folded in: out = RMSNorm(x) W^T (+ SwiGLU) against torch fp32; the packed
+    weight path must be bit-identical to the row-major one (same arithmetic order)."""
     from chatterbox_amd import ops, weights
     from oracle import ref_torch as O
-    res, nw = _r((M, K), 1), 1 + 0.1 * _r((K,), 2)
-    part = _r((ks, M, K), 3, 0.3) if ks else None
-    h = res + (part.sum(0) if ks == 1 else (part[0] + part[1]) if ks == 2 else 0)
-    hn = O.rms_norm(h, nw)
+    x, nwt = _r((M, K), 1), 1 + 0.1 * _r((K,), 2)
+    hn = O.rms_norm(x, nwt)
+    xp = ops.pack_gemv_weight(x.to(dev))
+    assert torch.equal(_unpack_operand(xp, M, K).cpu(), x), "operand packer"
     out = torch.empty(M, N, device=dev)
-    res_out = torch.full((M, K), 7.0, device=dev)
     if swiglu:
         g, u = _r((N, K), 4, 1 / math.sqrt(K)), _r((N, K), 5, 1 / math.sqrt(K))
-        ops.gemv_norm(res.to(dev), None if part is None else part.to(dev), nw.to(dev), weights.pack_swiglu(g, u).to(dev), out,
-                      res_out=res_out, swiglu=True)
+        wp = ops.pack_gemv_weight(torch.cat([g, u]).to(dev), swiglu=True)
+        ops.gemv(xp, wp, out, N=N, M=M, K=K, swiglu=True, nw=nw, w_packed=True, x_packed=True, norm_w=nwt.to(dev))
         ref = F.silu(F.linear(hn, g)) * F.linear(hn, u)
+        # no-norm variants: packed W (+ packed x) == row-major image, bit for bit
+        o1, o2, o3 = (torch.empty(M, N, device=dev) for _ in range(3))
+        ops.gemv(x.to(dev), weights.pack_swiglu(g, u).to(dev), o1, swiglu=True, nw=nw)
+        ops.gemv(x.to(dev), wp, o2, N=N, swiglu=True, nw=nw, w_packed=True)
+        ops.gemv(xp, wp, o3, N=N, M=M, K=K, swiglu=True, nw=nw, w_packed=True, x_packed=True)
     else:
         w = _r((N, K), 4, 1 / math.sqrt(K))
-        ops.gemv_norm(res.to(dev), None if part is None else part.to(dev), nw.to(dev), w.to(dev), out, res_out=res_out)
+        wp = ops.pack_gemv_weight(w.to(dev))
+        ops.gemv(xp, wp, out, N=N, M=M, K=K, nw=nw, w_packed=True, x_packed=True, norm_w=nwt.to(dev))
         ref = F.linear(hn, w)
-    _close(out, ref, 3e-5 * max(1.0, math.sqrt(K / 256)), "gemv_norm")
-    _close(res_out, h, 1e-6, "residual write-back")
+        o1, o2, o3 = (torch.empty(M, N, device=dev) for _ in range(3))
+        ops.gemv(x.to(dev), w.to(dev), o1, nw=nw)
+        ops.gemv(x.to(dev), wp, o2, N=N, nw=nw, w_packed=True)
+        ops.gemv(xp, wp, o3, N=N, M=M, K=K, nw=nw, w_packed=True, x_packed=True)
+    _close(out, ref, 3e-5 * max(1.0, math.sqrt(K / 256)), "gemv rms-fused")
+    assert torch.equal(o1, o2) and torch.equal(o1, o3), "packed operand paths must equal the row-major path bit for bit"
 
 
-@pytest.mark.skipif(not (_EXPERIMENTAL and _os.environ.get("CBX_SPLIT_AK") == "1"),
-                    reason="A-stationary K=256 split GEMM (gemm_split_ak.hip) is opt-in: CBX_TEST_EXPERIMENTAL=1 CBX_SPLIT_AK=1 runs it")
-def test_split_gemm_ak_shapes(dev):
+@pytest.mark.parametrize("M,N,K,nw", [(16, 1024, 1024, 16), (16, 1024, 4096, 16), (7, 1024, 1024, 8), (16, 64, 256, 4)])
+def test_gemv_packed_residual_epilogue(dev, M, N, K, nw):
+    """o / down projection form: out_packed = res_packed + x W^T, in place on the packed residual stream."""
     from chatterbox_amd import ops
-    with ops.gemm_precision(3):
-        for (M, N, K) in [(4000, 1536, 256), (2048, 1024, 256), (1027, 520, 256)]:
-            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
-            out = torch.empty(M, N, device=dev)
-            ops.linear(x.to(dev), w.to(dev), out, bias=b.to(dev), act=ops.GELU_ERF, residual=r.to(dev))
-            _close(out, F.gelu(F.linear(x, w, b)) + r, _SPLIT_TOL[3], f"split-ak linear {M}x{N}x{K}")
+    x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, N), 3)
+    xp, wp = ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(w.to(dev))
+    rp = ops.pack_gemv_weight(r.to(dev))
+    ops.gemv(xp, wp, rp, N=N, M=M, K=K, nw=nw, w_packed=True, x_packed=True, res=rp, out_packed=True)
+    got = _unpack_operand(rp, M, N)
+    _close(got, r + F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "gemv residual epilogue")
+    if M < 16:
+        assert float(rp.view(-1, 16, 4)[:, M:].abs().max()) == 0.0, "pad rows of the packed image must stay zero"
+
+
+def test_decode_attn_packed_output_and_embed_packed(dev):
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    rows, H, maxp = 6, 16, 128
+    kc, vc, qkv = _r((rows, H, maxp, 64), 1).to(dev), _r((rows, H, maxp, 64), 2).to(dev), _r((rows, 3 * H * 64), 3).to(dev)
+    pos = torch.tensor([0, 4, 63, 100, 17, 127], dtype=torch.int32, device=dev)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    a, b = torch.empty(rows, H * 64, device=dev), torch.zeros(16, H * 64, device=dev)
+    ops.decode_attn_rope(qkv, pos, cos.to(dev), sin.to(dev), kc.clone(), vc.clone(), a, 0.125)
+    ops.decode_attn_rope(qkv, pos, cos.to(dev), sin.to(dev), kc.clone(), vc.clone(), b, 0.125, out_packed=True)
+    assert torch.equal(_unpack_operand(b, rows, H * 64), a)
+    ids = torch.tensor([5, 0, 99, 3, 3, 7, 1], dtype=torch.int64, device=dev)
+    ids2 = torch.arange(7, dtype=torch.int32, device=dev)
+    t1, t2 = _r((100, 256), 5).to(dev), _r((16, 256), 6).to(dev)
+    e1, e2 = torch.empty(7, 256, device=dev), torch.zeros(16, 256, device=dev)
+    ops.embed(ids, t1, e1, table2=t2, ids2=ids2)
+    ops.embed(ids, t1, e2, table2=t2, ids2=ids2, out_packed=True)
+    assert torch.equal(_unpack_operand(e2, 7, 256), e1)

@@ -41,7 +41,7 @@ class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("out_packed", c_int), ("reserved0", c_int),
-                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("reserved1", c_int)]
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f)]
 
 
 class SamplerParams(ctypes.Structure):
@@ -51,7 +51,7 @@ class SamplerParams(ctypes.Structure):
         ("rep_penalty", c_float), ("top_k", c_int), ("order", c_int), ("ban_token", c_int), ("eos_token", c_int), ("ban_from", c_int),
         ("seen", c_f), ("uniforms", c_f), ("max_steps", c_int), ("step", c_f), ("out_tokens", c_f),
         ("done", c_f), ("n_generated", c_f), ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f),
-        ("ctx_lens", c_f),
+        ("ctx_lens", c_f), ("dev_params", c_f),
     ]
 
 

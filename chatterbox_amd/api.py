@@ -17,7 +17,7 @@ import torch
 
 from . import synth
 from .engine import ChatterboxEngine, TurboEngine
-from .text import EnTokenizer, MTLTokenizer, punc_norm, punc_norm_turbo
+from .text import EnTokenizer, MTLTokenizer, punc_norm, punc_norm_en, punc_norm_turbo
 
 S3GEN_SR, S3_SR = 24000, 16000
 REPO_ID = "ResembleAI/chatterbox"
@@ -171,7 +171,7 @@ class ChatterboxTTS(_Base):
         else:
             assert self.conds is not None, "Please `prepare_conditionals` first or specify `audio_prompt_path`"
         self._set_exaggeration(exaggeration)
-        toks = self.tokenizer.text_to_tokens(punc_norm(text))
+        toks = self.tokenizer.text_to_tokens(punc_norm_en(text))
         return self._generate(toks, drop_last_token=False, temperature=temperature, cfg_weight=cfg_weight,
                               repetition_penalty=repetition_penalty, min_p=min_p, top_p=top_p)
 

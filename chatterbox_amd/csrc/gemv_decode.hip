@@ -20,8 +20,13 @@ namespace {
 // RMS: LlamaRMSNorm of the x operand folded in: the lanes multiply their x values by norm_w[k] on the way to the MFMA, accumulate
 // sum_k x^2 per row as a by-product (every workgroup reads whole rows), and the per-row rstd -- a scalar that factors out of the
 // contraction -- is applied in the epilogue:  out[m][n] = rstd[m] * sum_k (x[m][k] * norm_w[k]) * W[n][k].  (ksplit must be 1.)
-template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS>
+// NP > 0 (RMS variants, <= 16 rows): the x operand is x + sum_{j < NP} xpart[j] -- the split-K partial images of the PRODUCING
+// projection are reduced (fixed order) on the way to the MFMA instead of by a separate kernel; workgroup 0 also writes the sum
+// (the new residual stream) to x_out.  Every workgroup re-reads the NP + 1 images from L2: NP * 64 KiB extra per workgroup,
+// which is cheaper than a dependent launch (~1.8 us boundary + a cross-XCD round trip) only for small NP.
+template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
+    static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
     __shared__ float ssq[RMS ? NW * MT * 16 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
     // start while blocks d+1.. are still in flight.
     for (int it0 = 0; it0 < nit; it0 += DEPTH) {
-        f32x4 wv[DEPTH][2], uv[DEPTH][2], xv[DEPTH][MT][2], nv[DEPTH][2];
+        f32x4 wv[DEPTH][2], uv[DEPTH][2], xv[DEPTH][MT][2], nv[DEPTH][2], pv[DEPTH][NP > 0 ? NP : 1][2];
         bool on[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -107,6 +112,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                 nv[d][0] = *reinterpret_cast<const f32x4*>(nwp + blk * 32);
                 nv[d][1] = *reinterpret_cast<const f32x4*>(nwp + blk * 32 + 4);
             }
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const float* pp = p.xpart + (long)j * p.xpart_stride + (xp[0] - p.x);
+                    pv[d][j][0] = *reinterpret_cast<const f32x4*>(pp + xoff);
+                    pv[d][j][1] = *reinterpret_cast<const f32x4*>(pp + xoff + 256);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);  // keep the issue order block by block, so block d's wait is vmcnt(later blocks)
         }
 #pragma unroll
@@ -119,7 +132,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                 if constexpr (SWIGLU) uq = won ? uv[d][h] : zero4;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    f32x4 xq = (on[d] && xok[t]) ? xv[d][t][h] : zero4;
+                    f32x4 xq = xv[d][t][h];
+                    if constexpr (NP > 0) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
+                        if (p.x_out && blockIdx.x == 0 && on[d])  // the reduced residual stream, same packed address as x
+                            *reinterpret_cast<f32x4*>(p.x_out + (xp[0] - p.x) + (it0 + d) * 512 + h * 256) = xq;
+                    }
+                    xq = (on[d] && xok[t]) ? xq : zero4;
                     if constexpr (RMS) {
                         ss[t] += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
                         xq *= nv[d][h];
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         }
         long o;
         if (p.out_packed)  // the consumer's lane-ordered operand layout (its K = this N): see cbx.h
-            o = (((long)t * (p.N >> 5) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + row) * 4 + (n & 3);
+            o = (long)ks * p.part_stride + (((long)t * (p.N >> 5) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + row) * 4 + (n & 3);
         else
             o = (long)ks * p.part_stride + (long)m * p.ldo + n;
         if (p.res) v += p.res[o];  // residual stream in the same layout as out (in place is fine: one thread per element)
@@ -189,26 +209,33 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     }
 }
 
-template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS>
+template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     dim3 grid((p.N + 15) / 16, p.ksplit);
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
-            hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false>), grid, dim3(1024), 0, st, p);
+            hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0>), grid, dim3(1024), 0, st, p);
             return cbx_check_launch("gemv");
         }
     }
-    if (p.nw >= 8) {
-        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU, PK, XPK, RMS>), grid, dim3(512), 0, st, p);
+    if (p.nw >= 8 || NP > 0) {
+        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU, PK, XPK, RMS, NP>), grid, dim3(512), 0, st, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU, PK, XPK, RMS>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU, PK, XPK, RMS, 0>), grid, dim3(256), 0, st, p);
     }
     return cbx_check_launch("gemv");
 }
 
 template <int MT, bool SWIGLU>
 int launch_pk(const cbx_gemv_t& p, hipStream_t st) {
-    if (p.norm_w) return launch_nw<MT, SWIGLU, true, true, true>(p, st);  // checked: w_packed && x_packed
+    if (p.norm_w) {  // checked: w_packed && x_packed && ksplit == 1
+        if constexpr (MT == 1) {
+            if (p.n_xpart == 2) return launch_nw<1, SWIGLU, true, true, true, 2>(p, st);
+            if constexpr (!SWIGLU)  // (the swiglu form would need > 256 VGPRs with 4 partial images in flight)
+                if (p.n_xpart == 4) return launch_nw<1, false, true, true, true, 4>(p, st);
+        }
+        return launch_nw<MT, SWIGLU, true, true, true>(p, st);
+    }
     if (p.w_packed && p.x_packed) return launch_nw<MT, SWIGLU, true, true, false>(p, st);
     if (p.w_packed) return launch_nw<MT, SWIGLU, true, false, false>(p, st);
     return launch_nw<MT, SWIGLU, false, false, false>(p, st);
@@ -354,7 +381,9 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
     CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
     CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && p.ksplit == 1), "gemv: norm_w needs w_packed, x_packed and ksplit == 1");
-    CBX_REQUIRE(!(p.res || p.out_packed) || p.ksplit == 1, "gemv: res / out_packed need ksplit == 1");
+    CBX_REQUIRE(!p.res || p.ksplit == 1, "gemv: res needs ksplit == 1");
+    CBX_REQUIRE(p.n_xpart == 0 || (p.norm_w && p.xpart && p.M <= 16 && (p.n_xpart == 2 || (p.n_xpart == 4 && !p.swiglu)) && p.nw == 8 && p.x_out != p.x),
+                "gemv: xpart needs norm_w, M <= 16, n_xpart in {2, 4}, nw == 8 and x_out != x");
     CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv: out_packed needs N %% 32 == 0");
     CBX_REQUIRE(!(p.w_packed || p.x_packed) || p.K % 32 == 0, "gemv: packed operands need K %% 32 == 0");
     return p.swiglu ? launch_mt<true>(p, (hipStream_t)stream) : launch_mt<false>(p, (hipStream_t)stream);

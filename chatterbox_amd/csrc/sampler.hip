@@ -112,6 +112,16 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     __shared__ int chosen;
 
     const int b = blockIdx.x, tid = threadIdx.x, V = p.V;
+    // sampling parameters: by value, or -- so that a captured hipGraph serves requests with different settings without being
+    // re-captured -- per utterance from device memory
+    float cfg_weight = p.cfg_weight, temperature = p.temperature, min_p = p.min_p, top_p = p.top_p, rep_pen = p.rep_penalty;
+    int top_k = p.top_k, ban_token = p.ban_token, ban_from = p.ban_from;
+    if (p.dev_params) {
+        const float* dp = p.dev_params + (long)b * CBX_SAMPLER_NPARAMS;
+        cfg_weight = dp[0], temperature = dp[1], min_p = dp[2], top_p = dp[3], rep_pen = dp[4];
+        top_k = (int)dp[5], ban_token = (int)dp[6], ban_from = (int)dp[7];
+    }
+    if (ban_from <= 0) ban_from = V;
     if (p.done[b]) return;
     const int step = p.step[b];
     if (step >= p.max_steps) return;
@@ -121,17 +131,17 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
 
     for (int i = tid; i < V; i += NT) {
         float c = lc[i];
-        l[i] = p.cfg ? c + p.cfg_weight * (c - lu[i]) : c;
+        l[i] = p.cfg ? c + cfg_weight * (c - lu[i]) : c;
     }
     __syncthreads();
 
     if (p.order == 0) {  // T3.inference: penalty -> temperature -> min-p -> top-p
-        if (p.rep_penalty != 1.0f) rep_penalty(l, seen, V, p.rep_penalty);
+        if (rep_pen != 1.0f) rep_penalty(l, seen, V, rep_pen);
         __syncthreads();
-        if (p.temperature != 1.0f)
-            for (int i = tid; i < V; i += NT) l[i] = l[i] / p.temperature;
+        if (temperature != 1.0f)
+            for (int i = tid; i < V; i += NT) l[i] = l[i] / temperature;
         __syncthreads();
-        if (p.min_p > 0.f) {
+        if (min_p > 0.f) {
             float m = -INFINITY;
             for (int i = tid; i < V; i += NT) m = fmaxf(m, l[i]);
             m = block_max(m, red);
@@ -141,18 +151,18 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
             const float top = 1.0f / z;
             for (int i = tid; i < V; i += NT) {
                 float pr = __expf(l[i] - m) / z;
-                if (pr < p.min_p * top && l[i] < m) l[i] = -INFINITY;
+                if (pr < min_p * top && l[i] < m) l[i] = -INFINITY;
             }
             __syncthreads();
         }
-        if (p.top_p < 1.0f) top_p_filter(l, V, p.top_p, red);
+        if (top_p < 1.0f) top_p_filter(l, V, top_p, red);
     } else {  // T3.inference_turbo: temperature -> top-k -> top-p -> penalty
-        if (p.temperature > 0.f && p.temperature != 1.0f)
-            for (int i = tid; i < V; i += NT) l[i] = l[i] / p.temperature;
+        if (temperature > 0.f && temperature != 1.0f)
+            for (int i = tid; i < V; i += NT) l[i] = l[i] / temperature;
         __syncthreads();
-        top_k_filter(l, V, p.top_k, red);
-        if (p.top_p < 1.0f) top_p_filter(l, V, p.top_p, red);
-        if (p.rep_penalty != 1.0f) rep_penalty(l, seen, V, p.rep_penalty);
+        top_k_filter(l, V, top_k, red);
+        if (top_p < 1.0f) top_p_filter(l, V, top_p, red);
+        if (rep_pen != 1.0f) rep_penalty(l, seen, V, rep_pen);
         __syncthreads();
     }
 
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     const int i0 = tid * per, i1 = min(V, i0 + per);
     double loc = 0.0;
     for (int i = i0; i < i1; ++i) {
-        float e = (i == p.ban_token || i >= p.ban_from) ? 0.f : __expf(l[i] - m);
+        float e = (i == ban_token || i >= ban_from) ? 0.f : __expf(l[i] - m);
         loc += (double)e;
     }
     // exclusive scan of `loc` over threads: inclusive wave scan + wave bases
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
         double run = excl;
         int pick = -1;
         for (int i = i0; i < i1; ++i) {
-            float e = (i == p.ban_token || i >= p.ban_from) ? 0.f : __expf(l[i] - m);
+            float e = (i == ban_token || i >= ban_from) ? 0.f : __expf(l[i] - m);
             if (e > 0.f) {
                 pick = i;
                 run += (double)e;
@@ -210,18 +220,18 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
         // block-wide arg-max -- `chosen` is block-uniform here, so the barriers below are safe.
         float bm = -INFINITY;
         for (int i = tid; i < V; i += NT)
-            if (i != p.ban_token && i < p.ban_from) {
+            if (i != ban_token && i < ban_from) {
                 const float c = lc[i];
-                bm = fmaxf(bm, p.cfg ? c + p.cfg_weight * (c - lu[i]) : c);
+                bm = fmaxf(bm, p.cfg ? c + cfg_weight * (c - lu[i]) : c);
             }
         bm = block_max(bm, red);
         __syncthreads();
         if (tid == 0) chosen = 0x7fffffff;
         __syncthreads();
         for (int i = tid; i < V; i += NT)
-            if (i != p.ban_token && i < p.ban_from) {
+            if (i != ban_token && i < ban_from) {
                 const float c = lc[i];
-                if ((p.cfg ? c + p.cfg_weight * (c - lu[i]) : c) == bm) atomicMin(&chosen, i);
+                if ((p.cfg ? c + cfg_weight * (c - lu[i]) : c) == bm) atomicMin(&chosen, i);
             }
         __syncthreads();
     }
@@ -251,7 +261,6 @@ extern "C" int cbx_t3_sample(const cbx_sampler_t* p, void* stream) {
                 "t3_sample: null operand");
     CBX_REQUIRE(p->V > 0 && p->V <= MAXV, "t3_sample: V=%d exceeds %d", p->V, MAXV);
     cbx_sampler_t q = *p;
-    if (q.ban_from <= 0) q.ban_from = q.V;
     hipLaunchKernelGGL(t3_sample_kernel, dim3(q.B), dim3(NT), 0, (hipStream_t)stream, q);
     return cbx_check_launch("t3_sample");
 }

@@ -64,7 +64,9 @@ def gather_waveforms(wavs, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [w.detach().cpu() for w in wavs]
     world, rank = dist.get_world_size(), dist.get_rank()
-    dev = wavs[0].device if len(wavs) and dist.get_backend() == "nccl" else torch.device("cpu")
+    # nccl (= RCCL) collectives need device tensors on THIS rank's GPU whatever the inputs are (host copies, an empty shard);
+    # every rank must pick the same kind of device or the collective hangs.  gloo (CPU tests): host tensors.
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     shape = torch.tensor([len(wavs), max([w.numel() for w in wavs], default=0)], dtype=torch.int64, device=dev)
     shapes = [torch.zeros_like(shape) for _ in range(world)]
     dist.all_gather(shapes, shape)

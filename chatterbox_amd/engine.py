@@ -10,6 +10,7 @@ import time
 
 import torch
 
+from . import ops
 from .hift import HiFTEngine
 from .s3gen import FlowEngine
 from .t3 import T3Engine, START_SPEECH, STOP_SPEECH
@@ -37,6 +38,7 @@ class ChatterboxEngine:
         self.hift = HiFTEngine(s3gen_sd, self.dev)
         self.last_timing = {}
 
+    @ops.on_device
     @torch.inference_mode()
     def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True):
         """S3Gen.inference for a list of 1-D token tensors (already valid ids).  Returns (list of 1-D wav tensors on
@@ -66,6 +68,7 @@ class ChatterboxEngine:
             out.append(wav[b, : keep * SAMPLES_PER_TOKEN])
         return out, mel
 
+    @ops.on_device
     @torch.inference_mode()
     def synthesize(self, text_tokens, t3_conds, gen_ref, *, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
                    repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, z=None, phase=None,
@@ -92,6 +95,7 @@ class ChatterboxEngine:
         (HBM-bound GEMVs on a fraction of the CUs); the CFM is MFMA-bound on wide grids -- the two fill each other's
         idle resources.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields (wavs, tokens, latency_s)
         per job in order.  Results are identical to synthesize() called per job."""
+        torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
         if not hasattr(self, "_s_t3"):
             self._s_t3 = torch.cuda.Stream(device=self.dev, priority=-1)
             self._s_voc = torch.cuda.Stream(device=self.dev)
@@ -140,6 +144,7 @@ class TurboEngine:
 
     vocode = ChatterboxEngine.vocode
 
+    @ops.on_device
     @torch.inference_mode()
     def synthesize(self, text_tokens, t3_conds, gen_ref, *, max_gen_len=1000, temperature=0.8, top_k=1000, top_p=0.95,
                    repetition_penalty=1.2, uniforms=None, ban_eos=False, ban_from=0, z=None, phase=None, noise=None):

@@ -22,6 +22,7 @@ class HiFTEngine:
     RB_K = (3, 7, 11)
     SRC_RB_K = (7, 7, 11)
 
+    @ops.on_device
     def __init__(self, sd, device="cuda", precision=None):
         self.dev = dev = torch.device(device)
         # numerics policy of the decoder convs; the F0 predictor always runs exact (its output is integrated into a phase
@@ -80,6 +81,7 @@ class HiFTEngine:
                 ops.conv1d(t1, r["c2"][0], out, taps=k, cin=C, bias=r["c2"][1], pad_left=(k - 1) // 2, lens=lens, residual=cur_x,
                            alpha=alpha, beta=beta, out2=out2, act2=act2, act2_slope=act2_slope)
 
+    @ops.on_device
     @torch.inference_mode()
     def f0_predict(self, mel, lens=None):
         """ConvRNNF0Predictor.forward: mel (B,T,80) -> f0 (B,T)."""
@@ -93,6 +95,7 @@ class HiFTEngine:
         ops.linear(x.view(B * T, 512), self.f0_cls[0], f0, bias=self.f0_cls[1], act=ops.ABS)
         return f0.view(B, T)
 
+    @ops.on_device
     @torch.inference_mode()
     def source(self, f0, phase, noise):
         """f0_upsamp + SourceModuleHnNSF (hifigan.py:467-469, 201-231, 267-283) -> s (B, 480*T)."""
@@ -102,6 +105,7 @@ class HiFTEngine:
         ops.hift_source(f0, phase.reshape(B, 9).contiguous(), noise.contiguous(), self.src_w, self.src_b, s, cum)
         return s
 
+    @ops.on_device
     @torch.inference_mode()
     def decode(self, mel, s, lens=None, fade=True):
         """HiFTGenerator.decode: mel (B,T,80), s (B,480T) -> wav (B,480T).  lens (B,) int32 valid mel frames or None."""
@@ -151,6 +155,7 @@ class HiFTEngine:
         ops.hift_istft(post, wav, 0.99, 480 if fade else 0)
         return wav
 
+    @ops.on_device
     @torch.inference_mode()
     def inference(self, mel, phase=None, noise=None, lens=None, fade=True):
         """HiFTGenerator.inference + S3Gen trim_fade.  mel (B,T,80) channel-last.  Returns (wav (B,480T), source (B,480T))."""

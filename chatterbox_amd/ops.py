@@ -46,6 +46,25 @@ def _timed(kind, flops, nbytes, fn):
     return r
 
 
+def on_device(fn):
+    """Method decorator for the engines: run the body with `self.dev` as the current HIP device, so that every launch (which goes
+    to torch's CURRENT stream of the CURRENT device, see _stream()) lands on the GPU the engine's tensors live on -- the drop-in
+    API accepts any device string (e.g. 'cuda:1' in a process whose current device is 0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        dev = getattr(self, "dev", None)
+        if dev is None:  # decorating __init__(self, state_dict, device="cuda", ...): the device is the 2nd argument
+            dev = k.get("device", a[1] if len(a) > 1 else "cuda")
+        dev = dev if isinstance(dev, torch.device) else torch.device(dev)
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -159,11 +178,12 @@ def pack_gemv_weight(w, swiglu=False):
 
 
 def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-         norm_w=None, eps=1e-5, res=None, out_packed=False):
+         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
-    out_packed: out is written in the packed operand layout of the next gemv."""
+    out_packed: out is written in the packed operand layout of the next gemv (ksplit > 1: out (ksplit, rows16, N) partial images);
+    xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart)."""
     if x_packed:
         assert w_packed and M is not None and K is not None
     else:
@@ -175,6 +195,8 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     p.ldx, p.ldw = x.stride(0), w.stride(0)
     p.w_packed, p.x_packed = int(w_packed), int(x_packed)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
+    if xpart is not None:
+        p.n_xpart, p.xpart, p.xpart_stride, p.x_out = xpart.shape[0], _p(_f32(xpart, "xpart")), xpart.stride(0), _p(x_out)
     if ksplit > 1:
         assert out.dim() == 3 and out.shape[0] == ksplit
         p.ldo, p.part_stride = out.stride(1), out.stride(0)

@@ -21,6 +21,7 @@ def _dev(t, dev):
 
 
 class FlowEngine:
+    @ops.on_device
     def __init__(self, sd, device="cuda", meanflow=False, precision=None):
         self.dev = dev = torch.device(device)
         self.meanflow = meanflow
@@ -140,6 +141,7 @@ class FlowEngine:
         ops.linear(h, lw["w1"], f, bias=lw["b1"], act=ops.SILU)
         ops.linear(f, lw["w2"], x, bias=lw["b2"], residual=x)
 
+    @ops.on_device
     def encode(self, tok, lens):
         """tok (B,N) int64 padded with any valid id, lens (B,) int32 -> mu (B, 2N, 80) channel-last."""
         dev, (B, N) = self.dev, tok.shape
@@ -270,6 +272,7 @@ class FlowEngine:
         ops.linear(m, self.tmlp_w, out, bias=self.tmlp_b)
         return out.view(n, -1, 256)
 
+    @ops.on_device
     def cfm(self, mu, lens, spk, cond, z, n_steps=10, cfg_rate=0.7):
         """CausalConditionalCFM.forward + solve_euler (flow_matching.py:78-145,196-233).
         mu/cond/z (B,T,80) channel-last, lens (B,) int32 valid frames, spk (B,80).  Returns x (B,T,80)."""
@@ -298,6 +301,7 @@ class FlowEngine:
         return xin[:B, :, :80]
 
     # ------------------------------------------------------------------ flow.inference
+    @ops.on_device
     @torch.inference_mode()
     def inference(self, tokens, token_lens, ref, z=None, n_steps=10):
         with ops.gemm_precision(self.precision):

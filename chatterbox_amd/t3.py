@@ -38,7 +38,9 @@ def llama3_rope_tables(max_pos, head_dim=64, theta=500000.0, factor=8.0, low=1.0
 
 class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
+    MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
 
+    @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):
         self.dev = torch.device(device)
         if n_layers is None:
@@ -85,7 +87,7 @@ class T3Engine:
         self.max_pos = max_pos
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
-        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=16, d_nw2=16)
+        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=16, d_ks2=4, d_nw2=8)
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -109,6 +111,7 @@ class T3Engine:
         ops.linear(o, self.p_out[0], out, bias=self.p_out[1], residual=x1)
         return out
 
+    @ops.on_device
     def cond_embeds(self, cond):
         """T3.prepare_conditioning -> (34, 1024): [speaker | 32 perceiver latents | emotion]."""
         dev = self.dev
@@ -158,21 +161,32 @@ class T3Engine:
         ops.gemv(h, self.head, st["logits"], nw=tn["head_nw"])
 
     def _forward_decode_v2(self, st):
-        """5 launches per layer, no split-K partials and no standalone norm kernels: every GEMV operand lives in the lane-ordered
-        packed layout (written that way by its producer), RMSNorm is folded into the q/k/v, gate/up and head GEMVs (x * norm_w on
-        the way to the MFMA, rstd in the epilogue), and the o / down projections add the residual in their epilogue (in place)."""
+        """5 launches per layer and no standalone norm / reduce kernels.  Every GEMV operand lives in the lane-ordered packed layout
+        (written that way by its producer); RMSNorm is folded into the q/k/v, gate/up and head GEMVs (x * norm_w on the way to the
+        MFMA, rstd in the epilogue); the o projection (4 MB) adds the residual in its epilogue; the down projection (16.8 MB, needs all
+        256 CUs) emits `d_ks` split-K partial images that the NEXT consumer (q/k/v of the following layer, or the head) sums into its x
+        operand on the fly, writing the new residual stream to the other ping-pong image."""
         ws, tn = st["dws"], self.tune
-        rows = st["rows"]
-        x, qkv, att, g = ws["x_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"]
+        rows, dks = st["rows"], tn["d_ks2"]
+        cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"][:dks]
         pk = dict(w_packed=True, x_packed=True, M=rows)
-        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.speech_pos, ids2=st["next_pos_ids"], out_packed=True)
+        ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.speech_pos, ids2=st["next_pos_ids"], out_packed=True)
+        red = {}  # partial images pending on the residual stream
         for i, lw in enumerate(self.layers):
-            ops.gemv(x, lw["wqkv_pk"], qkv, N=3 * self.D, K=self.D, nw=tn["qkv_nw"], norm_w=lw["ln1"], **pk)
+            ops.gemv(cur, lw["wqkv_pk"], qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], **red, **pk)
+            if red:
+                cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ops.gemv(att, lw["wo_pk"], x, N=self.D, K=self.D, nw=tn["o_nw2"], res=x, out_packed=True, **pk)
-            ops.gemv(x, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
-            ops.gemv(g, lw["wd_pk"], x, N=self.D, K=self.F, nw=tn["d_nw2"], res=x, out_packed=True, **pk)
-        ops.gemv(x, self.head_pk, st["logits"], N=self.V, K=self.D, nw=tn["head_nw"], norm_w=self.norm, **pk)
+            ops.gemv(att, lw["wo_pk"], cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, **pk)
+            ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
+            if dks > 1:
+                ops.gemv(g, lw["wd_pk"], pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, **pk)
+                red = dict(xpart=pd, x_out=nxt)
+            else:
+                ops.gemv(g, lw["wd_pk"], cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, **pk)
+        if red:
+            red["x_out"] = None
+        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, **red, **pk)
 
     def _forward(self, st):
         if self.decode_mode == "v2" and st["rows"] <= 16:
@@ -215,11 +229,14 @@ class T3Engine:
                            # packed operand images of the v2 decode path (rows padded to whole 16-row tiles, pad rows stay 0)
                            x_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            att_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
+                           x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
+                           pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
                            g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
                   graph=None, samp=None)
         self._state[key] = st
         return st
 
+    @ops.on_device
     def collect(self, handle):
         """Fetch the tokens of an (async) generate() call.  Must run on the stream the call was enqueued on."""
         st, B = handle["st"], handle["B"]
@@ -228,6 +245,7 @@ class T3Engine:
         return [toks[b, : n[b]].clone() for b in range(B)]
 
     # ------------------------------------------------------------------ T3.inference
+    @ops.on_device
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
                  repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16,
@@ -236,6 +254,22 @@ class T3Engine:
         carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled).
         `slot` selects an independent set of workspaces / KV cache / decode graph (pipelined serving keeps two alive)."""
         dev, B = self.dev, len(text_tokens)
+        assert B >= 1, "empty batch"
+        if uniforms is not None:
+            uniforms = torch.as_tensor(uniforms, dtype=torch.float32)
+            assert uniforms.numel() % B == 0 and uniforms.numel() // B >= max_new_tokens, \
+                f"uniforms must hold at least max_new_tokens={max_new_tokens} draws per utterance"
+            uniforms = uniforms.view(B, -1)
+        if B > self.MAX_BATCH:  # rows = 2B feeds the decode GEMV (M <= 64): larger batches run as consecutive sub-batches
+            assert not (async_mode or debug_logits or return_prefill_logits), "sub-batching is only defined for the plain token path"
+            out = []
+            for lo in range(0, B, self.MAX_BATCH):
+                hi = min(B, lo + self.MAX_BATCH)
+                out += self.generate(conds if isinstance(conds, dict) else conds[lo:hi], text_tokens[lo:hi], max_new_tokens=max_new_tokens,
+                                     temperature=temperature, top_p=top_p, min_p=min_p, repetition_penalty=repetition_penalty,
+                                     cfg_weight=cfg_weight, uniforms=None if uniforms is None else uniforms[lo:hi], ban_eos=ban_eos,
+                                     ban_from=ban_from, use_graph=use_graph, poll_every=poll_every, slot=slot)
+            return out
         rows = 2 * B
         if isinstance(conds, dict):
             ce = [self.cond_embeds(conds)] * B

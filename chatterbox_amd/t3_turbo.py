@@ -12,6 +12,8 @@ START_SPEECH, STOP_SPEECH = 6561, 6562
 
 
 class T3TurboEngine:
+    MAX_BATCH = 64
+    @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None):
         self.dev = dev = torch.device(device)
         if n_layers is None:
@@ -91,6 +93,7 @@ class T3TurboEngine:
         self._state[key] = st
         return st
 
+    @ops.on_device
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_gen_len=1000, temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2,
                  uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16, debug_logits=False):
@@ -98,6 +101,21 @@ class T3TurboEngine:
         1-D LongTensors (GPT-2 BPE ids, no SOT/EOT).  Returns a list of B 1-D LongTensors without the trailing EOS."""
         dev, B, D = self.dev, len(text_tokens), self.D
         conds = [conds] * B if isinstance(conds, dict) else conds
+        assert B >= 1, "empty batch"
+        if uniforms is not None:
+            uniforms = torch.as_tensor(uniforms, dtype=torch.float32)
+            assert uniforms.numel() % B == 0 and uniforms.numel() // B >= max_gen_len + 1, \
+                f"uniforms must hold at least max_gen_len + 1 = {max_gen_len + 1} draws per utterance"
+            uniforms = uniforms.view(B, -1)
+        if B > self.MAX_BATCH:  # one row per utterance (no CFG); the decode GEMV serves M <= 64 rows
+            assert not debug_logits, "sub-batching is only defined for the plain token path"
+            out = []
+            for lo in range(0, B, self.MAX_BATCH):
+                hi = min(B, lo + self.MAX_BATCH)
+                out += self.generate(conds[lo:hi], text_tokens[lo:hi], max_gen_len=max_gen_len, temperature=temperature, top_k=top_k,
+                                     top_p=top_p, repetition_penalty=repetition_penalty, uniforms=None if uniforms is None else uniforms[lo:hi],
+                                     ban_eos=ban_eos, ban_from=ban_from, use_graph=use_graph, poll_every=poll_every)
+            return out
         n_prompt = [int(c["cond_prompt_speech_tokens"].numel()) for c in conds]
         tl = [int(t.numel()) for t in text_tokens]
         s0 = [1 + n_prompt[b] + tl[b] + 1 for b in range(B)]

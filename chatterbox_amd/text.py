@@ -19,7 +19,8 @@ _ENDERS = (".", "!", "?", "-", ",", "、", "，", "。", "？", "！")
 _NEEDS_EXTRA = {"zh", "ja", "he", "ko", "ru"}
 
 
-def punc_norm(text: str) -> str:
+def punc_norm(text: str, enders=_ENDERS) -> str:
+    """Multilingual variant (mtl_tts.py:71-110): sentence enders include the CJK marks."""
     if not text:
         return "You need to add some text for me to talk."
     if text[0].islower():
@@ -28,9 +29,14 @@ def punc_norm(text: str) -> str:
     for old, new in _PUNC_MAP.items():
         text = text.replace(old, new)
     text = text.rstrip(" ")
-    if not text.endswith(_ENDERS):
+    if not text.endswith(enders):
         text += "."
     return text
+
+
+def punc_norm_en(text: str) -> str:
+    """English ChatterboxTTS variant (tts.py:26-61): same replacement table, ASCII-only sentence enders."""
+    return punc_norm(text, enders=(".", "!", "?", "-", ","))
 
 
 _TURBO_PUNC_MAP = {"…": ", ", ":": ",", "—": "-", "–": "-", " ,": ",", "“": '"', "”": '"', "‘": "'", "’": "'"}

@@ -81,13 +81,18 @@ typedef struct cbx_gemv_t {
     int w_packed;    /* W is the lane-ordered packed image written by cbx_pack_gemv_weight_f32 (ldw ignored; swiglu: tiles
                         2f = gate, 2f+1 = up of feature tile f) */
     int x_packed;    /* x is in the same packed layout (rows padded to 16, ldx ignored); needs w_packed */
-    int out_packed;  /* out (and res) use the packed operand layout of the CONSUMING gemv (its K = this N; N % 32 == 0, ksplit 1) */
+    int out_packed;  /* out (and res) use the packed operand layout of the CONSUMING gemv (its K = this N; N % 32 == 0); with ksplit > 1
+                        the partial images are part_stride floats apart */
     int reserved0;
     const float* norm_w; /* [K] or NULL: LlamaRMSNorm(x) folded in (x * norm_w feeds the MFMAs, rstd applied in the epilogue);
                             needs w_packed, x_packed, ksplit == 1 */
     const float* res;    /* or NULL: out = res + x W^T, res in the same layout as out (in place allowed); ksplit == 1 */
     float eps;           /* RMSNorm epsilon */
-    int reserved1;
+    int n_xpart;         /* 0, 2 or 4: the x operand is x + sum_j xpart[j] (split-K partial images of the producing projection, packed
+                            layout, reduced in fixed order on the way to the MFMA); needs norm_w, M <= 16, nw == 8 */
+    const float* xpart;  /* [n_xpart] images, xpart_stride floats apart */
+    long xpart_stride;
+    float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it) */
 } cbx_gemv_t;
 /* Packed GEMV weight layout (decode path; the weights are constants, so they are laid out once for the MFMA lane order):
  *   dst[(((tile * (K/32) + kb) * 2 + h) * 64 + lane) * 4 + s] = src[tile*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + h*4 + s]
@@ -170,6 +175,7 @@ int cbx_cfm_euler_f32(float* xin, const float* v, int B, long T, int C, long ld_
                       float dt, float w, int cfg, void* stream);
 
 /* ---- T3 sampler (t3.py:339-368 + HF logits processors): one workgroup per utterance ---- */
+#define CBX_SAMPLER_NPARAMS 8
 typedef struct cbx_sampler_t {
     const float* logits;       /* [2*B][ld] rows b (cond) and B+b (uncond) when cfg, else [B][ld] */
     long ld; int V; int B; int cfg;
@@ -195,6 +201,9 @@ typedef struct cbx_sampler_t {
     int* next_pos_ids;         /* [rows] learned speech-position index of the next input (= step+1), or NULL */
     int* positions;            /* [rows] RoPE / cache position of the next input, incremented, or NULL */
     int* ctx_lens;             /* [rows] context length of the next decode step, incremented, or NULL */
+    const float* dev_params;   /* ABI v4: NULL, or [B][CBX_SAMPLER_NPARAMS] floats in DEVICE memory that override, per utterance,
+                                  {cfg_weight, temperature, min_p, top_p, rep_penalty, top_k, ban_token, ban_from}: a new request
+                                  with other settings then needs no re-capture of the decode hipGraph */
 } cbx_sampler_t;
 int cbx_t3_sample(const cbx_sampler_t* p, void* stream);
 

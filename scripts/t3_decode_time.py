@@ -15,7 +15,7 @@ B, N = 8, 250
 texts = [synth.text_tokens(64, seed=b) for b in range(B)]
 u = synth.rand((B, N), seed=1)
 res = {}
-for mode, tune in (("v1", {}), ("v2", {}), ("v2", dict(o_nw2=8, d_nw2=8)), ("v2", dict(qkv_nw=4, gu_nw=4)), ("v2", dict(da_u=16)), ("v2", dict(da_u=8))):
+for mode, tune in (("v1", {}), ("v2", {}), ("v2", dict(d_ks2=2, d_nw2=8)), ("v2", dict(d_ks2=1, d_nw2=16)), ("v2", dict(o_nw2=8)), ("v2", dict(gu_nw=4))):
     os.environ["CBX_T3_DECODE"] = mode
     eng = T3Engine(sd, dev)
     da_u = tune.pop("da_u", 4)

@@ -32,6 +32,14 @@ def _worker(rank, world, port, q):
         ok &= len(allw) == 5 and all(w.numel() == 100 * (i + 1) and bool((w == i).all()) for i, w in enumerate(allw))
     else:
         ok &= allw is None
+    # an EMPTY shard on one rank (1 utterance over 2 ranks) must neither hang nor mis-shape the collective
+    lo, hi = cdist.shard_range(1, rank, world)
+    one = cdist.gather_waveforms([torch.arange(7, dtype=torch.float32) for _ in range(lo, hi)], dst=0)
+    if rank == 0:
+        ok &= len(one) == 1 and one[0].tolist() == list(range(7))
+    # strong sharding of configs[3]: 256 utterances over 8 ranks = 32 each, contiguous, complete
+    cover = [cdist.shard_range(256, r, 8) for r in range(8)]
+    ok &= all(b - a == 32 for a, b in cover) and cover[0][0] == 0 and cover[-1][1] == 256 and all(cover[i][1] == cover[i + 1][0] for i in range(7))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

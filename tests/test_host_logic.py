@@ -132,13 +132,17 @@ def test_punc_norm_matches_reference_when_available():
     from oracle import ref_import
     if not ref_import.available():
         pytest.skip("reference tree not present (GPU box)")
-    src = open(os.path.join(ref_import.REF_SRC, "mtl_tts.py")).read()
-    start, end = src.index("def punc_norm"), src.index("@dataclass")
-    ns = {}
-    exec(src[start:end], ns)
-    from chatterbox_amd.text import punc_norm
-    for t in ["hello world...  how are you; fine — ok", "Déjà vu: “quoted” ‘text’ ", "x", "already done!", "multi\n line\ttext - dash"]:
-        assert punc_norm(t) == ns["punc_norm"](t), t
+    from chatterbox_amd.text import punc_norm, punc_norm_en, punc_norm_turbo
+    cases = ["hello world...  how are you; fine — ok", "Déjà vu: “quoted” ‘text’ ", "x", "already done!", "multi\n line\ttext - dash",
+             "你好。", "こんにちは、", "ends with cjk comma，", ""]
+    for fname, ours in (("mtl_tts.py", punc_norm), ("tts.py", punc_norm_en), ("tts_turbo.py", punc_norm_turbo)):
+        src = open(os.path.join(ref_import.REF_SRC, fname)).read()
+        start = src.index("def punc_norm")
+        end = src.index("@dataclass", start)
+        ns = {}
+        exec(src[start:end], ns)
+        for t in cases:
+            assert ours(t) == ns["punc_norm"](t), (fname, t)
 
 
 def test_conditionals_roundtrip_and_api_surface(tmp_path):

@@ -515,6 +515,41 @@ def test_gemv_packed_residual_epilogue(dev, M, N, K, nw):
         assert float(rp.view(-1, 16, 4)[:, M:].abs().max()) == 0.0, "pad rows of the packed image must stay zero"
 
 
+@pytest.mark.parametrize("M,N,npart,swiglu", [(16, 3072, 4, False), (16, 8194, 4, False), (9, 1024, 2, False), (16, 4096, 2, True)])
+def test_gemv_partial_sum_operand(dev, M, N, npart, swiglu):
+    """x operand = x + sum of the producer's split-K partial images (fixed order), RMSNorm folded in, the sum written to x_out; and
+    the producer side: a split-K GEMV writing its partial images in the packed layout."""
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    K = 1024
+    x, parts, nwt = _r((M, K), 1), _r((npart, M, K), 2, 0.3), 1 + 0.1 * _r((K,), 3)
+    h = x.clone()
+    for j in range(npart):
+        h = h + parts[j]
+    hn = O.rms_norm(h, nwt)
+    xp = ops.pack_gemv_weight(x.to(dev))
+    pp = torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(npart)])
+    x_out = torch.zeros_like(xp)
+    out = torch.empty(M, N, device=dev)
+    if swiglu:
+        g, u = _r((N, K), 4, 1 / math.sqrt(K)), _r((N, K), 5, 1 / math.sqrt(K))
+        wp = ops.pack_gemv_weight(torch.cat([g, u]).to(dev), swiglu=True)
+        ref = F.silu(F.linear(hn, g)) * F.linear(hn, u)
+    else:
+        w = _r((N, K), 4, 1 / math.sqrt(K))
+        wp = ops.pack_gemv_weight(w.to(dev))
+        ref = F.linear(hn, w)
+    ops.gemv(xp, wp, out, N=N, M=M, K=K, swiglu=swiglu, nw=8, w_packed=True, x_packed=True, norm_w=nwt.to(dev), xpart=pp, x_out=x_out)
+    _close(out, ref, 4e-5, "gemv with partial-sum operand")
+    assert torch.equal(_unpack_operand(x_out, M, K).cpu(), h), "x_out must be x + sum(partials) in fixed order, bit for bit"
+    # producer: split-K partial images in the packed layout
+    w2 = _r((64, K), 6, 1 / math.sqrt(K))
+    pimg = torch.zeros(4, 16, 64, device=dev)
+    ops.gemv(xp, ops.pack_gemv_weight(w2.to(dev)), pimg, N=64, M=M, K=K, ksplit=4, nw=4, w_packed=True, x_packed=True, out_packed=True)
+    got = sum(_unpack_operand(pimg[j], M, 64) for j in range(4))
+    _close(got, F.linear(x, w2), 3e-5, "packed split-K partial images")
+
+
 def test_decode_attn_packed_output_and_embed_packed(dev):
     from chatterbox_amd import ops
     from oracle import ref_torch as O

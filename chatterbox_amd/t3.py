@@ -198,11 +198,10 @@ class T3Engine:
         self._sample(st)
 
     def _sample(self, st):
-        sp = st["samp"]
-        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, cfg_weight=sp["cfg_weight"],
-                      temperature=sp["temperature"], min_p=sp["min_p"], top_p=sp["top_p"], rep_penalty=sp["repetition_penalty"],
-                      top_k=0, order=0, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH,
-                      ban_from=sp["ban_from"], seen=st["seen"],
+        # the sampling parameters are read from device memory (st["samp_dev"], one row per utterance): a request with other settings
+        # replays the SAME captured decode graph
+        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, order=0, eos_token=STOP_SPEECH,
+                      dev_params=st["samp_dev"], seen=st["seen"],
                       uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"], out_tokens=st["out_tokens"],
                       done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"], next_pos_ids=st["next_pos_ids"],
                       positions=st["positions"], ctx_lens=st["ctx_lens"])
@@ -232,7 +231,7 @@ class T3Engine:
                            x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
                            g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
-                  graph=None, samp=None)
+                  graph=None, samp_dev=torch.zeros(B, 8, device=dev))
         self._state[key] = st
         return st
 
@@ -281,10 +280,9 @@ class T3Engine:
         max_ctx = (S + max_new_tokens + 63) // 64 * 64
         assert max_ctx <= self.max_pos, "context exceeds the RoPE table"
         st = self._get_state(B, max_ctx, max_new_tokens, slot)
-        samp = dict(temperature=float(temperature), top_p=float(top_p), min_p=float(min_p),
-                    repetition_penalty=float(repetition_penalty), cfg_weight=float(cfg_weight), ban_eos=bool(ban_eos), ban_from=int(ban_from))
-        if st["samp"] != samp:
-            st["samp"], st["graph"] = samp, None
+        # {cfg_weight, temperature, min_p, top_p, rep_penalty, top_k, ban_token, ban_from} per utterance (cbx_sampler_t.dev_params)
+        st["samp_dev"].copy_(torch.tensor([float(cfg_weight), float(temperature), float(min_p), float(top_p), float(repetition_penalty), 0.0,
+                                           float(STOP_SPEECH if ban_eos else -1), float(ban_from)]).repeat(B, 1), non_blocking=True)
         for k in ("seen", "step", "done", "n_generated", "out_tokens"):
             st[k].zero_()
         st["seen"][:, START_SPEECH] = 1

@@ -63,11 +63,8 @@ class T3TurboEngine:
         ops.gemv(h, self.head, st["logits"], bias=self.head_b, nw=4)
 
     def _sample(self, st):
-        sp = st["samp"]
-        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, cfg_weight=0.0,
-                      temperature=sp["temperature"], min_p=0.0, top_p=sp["top_p"], rep_penalty=sp["repetition_penalty"],
-                      top_k=sp["top_k"], order=1, ban_token=STOP_SPEECH if sp["ban_eos"] else -1, eos_token=STOP_SPEECH,
-                      ban_from=sp["ban_from"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
+        ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, order=1, eos_token=STOP_SPEECH,
+                      dev_params=st["samp_dev"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
                       out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
                       next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
 
@@ -89,7 +86,7 @@ class T3TurboEngine:
                   out_tokens=torch.zeros(B, max_steps, dtype=torch.int64, device=dev), done=i32(B), n_generated=i32(B),
                   next_ids=torch.zeros(B, dtype=torch.int64, device=dev), next_pos_ids=i32(B), positions=i32(B), ctx_lens=i32(B),
                   dws=dict(x=f(B, D), h=f(B, D), qkv=f(B, 3 * D), att=f(B, D), g=f(B, 4 * D), po=f(self.ks_o, B, D), pd=f(self.ks_p, B, D)),
-                  graph=None, samp=None)
+                  graph=None, samp_dev=torch.zeros(B, 8, device=dev))
         self._state[key] = st
         return st
 
@@ -124,10 +121,9 @@ class T3TurboEngine:
         max_ctx = (S + n_samples + 63) // 64 * 64
         assert max_ctx <= self.wpe.shape[0], "context exceeds GPT-2 n_positions"
         st = self._get_state(B, max_ctx, n_samples)
-        samp = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p), repetition_penalty=float(repetition_penalty),
-                    ban_eos=bool(ban_eos), ban_from=int(ban_from))
-        if st["samp"] != samp:
-            st["samp"], st["graph"] = samp, None
+        # sampling parameters live in device memory (cbx_sampler_t.dev_params): no graph re-capture when a request changes them
+        st["samp_dev"].copy_(torch.tensor([0.0, float(temperature), 0.0, float(top_p), float(repetition_penalty), float(top_k),
+                                           float(STOP_SPEECH if ban_eos else -1), float(ban_from)]).repeat(B, 1), non_blocking=True)
         for k in ("seen", "step", "done", "n_generated", "out_tokens"):
             st[k].zero_()
         st["seen"][:, START_SPEECH] = 1  # the first processor call sees ids = [start token] (t3.py:428)

@@ -69,6 +69,7 @@ _SIGS = {
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
     "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
+    "cbx_set_split_tile": ([c_int], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
     "cbx_axpby_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_float, c_f], c_int),

@@ -37,7 +37,10 @@ __device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plan
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP>
+// NS = LDS stages.  2: one barrier per K tile (the next tile is written to the other stage while this one is read).  1: half the
+// LDS (two workgroups per CU also with three planes) at the price of a second barrier per K tile -- the co-resident workgroup fills
+// the bubbles; the register prefetch (two K tiles ahead) is the same.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p) {
     constexpr int BK = SBK;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -195,10 +198,12 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     for (int kt = 0; kt < nk; kt += 2) {
         load_tiles(ra[0], rb[0], ok0);       // tile kt+2
         compute(0);                          // tile kt
-        store_tiles(1, ra[1], rb[1], ok1);   // tile kt+1
+        if constexpr (NS == 1) __syncthreads();  // every wave is done reading the single stage
+        store_tiles(NS == 1 ? 0 : 1, ra[1], rb[1], ok1);   // tile kt+1
         __syncthreads();
         load_tiles(ra[1], rb[1], ok1);       // tile kt+3
-        compute(1);                          // tile kt+1 (all zero when nk is odd and this is past the end)
+        compute(NS == 1 ? 0 : 1);            // tile kt+1 (all zero when nk is odd and this is past the end)
+        if constexpr (NS == 1) __syncthreads();
         store_tiles(0, ra[0], rb[0], ok0);   // tile kt+2
         __syncthreads();
     }
@@ -244,10 +249,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2>
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * NP * (BM + BN) * SLD * sizeof(__bf16);
-    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP>;
+    constexpr size_t lds = (size_t)NS * NP * (BM + BN) * SLD * sizeof(__bf16);
+    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS>;
     static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -261,21 +266,31 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
 
 }  // namespace
 
+static int g_split_tile = getenv("CBX_SPLIT_TILE") ? atoi(getenv("CBX_SPLIT_TILE")) : 0;
+// tuning knob: 0 = automatic, 64 / 12864 / 128 force a tile shape, 1286401 / 12801 = the single-LDS-stage forms
+extern "C" int cbx_set_split_tile(int t) {
+    g_split_tile = t;
+    return 0;
+}
+
 // Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3) or 3 (bf16x6).  Returns -1 when the shape is not
 // served by this kernel (caller falls back to the exact fp32 MFMA kernel).
 int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     if (p.w_kn || p.swiglu) return -1;
     if (p.taps > 1 && p.Cin % SBK != 0) return -1;  // a K tile must not straddle two conv taps
-    static const int force = getenv("CBX_SPLIT_TILE") ? atoi(getenv("CBX_SPLIT_TILE")) : 0;
+    const int force = g_split_tile;
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
     // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by
     // 5-45 % and 64x64 by 0-15 %
     int tile = force ? force : (g128 >= 64 && p.N > 64 ? 12864 : 64);
     if (planes == 2) {
+        if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1>(p, st);
         if (tile == 128) return launch_split<128, 128, 2, 4, 2>(p, st);
         if (tile == 12864) return launch_split<128, 64, 4, 2, 2>(p, st);
         return launch_split<64, 64, 2, 2, 2>(p, st);
     }
+    if (tile == 1286401) return launch_split<128, 64, 4, 2, 3, 1>(p, st);
+    if (tile == 12801) return launch_split<128, 128, 2, 4, 3, 1>(p, st);
     if (tile == 128) return launch_split<128, 128, 2, 4, 3>(p, st);
     if (tile == 12864) return launch_split<128, 64, 4, 2, 3>(p, st);
     return launch_split<64, 64, 2, 2, 3>(p, st);

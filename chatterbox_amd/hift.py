@@ -27,7 +27,7 @@ class HiFTEngine:
         self.dev = dev = torch.device(device)
         # numerics policy of the decoder convs; the F0 predictor always runs exact (its output is integrated into a phase
         # over ~10^5 samples, which amplifies any error in f0)
-        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "3")) if precision is None else int(precision)
+        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "6")) if precision is None else int(precision)
         d = lambda t: t.float().contiguous().to(dev)
         h = "mel2wav."
         fw = lambda p: weights.fold_weight_norm(sd, p)

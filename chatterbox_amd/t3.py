@@ -87,7 +87,8 @@ class T3Engine:
         self.max_pos = max_pos
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
-        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=16, d_ks2=4, d_nw2=8)
+        self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
+        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8)
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -334,7 +335,13 @@ class T3Engine:
             for k, v in saved.items():  # the capture warm-up must not leak into the real sequence
                 st[k].copy_(v)
             st["graph"] = g
+        ev = None
+        if self.time_decode:  # two HIP events around the decode loop on its launch stream (bench.py: in-run decode-step roofline)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        n_replays = 0
         for i in range(1, max_new_tokens):
+            n_replays += 1
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
             elif debug_logits:  # forward and sampler split so that the raw logits of every step can be inspected
@@ -345,6 +352,9 @@ class T3Engine:
                 self._decode_step(st)
             if not ban_eos and not async_mode and (i % poll_every == 0) and bool(st["done"].all()):
                 break
+        if ev is not None:
+            ev[1].record()
+            self.decode_events.append((ev[0], ev[1], n_replays, list(s0), rows))
         if async_mode:  # everything is enqueued on the current stream; no host synchronisation happened
             return dict(st=st, B=B)
         out = self.collect(dict(st=st, B=B))

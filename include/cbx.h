@@ -144,6 +144,8 @@ int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float*
 int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                              float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                              long cache_row_stride, long cache_head_stride, float scale, void* stream);
+/* tuning knob: tile shape of the split-bf16 GEMM (0 = automatic; 64, 12864, 128, 1282) */
+int cbx_set_split_tile(int t);
 /* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
 int cbx_set_decode_attn_unroll(int u);
 

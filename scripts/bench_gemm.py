@@ -31,7 +31,8 @@ for name, m, n, k, taps in shapes:
         else:
             ops.conv1d(x[:, : m // 16], w, out, taps=taps, cin=cin, bias=b, pad_left=taps - 1)
     line = f"{name:16s} M={m:6d} N={n:5d} K={k:5d} "
-    for prec in [int(v) for v in os.environ.get("CBX_PRECS", "1").split(",")]:
+    for prec, tile in [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else 0) for v in os.environ.get("CBX_PRECS", "1").split(",")]:
+        ops.lib.cbx_set_split_tile(tile)
         with ops.gemm_precision(prec):
             for _ in range(3): run()
             torch.cuda.synchronize()
@@ -42,5 +43,5 @@ for name, m, n, k, taps in shapes:
             e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         fl = 2.0 * m * n * k
-        line += f" | p{prec}: {us:7.1f} us {fl/us/1e6:6.1f} TF"
+        line += f" | p{prec}/t{tile}: {us:7.1f} us {fl/us/1e6:6.1f} TF"
     print(line, flush=True)

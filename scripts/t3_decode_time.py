@@ -15,7 +15,10 @@ B, N = 8, 250
 texts = [synth.text_tokens(64, seed=b) for b in range(B)]
 u = synth.rand((B, N), seed=1)
 res = {}
-for mode, tune in (("v1", {}), ("v2", {}), ("v2", dict(d_ks2=2, d_nw2=8)), ("v2", dict(d_ks2=1, d_nw2=16)), ("v2", dict(o_nw2=8)), ("v2", dict(gu_nw=4))):
+VARIANTS = [("v1", {}), ("v2", {}), ("v2", dict(d_ks2=2, d_nw2=8)), ("v2", dict(o_nw2=16)), ("v2", dict(gu_nw=4))]
+if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
+    VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
+for mode, tune in VARIANTS:
     os.environ["CBX_T3_DECODE"] = mode
     eng = T3Engine(sd, dev)
     da_u = tune.pop("da_u", 4)

@@ -26,8 +26,13 @@ SAMP = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05,
 TOL_LOGITS = 1e-3                                            # T3 raw logits, max-abs
 TOL_MEL = {1: (5e-6, 5e-5), 6: (5e-6, 5e-5), 3: (1e-4, 1e-3)}  # CFM mel (L1, max-abs) per numerics mode
 TOL_WAV_SAME_SOURCE = 1e-4                                   # HiFT decode, same mel + same source: RMSE of full scale
-TOL_WAV_FULL = 1e-3                                          # HiFT full inference (own F0 -> own source): RMSE.  The CPU oracle
-#                                                              itself sits 1.7e-4 .. 2.0e-4 from the reference here (F0 phase)
+# HiFT full inference (own F0 -> own source): the waveform is phase-sensitive to F0 (2*pi*h*t*df0), so its tolerance is stated as
+# 5x the measured noise floor = the RMSE of the CPU ORACLE against the reference on the same inputs (make_golden_big.py prints it):
+#   10 s, reference mel in: floor 2.0e-4 -> 1e-3;   60 s, reference mel in: floor 2.7e-4 -> 1.35e-3;
+#   60 s end to end (own CFM mel in): floor 7.4e-4 -> 3.7e-3.
+TOL_WAV_FULL = {"s3gen_t1000": 1e-3, "vc_t3500": 1.35e-3}
+TOL_WAV_E2E_60S = 3.7e-3
+TOL_WAV_BF16_MODE = 2e-2                                     # SURVEY.md 8d "bf16-MFMA mode" waveform tolerance (mode 3, opt-in)
 
 
 def _fp(sd):
@@ -91,6 +96,28 @@ def test_t3_b2_ragged_250_steps_logits_and_tokens(dev, t3_30):
     assert err <= TOL_LOGITS, f"teacher-forced logits max-abs {err:.3e} over 250 steps"
 
 
+def test_t3_config3_per_gpu_shape_64_rows(dev, t3_30):
+    """configs[3] shards 256 utterances 8-way: 32 per GPU = 64 decode rows (the M = 64 decode path: 4 MFMA row tiles, split-K
+    partials + add_rmsnorm).  The 8 golden utterances ride in a 32-utterance device batch; their first 64 sampled ids must equal the
+    reference's (sampling is causal: the 250-step golden run's prefix), whatever their neighbours do."""
+    from chatterbox_amd import synth
+    g = _need("t3_l30_b8")
+    sd, eng = t3_30
+    steps, n_text = 64, int(g["n_text"])
+    where = {0: 0, 5: 1, 9: 2, 14: 3, 17: 4, 22: 5, 27: 6, 31: 7}  # slot in the batch -> golden utterance
+    texts, us = [], []
+    for slot in range(32):
+        if slot in where:
+            texts.append(synth.text_tokens(n_text, seed=1 + where[slot]))
+            us.append(torch.from_numpy(g["uniforms"][where[slot]][:steps]))
+        else:
+            texts.append(synth.text_tokens(20 + (slot * 7) % 45, seed=50 + slot))
+            us.append(synth.rand((steps,), seed=200 + slot))
+    toks = eng.generate(synth.t3_cond(), texts, max_new_tokens=steps, uniforms=torch.stack(us), ban_eos=True, **SAMP)
+    for slot, b in where.items():
+        assert toks[slot].tolist() == g["tokens"][b][:steps].tolist(), f"golden utterance {b} in slot {slot} of the 64-row batch"
+
+
 # ----------------------------------------------------------------------------- configs[2]: S3Gen at T = 1000, HiFT at that length
 
 
@@ -148,7 +175,7 @@ def test_hift_full_length_vs_reference(dev, s3_sd, name):
         mel = torch.from_numpy(g["mel"][b]).t().contiguous()[None].to(dev)
         wav, _ = eng.inference(mel, phase, noise)
         rmse = _window_rmse(wav[0].cpu(), g, b)
-        assert rmse <= TOL_WAV_FULL, f"{name} utt {b}: waveform RMSE {rmse:.3e} (signal rms {float(g['wav_rms'][b]):.3e})"
+        assert rmse <= TOL_WAV_FULL[name], f"{name} utt {b}: waveform RMSE {rmse:.3e} (signal rms {float(g['wav_rms'][b]):.3e})"
 
 
 # ----------------------------------------------------------------------------- configs[4]: 60 s VC, T = 3500, CFG estimator
@@ -169,10 +196,11 @@ def test_vc_t3500_flow_and_wave_vs_reference(dev, s3_sd, prec):
     tol = TOL_MEL[prec]
     assert err.mean() <= tol[0] and err.max() <= tol[1], f"mode {prec}: mel L1 {err.mean():.3e} max {err.max():.3e} at T = {2 * (P + N)}"
     del eng
-    wav, _ = HiFTEngine(s3_sd, dev).inference(mel, phase, noise)
+    wav, _ = HiFTEngine(s3_sd, dev, precision=prec).inference(mel, phase, noise)
     assert wav.shape[1] == 960 * N
     rmse = _window_rmse(wav[0].cpu(), g, 0)
-    assert rmse <= TOL_WAV_FULL, f"mode {prec}: 60 s waveform RMSE {rmse:.3e}"
+    tol_w = TOL_WAV_E2E_60S if prec != 3 else TOL_WAV_BF16_MODE
+    assert rmse <= tol_w, f"mode {prec}: 60 s waveform RMSE {rmse:.3e} > {tol_w:.1e}"
 
 
 # ----------------------------------------------------------------------------- configs[1]: Turbo 24 layers

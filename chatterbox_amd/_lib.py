@@ -76,6 +76,16 @@ _SIGS = {
     "cbx_embed_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_float, c_int, c_f], c_int),
     "cbx_rope_kv_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_f], c_int),
     "cbx_cfm_euler_f32": ([c_f, c_f, c_int, c_long, c_int, c_long, c_long, c_long, c_long, c_float, c_float, c_int, c_f], c_int),
+    "cbx_dwconv1d_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int, c_f], c_int),
+    "cbx_lstm_cell_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_f], c_int),
+    "cbx_affine_act_f32": ([c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_f], c_int),
+    "cbx_cplx_power_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
+    "cbx_unary_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_float, c_f, c_f], c_int),
+    "cbx_reduce_max_f32": ([c_f, c_f, c_long, c_int, c_long, c_f], c_int),
+    "cbx_seg_context_f32": ([c_f, c_f, c_int, c_int, c_int, c_long, c_long, c_f], c_int),
+    "cbx_seg_gate_mul_f32": ([c_f, c_f, c_int, c_int, c_int, c_long, c_long, c_f], c_int),
+    "cbx_stats_pool_f32": ([c_f, c_f, c_int, c_int, c_long, c_f], c_int),
+    "cbx_fsq_index": ([c_f, c_f, c_long, c_long, c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
     "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),

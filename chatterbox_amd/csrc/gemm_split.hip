@@ -285,6 +285,7 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     int tile = force ? force : (g128 >= 64 && p.N > 64 ? 12864 : 64);
     if (planes == 2) {
         if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1>(p, st);
+        if (tile == 1286401) return launch_split<128, 64, 4, 2, 2, 1>(p, st);
         if (tile == 128) return launch_split<128, 128, 2, 4, 2>(p, st);
         if (tile == 12864) return launch_split<128, 64, 4, 2, 2>(p, st);
         return launch_split<64, 64, 2, 2, 2>(p, st);
@@ -292,6 +293,8 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     if (tile == 1286401) return launch_split<128, 64, 4, 2, 3, 1>(p, st);
     if (tile == 12801) return launch_split<128, 128, 2, 4, 3, 1>(p, st);
     if (tile == 128) return launch_split<128, 128, 2, 4, 3>(p, st);
-    if (tile == 12864) return launch_split<128, 64, 4, 2, 3>(p, st);
+    // three planes: the double-buffered 128x64 image is 92 KB (one workgroup per CU); the single-stage form (46 KB, two per CU) is
+    // 20-55 % faster on every CFM / encoder shape (scripts/bench_gemm.py, gpurun_out/bench_gemm_ns1.log)
+    if (tile == 12864) return force ? launch_split<128, 64, 4, 2, 3>(p, st) : launch_split<128, 64, 4, 2, 3, 1>(p, st);
     return launch_split<64, 64, 2, 2, 3>(p, st);
 }

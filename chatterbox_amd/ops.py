@@ -340,3 +340,71 @@ def hift_istft(x, wav, clamp=0.99, fade_n=0):
     B, frames = x.shape[0], x.shape[1]
     check(lib.cbx_hift_istft_f32(_p(x), _p(wav), B, frames, x.stride(1), clamp, fade_n, _stream()), "cbx_hift_istft_f32")
     return wav
+
+
+# ----------------------------------------------------------------------------- front-end (prompt analysis / voice conversion) kernels
+
+UN_LOG_CLAMP, UN_LOG10_CLAMP, UN_FLOOR_AFFINE, UN_AFFINE = 1, 2, 3, 4
+
+
+def dwconv1d(x, w, y, taps, pad_left, lens=None, add_input=False):
+    """Depthwise conv, channel-last: x, y (B, T, C); w (C, taps)."""
+    B, T, C = x.shape
+    check(lib.cbx_dwconv1d_f32(_p(_f32(x, "x")), _p(_f32(w, "w")), _p(y), _p(lens), B, T, C, taps, pad_left, x.stride(1), y.stride(1),
+                               x.stride(0), y.stride(0), int(add_input), _stream()), "cbx_dwconv1d_f32")
+    return y
+
+
+def lstm_cell(pre, hh, c, h):
+    B, H = c.shape
+    check(lib.cbx_lstm_cell_f32(_p(pre), _p(hh), _p(c), _p(h), B, H, pre.stride(0), hh.stride(0), c.stride(0), h.stride(0), _stream()),
+          "cbx_lstm_cell_f32")
+
+
+def affine_act(x, y, scale, shift, act=NONE):
+    rows, C = x.shape
+    check(lib.cbx_affine_act_f32(_p(_f32(x, "x")), _p(y), _p(scale), _p(shift), rows, C, x.stride(0), y.stride(0), act, _stream()),
+          "cbx_affine_act_f32")
+    return y
+
+
+def cplx_power(spec, out, mode=0, eps=0.0):
+    rows, F = out.shape
+    check(lib.cbx_cplx_power_f32(_p(_f32(spec, "spec")), _p(out), rows, F, spec.stride(0), out.stride(0), mode, eps, _stream()),
+          "cbx_cplx_power_f32")
+    return out
+
+
+def unary(x, y, op, a=0.0, b=0.0, dev_scalar=None):
+    rows, C = x.shape
+    check(lib.cbx_unary_f32(_p(_f32(x, "x")), _p(y), rows, C, x.stride(0), y.stride(0), op, a, b, _p(dev_scalar), _stream()), "cbx_unary_f32")
+    return y
+
+
+def reduce_max(x, out):
+    rows, C = x.shape
+    check(lib.cbx_reduce_max_f32(_p(_f32(x, "x")), _p(out), rows, C, x.stride(0), _stream()), "cbx_reduce_max_f32")
+    return out
+
+
+def seg_context(x, ctx, seg_len=100):
+    T, C = x.shape
+    check(lib.cbx_seg_context_f32(_p(_f32(x, "x")), _p(ctx), T, C, seg_len, x.stride(0), ctx.stride(0), _stream()), "cbx_seg_context_f32")
+    return ctx
+
+
+def seg_gate_mul(y, m, seg_len=100):
+    T, C = y.shape
+    check(lib.cbx_seg_gate_mul_f32(_p(y), _p(m), T, C, seg_len, y.stride(0), m.stride(0), _stream()), "cbx_seg_gate_mul_f32")
+    return y
+
+
+def stats_pool(x, out):
+    T, C = x.shape
+    check(lib.cbx_stats_pool_f32(_p(_f32(x, "x")), _p(out), T, C, x.stride(0), _stream()), "cbx_stats_pool_f32")
+    return out
+
+
+def fsq_index(h, idx):
+    check(lib.cbx_fsq_index(_p(_f32(h, "h")), _p(idx), h.shape[0], h.stride(0), _stream()), "cbx_fsq_index")
+    return idx

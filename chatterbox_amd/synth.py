@@ -236,6 +236,120 @@ def s3gen_state_dict(seed=0, meanflow=False, n_mid=12, n_enc=6, n_up_enc=4):
     return sd
 
 
+# ----------------------------------------------------------------------------- prompt-analysis networks
+
+
+def _bnorm(sd, name, c, seed, affine=True):
+    """eval-mode BatchNorm buffers (+ affine parameters)."""
+    if affine:
+        sd[name + ".weight"] = 1.0 + _normal(name + ".weight", (c,), 0.1, seed)
+        sd[name + ".bias"] = _normal(name + ".bias", (c,), 0.1, seed)
+    sd[name + ".running_mean"] = _normal(name + ".running_mean", (c,), 0.1, seed)
+    sd[name + ".running_var"] = 1.0 + _normal(name + ".running_var", (c,), 0.1, seed).abs()
+    sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+
+CAMPPLUS_BLOCKS = ((12, 3, 1), (24, 3, 2), (16, 3, 2))  # (layers, kernel, dilation): reference xvector.py:377-379
+
+
+def campplus_state_dict(seed=0, prefix="speaker_encoder."):
+    """Keys of `CAMPPlus()` (reference models/s3gen/xvector.py:340-415), stored under `speaker_encoder.` in the S3Gen checkpoint."""
+    sd = {}
+
+    def conv2(name, co, ci, k):
+        sd[name + ".weight"] = _normal(name + ".weight", (co, ci, k, k), math.sqrt(2.0 / (ci * k * k)), seed)
+
+    def conv1(name, co, ci, k, bias=False):
+        sd[name + ".weight"] = _normal(name + ".weight", (co, ci, k), math.sqrt(2.0 / (ci * k)), seed)
+        if bias:
+            sd[name + ".bias"] = _uniform(name + ".bias", (co,), 0.1, seed)
+
+    conv2("head.conv1", 32, 1, 3)
+    _bnorm(sd, "head.bn1", 32, seed)
+    for layer in ("head.layer1", "head.layer2"):
+        for j in (0, 1):
+            q = f"{layer}.{j}"
+            conv2(q + ".conv1", 32, 32, 3)
+            _bnorm(sd, q + ".bn1", 32, seed)
+            conv2(q + ".conv2", 32, 32, 3)
+            _bnorm(sd, q + ".bn2", 32, seed)
+            if j == 0:  # stride 2 -> projection shortcut
+                conv2(q + ".shortcut.0", 32, 32, 1)
+                _bnorm(sd, q + ".shortcut.1", 32, seed)
+    conv2("head.conv2", 32, 32, 3)
+    _bnorm(sd, "head.bn2", 32, seed)
+    conv1("xvector.tdnn.linear", 128, 320, 5)
+    _bnorm(sd, "xvector.tdnn.nonlinear.batchnorm", 128, seed)
+    ch = 128
+    for bi, (n_layers, k, _dil) in enumerate(CAMPPLUS_BLOCKS):
+        for li in range(n_layers):
+            q = f"xvector.block{bi + 1}.tdnnd{li + 1}"
+            cin = ch + li * 32
+            _bnorm(sd, q + ".nonlinear1.batchnorm", cin, seed)
+            conv1(q + ".linear1", 128, cin, 1)
+            _bnorm(sd, q + ".nonlinear2.batchnorm", 128, seed)
+            conv1(q + ".cam_layer.linear_local", 32, 128, k)
+            conv1(q + ".cam_layer.linear1", 64, 128, 1, bias=True)
+            conv1(q + ".cam_layer.linear2", 32, 64, 1, bias=True)
+        ch += n_layers * 32
+        _bnorm(sd, f"xvector.transit{bi + 1}.nonlinear.batchnorm", ch, seed)
+        conv1(f"xvector.transit{bi + 1}.linear", ch // 2, ch, 1)
+        ch //= 2
+    _bnorm(sd, "xvector.out_nonlinear.batchnorm", ch, seed)
+    conv1("xvector.dense.linear", 192, 2 * ch, 1)
+    _bnorm(sd, "xvector.dense.nonlinear.batchnorm", 192, seed, affine=False)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def voice_encoder_state_dict(seed=0):
+    """Keys of `VoiceEncoder()` (reference models/voice_encoder/voice_encoder.py:139-154; ve.safetensors)."""
+    sd = {"similarity_weight": torch.tensor([10.0]), "similarity_bias": torch.tensor([-5.0])}
+    for l, cin in enumerate((40, 256, 256)):
+        b = 1.0 / math.sqrt(256)
+        # inputs are power mels (large dynamic range): keep layer 0's input weights small so the gates do not saturate
+        sd[f"lstm.weight_ih_l{l}"] = _uniform(f"lstm.weight_ih_l{l}", (1024, cin), b * (0.05 if l == 0 else 1.0), seed)
+        sd[f"lstm.weight_hh_l{l}"] = _uniform(f"lstm.weight_hh_l{l}", (1024, 256), b, seed)
+        sd[f"lstm.bias_ih_l{l}"] = _uniform(f"lstm.bias_ih_l{l}", (1024,), b, seed)
+        sd[f"lstm.bias_hh_l{l}"] = _uniform(f"lstm.bias_hh_l{l}", (1024,), b, seed)
+    _linear(sd, "proj", 256, 256, seed)
+    return sd
+
+
+def s3tokenizer_state_dict(seed=0, prefix="tokenizer.", n_layer=6):
+    """Keys of the third-party `S3TokenizerV2` as stored under `tokenizer.` in the S3Gen checkpoint (assumed from the published
+    s3tokenizer package: AudioEncoderV2 + FSQ; parity unpinned)."""
+    sd = {}
+    D = 1280
+    _conv(sd, "encoder.conv1", D, 128, 3, seed)
+    _conv(sd, "encoder.conv2", D, D, 3, seed)
+    for i in range(n_layer):
+        q = f"encoder.blocks.{i}."
+        _norm(sd, q + "attn_ln", D, seed)
+        _linear(sd, q + "attn.query", D, D, seed)
+        _linear(sd, q + "attn.key", D, D, seed, bias=False)
+        _linear(sd, q + "attn.value", D, D, seed)
+        _linear(sd, q + "attn.out", D, D, seed)
+        sd[q + "attn.fsmn_block.weight"] = _uniform(q + "attn.fsmn_block.weight", (D, 1, 31), 0.1, seed)
+        _norm(sd, q + "mlp_ln", D, seed)
+        _linear(sd, q + "mlp.0", 4 * D, D, seed)
+        _linear(sd, q + "mlp.2", D, 4 * D, seed)
+    _linear(sd, "quantizer._codebook.project_down", 8, D, seed, gain=3.0)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def prompt_wav(seconds=6.0, sr=24000, seed=9):
+    """A deterministic speech-like test signal: a few drifting harmonics with an amplitude envelope + a little noise, |x| < 1."""
+    n = int(seconds * sr)
+    t = torch.arange(n, dtype=torch.float64) / sr
+    g = torch.Generator().manual_seed(9000 + seed)
+    f0 = 120.0 + 40.0 * torch.sin(2 * math.pi * 0.7 * t) + 15.0 * torch.sin(2 * math.pi * 2.3 * t)
+    ph = 2 * math.pi * torch.cumsum(f0, 0) / sr
+    x = sum((0.5 / h) * torch.sin(h * ph + float(torch.rand(1, generator=g)) * 6.28) for h in range(1, 9))
+    env = 0.5 * (1 + torch.sin(2 * math.pi * 1.1 * t - 1.0)).clamp(min=0.05)
+    x = x * env + 0.01 * torch.randn(n, generator=g, dtype=torch.float64)
+    return (0.6 * x / x.abs().max()).float()
+
+
 # ----------------------------------------------------------------------------- synthetic inputs (SURVEY 8d)
 
 

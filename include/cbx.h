@@ -218,6 +218,38 @@ int cbx_hift_stft_f32(const float* s, float* spec, const int* sample_lens, int B
 int cbx_hift_istft_f32(const float* x, float* wav, int B, long frames, long ldx, float clamp, int fade_n,
                        void* stream);
 
+/* ---- voice-prompt / voice-conversion front-end ----
+ * Contractions (framed DFT as a GEMM over overlapping waveform rows, mel filterbanks, Conv1d/Conv2d-as-Toeplitz, attention, LSTM
+ * projections) use cbx_gemm_f32 / cbx_flash_attn_f32 / cbx_gemv_f32; these are the remaining element-wise / reduction passes. */
+/* depthwise Conv1d, channel-last: y[b][t][c] = sum_k w[c][k] x[b][t+k-pad_left][c] (+ x[b][t][c]); rows >= lens[b] are zero.
+ * S3TokenizerV2 FSMN memory block (third-party s3tokenizer.model_v2, Conv1d k31 groups=C; parity unpinned). */
+int cbx_dwconv1d_f32(const float* x, const float* w, float* y, const int* lens, int B, int T, int C, int taps, int pad_left,
+                     long ldx, long ldy, long x_sb, long y_sb, int add_input, void* stream);
+/* torch.nn.LSTM cell, gates (i,f,g,o) = pre + hh (voice_encoder.py:139-163: nn.LSTM(40, 256, 3 layers)) */
+int cbx_lstm_cell_f32(const float* pre, const float* hh, float* c, float* h, int B, int H, long ld_pre, long ld_hh, long ldc,
+                      long ldh, void* stream);
+/* y = act(x * scale[c] + shift[c]): eval BatchNorm + ReLU that PRECEDES a conv in CAMPPlus (xvector.py:136-151,262-266) */
+int cbx_affine_act_f32(const float* x, float* y, const float* scale, const float* shift, long rows, int C, long ldx, long ldy,
+                       int act, void* stream);
+/* spec row [re(0..F-1) | im(0..F-1)] -> |.|^2 (mode 0: s3tokenizer.py:158, voice_encoder/melspec.py:40-44) or
+ * sqrt(|.|^2 + eps) (mode 1: s3gen/utils/mel.py:77) */
+int cbx_cplx_power_f32(const float* spec, float* out, long rows, int F, long ld_spec, long ld_out, int mode, float eps, void* stream);
+#define CBX_UN_LOG_CLAMP 1     /* log(max(x, a))                 utils/mel.py:18-19 */
+#define CBX_UN_LOG10_CLAMP 2   /* log10(max(x, a))               s3tokenizer.py:163 */
+#define CBX_UN_FLOOR_AFFINE 3  /* (max(x, *dev_scalar - a) + b) / b   s3tokenizer.py:164-165 */
+#define CBX_UN_AFFINE 4        /* a x + b */
+int cbx_unary_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, int op, float a, float b, const float* dev_scalar,
+                  void* stream);
+int cbx_reduce_max_f32(const float* x, float* out, long rows, int C, long ldx, void* stream);
+/* CAMLayer context (xvector.py:204-231): ctx[s][c] = mean_t x + mean over segment s (avg_pool1d ceil_mode), s = t / seg_len */
+int cbx_seg_context_f32(const float* x, float* ctx, int T, int C, int seg_len, long ldx, long ldc, void* stream);
+/* y[t][c] *= sigmoid(m[t / seg_len][c])  (xvector.py:209-213) */
+int cbx_seg_gate_mul_f32(float* y, const float* m, int T, int C, int seg_len, long ldy, long ldm, void* stream);
+/* StatsPool (xvector.py:153-165): out = [mean_t | unbiased std_t] */
+int cbx_stats_pool_f32(const float* x, float* out, int T, int C, long ldx, void* stream);
+/* FSQ codebook index of S3TokenizerV2 (third-party; restated: tanh * 0.999 -> round -> +1 -> base-3 digits) */
+int cbx_fsq_index(const float* h, long long* idx, long rows, long ldh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

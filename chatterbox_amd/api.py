@@ -3,10 +3,12 @@
 `ChatterboxTTS` (reference tts.py:106), `ChatterboxMultilingualTTS` (mtl_tts.py:155), `ChatterboxVC` (vc.py:16) keep
 the reference names, signatures, defaults, return convention (CPU float tensor (1, n_samples) at `.sr` = 24 kHz) and
 error behaviour (ValueError for an unknown language / model alias, assert when no voice is prepared).  Checkpoints
-are read in the reference's own file and state-dict layout.  Out of scope this round (SURVEY.md 8f "next" rows):
-voice-prompt analysis (`prepare_conditionals` needs the S3 tokenizer, CAMPPlus and the voice encoder), hence voices
-come from `conds.pt` / `Conditionals`; the Turbo/Nano GPT-2 T3 backbone; the watermarker (third-party `perth`,
-applied only if importable -- parity is defined on the pre-watermark waveform).
+are read in the reference's own file and state-dict layout.  `ChatterboxTurboTTS` (tts_turbo.py:111) covers the Turbo / Nano GPT-2
+backbone.  Voice-prompt analysis (`prepare_conditionals`, `ChatterboxVC.set_target_voice`, `ChatterboxVC.generate(audio)`) runs on
+the device through chatterbox_amd/frontend.py (S3 tokenizer, CAMPPlus, voice encoder, 24 kHz mel); it needs the `tokenizer.*` /
+`speaker_encoder.*` tensors of the S3Gen checkpoint and `ve.safetensors`, and fails with a clear message when a checkpoint lacks
+them.  The watermarker (third-party `perth`) is applied only if importable -- parity is defined on the pre-watermark waveform;
+Turbo's `norm_loudness` needs `pyloudnorm` and is skipped with a warning when that is missing (as the reference does on error).
 """
 import os
 from dataclasses import dataclass
@@ -96,6 +98,41 @@ def _load_state(path):
     return sd
 
 
+def _make_analyzer(s3gen_sd, ve_sd, device):
+    from .frontend import PromptAnalyzer
+    return PromptAnalyzer(s3gen_sd, ve_sd, device)
+
+
+def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_seconds=None, norm_loudness=False):
+    """The common body of prepare_conditionals (tts.py:182-206, mtl_tts.py:253-277, tts_turbo.py:241-270).  `wav`: a file path or a
+    (waveform, sample_rate) pair."""
+    from . import frontend as fe
+    if analyzer is None or not analyzer.tokenizer.available or not analyzer.speaker_encoder.available or analyzer.ve is None:
+        raise RuntimeError("voice-prompt analysis needs the `tokenizer.*` and `speaker_encoder.*` tensors of the S3Gen checkpoint and "
+                           "ve.safetensors; this model was built without them -- load a prepared voice with Conditionals.load('conds.pt')")
+    if isinstance(wav, (tuple, list)):
+        w24 = fe.resample(wav[0], wav[1], S3GEN_SR)
+    else:
+        w24, _ = fe.load_wav(wav, S3GEN_SR)
+    if min_seconds is not None:
+        assert len(w24) / S3GEN_SR > min_seconds, "Audio prompt must be longer than 5 seconds!"
+    if norm_loudness:
+        try:
+            import pyloudnorm as ln
+            import numpy as np
+            meter = ln.Meter(S3GEN_SR)
+            gain = 10.0 ** ((-27.0 - meter.integrated_loudness(w24)) / 20.0)
+            if np.isfinite(gain) and gain > 0.0:
+                w24 = w24 * gain
+        except Exception as e:  # the reference prints a warning and carries on (tts_turbo.py:236-237)
+            print(f"Warning: Error in norm_loudness, skipping: {e}")
+    w16 = fe.resample(w24, S3GEN_SR, S3_SR)
+    gen = analyzer.embed_ref(w24[: analyzer.DEC_COND_LEN], S3GEN_SR)
+    spk, ptoks = analyzer.t3_prompt(w16, prompt_len)
+    t3 = T3Cond(speaker_emb=spk, cond_prompt_speech_tokens=ptoks, emotion_adv=exaggeration * torch.ones(1, 1, 1)).to(device=device)
+    return Conditionals(t3, {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in gen.items()})
+
+
 def _watermarker():
     try:
         import perth
@@ -107,15 +144,18 @@ def _watermarker():
 class _Base:
     sr = S3GEN_SR
 
-    def __init__(self, engine: ChatterboxEngine, tokenizer, device, conds: Optional[Conditionals] = None):
+    ENC_COND_LEN, DEC_COND_LEN = 6 * S3_SR, 10 * S3GEN_SR
+    PROMPT_LEN = 150  # T3Config.speech_cond_prompt_len
+
+    def __init__(self, engine: ChatterboxEngine, tokenizer, device, conds: Optional[Conditionals] = None, analyzer=None):
         self.engine, self.tokenizer, self.device, self.conds = engine, tokenizer, device, conds
-        self.t3, self.s3gen, self.ve = engine.t3, engine, None
+        self.analyzer = analyzer  # frontend.PromptAnalyzer (S3 tokenizer + CAMPPlus + voice encoder + 24 kHz mel) or None
+        self.t3, self.s3gen, self.ve = engine.t3, engine, (analyzer.ve if analyzer is not None else None)
         self.watermarker = _watermarker()
 
     def prepare_conditionals(self, wav_fpath, exaggeration=0.5):
-        raise NotImplementedError(
-            "voice-prompt analysis (S3 tokenizer + CAMPPlus x-vector + voice encoder, reference tts.py:182-206) is a "
-            "'next' row of this build (SURVEY.md 8f N1/N2): load a voice with Conditionals.load('conds.pt') instead")
+        """reference tts.py:182-206 / mtl_tts.py:253-277: waveform file -> self.conds."""
+        self.conds = _prepare_conditionals(self.analyzer, wav_fpath, exaggeration, self.PROMPT_LEN, self.device)
 
     def _finish(self, wav):
         wav = wav.detach().float().cpu()
@@ -144,7 +184,12 @@ class _Base:
                                device, n_t3_layers=t3_layers)
         c = synth.t3_cond()
         conds = Conditionals(T3Cond(**c), synth.s3gen_ref())
-        return cls(eng, None, device, conds)
+        analyzer = None
+        if kw.get("with_prompt_nets"):  # synthetic S3 tokenizer / CAMPPlus / voice encoder so that prepare_conditionals runs end to end
+            nl = kw.get("tokenizer_layers", 6)
+            analyzer = _make_analyzer(dict(synth.s3tokenizer_state_dict(seed, n_layer=nl), **synth.campplus_state_dict(seed)),
+                                      synth.voice_encoder_state_dict(seed), device)
+        return cls(eng, None, device, conds, analyzer)
 
 
 class ChatterboxTTS(_Base):
@@ -153,9 +198,11 @@ class ChatterboxTTS(_Base):
     @classmethod
     def from_local(cls, ckpt_dir, device):
         d = Path(ckpt_dir)
-        eng = ChatterboxEngine(_load_state(d / "t3_cfg.safetensors"), _load_state(d / "s3gen.safetensors"), device)
+        s3 = _load_state(d / "s3gen.safetensors")
+        eng = ChatterboxEngine(_load_state(d / "t3_cfg.safetensors"), s3, device)
         conds = Conditionals.load(d / "conds.pt") if (d / "conds.pt").exists() else None
-        return cls(eng, EnTokenizer(d / "tokenizer.json"), device, conds)
+        ve = _load_state(d / "ve.safetensors") if (d / "ve.safetensors").exists() else None
+        return cls(eng, EnTokenizer(d / "tokenizer.json"), device, conds, _make_analyzer(s3, ve, device))
 
     @classmethod
     def from_pretrained(cls, device):
@@ -187,9 +234,11 @@ class ChatterboxMultilingualTTS(_Base):
     def from_local(cls, ckpt_dir, device, t3_model=None):
         d = Path(ckpt_dir)
         t3_file = _resolve_multilingual_t3_model(t3_model)
-        eng = ChatterboxEngine(_load_state(d / t3_file), _load_state(d / "s3gen.pt"), device)
+        s3 = _load_state(d / "s3gen.pt")
+        eng = ChatterboxEngine(_load_state(d / t3_file), s3, device)
         conds = Conditionals.load(d / "conds.pt") if (d / "conds.pt").exists() else None
-        return cls(eng, MTLTokenizer(d / "grapheme_mtl_merged_expanded_v1.json"), device, conds)
+        ve = _load_state(d / "ve.pt") if (d / "ve.pt").exists() else None
+        return cls(eng, MTLTokenizer(d / "grapheme_mtl_merged_expanded_v1.json"), device, conds, _make_analyzer(s3, ve, device))
 
     @classmethod
     def from_pretrained(cls, device, t3_model=None):
@@ -218,9 +267,10 @@ class ChatterboxTurboTTS:
     """Reference tts_turbo.py:111-320: GPT2-medium (Turbo) or GPT2-small (Nano) T3, meanflow S3Gen, GPT-2 BPE tokenizer."""
     sr = S3GEN_SR
 
-    def __init__(self, engine, tokenizer, device, conds=None, model_label="Turbo"):
+    def __init__(self, engine, tokenizer, device, conds=None, model_label="Turbo", analyzer=None):
         self.engine, self.tokenizer, self.device, self.conds, self.model_label = engine, tokenizer, device, conds, model_label
-        self.t3, self.s3gen, self.ve = engine.t3, engine, None
+        self.analyzer = analyzer
+        self.t3, self.s3gen, self.ve = engine.t3, engine, (analyzer.ve if analyzer is not None else None)
         self.watermarker = _watermarker()
 
     @classmethod
@@ -228,13 +278,15 @@ class ChatterboxTurboTTS:
         d = Path(ckpt_dir)
         t3_sd = _load_state(d / ("t3_nano_v1.safetensors" if nano else "t3_turbo_v1.safetensors"))
         t3_sd.pop("tfmr.wte.weight", None)  # present in the file, unused (reference deletes it after loading, tts_turbo.py:167)
-        eng = TurboEngine(t3_sd, _load_state(d / "s3gen_meanflow.safetensors"), device)
+        s3 = _load_state(d / "s3gen_meanflow.safetensors")
+        eng = TurboEngine(t3_sd, s3, device)
+        ve = _load_state(d / "ve.safetensors") if (d / "ve.safetensors").exists() else None
         from transformers import AutoTokenizer
         tok = AutoTokenizer.from_pretrained(str(d))
         if tok.pad_token is None:
             tok.pad_token = tok.eos_token
         conds = Conditionals.load(d / "conds.pt") if (d / "conds.pt").exists() else None
-        return cls(eng, tok, device, conds, "Nano" if nano else "Turbo")
+        return cls(eng, tok, device, conds, "Nano" if nano else "Turbo", _make_analyzer(s3, ve, device))
 
     @classmethod
     def from_pretrained(cls, device, nano=False):
@@ -254,7 +306,9 @@ class ChatterboxTurboTTS:
                                                           emotion_adv=None), synth.s3gen_ref()), "Nano" if nano else "Turbo")
 
     def prepare_conditionals(self, wav_fpath, exaggeration=0.0, norm_loudness=True):
-        raise NotImplementedError("voice-prompt analysis is a 'next' row (SURVEY.md 8f N1/N2): load conds.pt instead")
+        """reference tts_turbo.py:241-270 (prompt > 5 s, optional loudness normalisation to -27 LUFS, 375 prompt tokens)."""
+        self.conds = _prepare_conditionals(self.analyzer, wav_fpath, exaggeration, 375, self.device, min_seconds=5.0,
+                                           norm_loudness=norm_loudness)
 
     def _generate(self, text_tokens, **samp):
         wavs, _ = self.engine.synthesize([text_tokens.view(-1).long().cpu()], self.conds.t3.as_dict(), self.conds.gen, **samp)
@@ -277,37 +331,69 @@ class ChatterboxTurboTTS:
 
 
 class ChatterboxVC:
-    """Voice conversion = S3 tokens of the source audio -> S3Gen with the target voice (reference vc.py:83-104).
-    The S3 tokenizer front-end is a 'next' row, so `generate` accepts the source as S3 tokens (config 5's parity
-    contract starts at the token boundary)."""
+    """Voice conversion (reference vc.py:16-104): S3 tokens of the source audio (S3 tokenizer on the device) -> S3Gen with the target
+    voice -> HiFT.  `generate` also accepts the source as S3 tokens (`s3_tokens=`): the parity contract of config 5 starts at the token
+    boundary because the tokenizer's arithmetic is third-party."""
     sr = S3GEN_SR
+    ENC_COND_LEN, DEC_COND_LEN = 6 * S3_SR, 10 * S3GEN_SR
 
-    def __init__(self, engine, device, ref_dict=None):
-        self.engine, self.device, self.ref_dict = engine, device, ref_dict
+    def __init__(self, engine, device, ref_dict=None, analyzer=None):
+        self.engine, self.device, self.ref_dict, self.analyzer = engine, device, ref_dict, analyzer
         self.s3gen = engine
         self.watermarker = _watermarker()
+
+    @staticmethod
+    def _engine(s3, device):
+        from .hift import HiFTEngine
+        from .s3gen import FlowEngine
+        eng = ChatterboxEngine.__new__(ChatterboxEngine)
+        eng.dev, eng.t3, eng.flow, eng.hift, eng.last_timing = torch.device(device), None, FlowEngine(s3, device), HiFTEngine(s3, device), {}
+        return eng
 
     @classmethod
     def from_local(cls, ckpt_dir, device):
         d = Path(ckpt_dir)
         s3 = _load_state(d / "s3gen.safetensors")
-        eng = ChatterboxEngine.__new__(ChatterboxEngine)
-        from .hift import HiFTEngine
-        from .s3gen import FlowEngine
-        eng.dev, eng.t3, eng.flow, eng.hift, eng.last_timing = torch.device(device), None, FlowEngine(s3, device), HiFTEngine(s3, device), {}
         ref = Conditionals.load(d / "conds.pt").gen if (d / "conds.pt").exists() else None
-        return cls(eng, device, ref)
+        return cls(cls._engine(s3, device), device, ref, _make_analyzer(s3, None, device))
+
+    @classmethod
+    def from_pretrained(cls, device):
+        """reference vc.py:61-74"""
+        from huggingface_hub import hf_hub_download
+        for f in ("s3gen.safetensors", "conds.pt"):
+            local = hf_hub_download(repo_id=REPO_ID, filename=f)
+        return cls.from_local(Path(local).parent, device)
+
+    @classmethod
+    def from_synthetic(cls, device="cuda", seed=0, tokenizer_layers=6):
+        s3 = dict(synth.s3gen_state_dict(seed), **synth.s3tokenizer_state_dict(seed, n_layer=tokenizer_layers), **synth.campplus_state_dict(seed))
+        return cls(cls._engine(s3, device), device, synth.s3gen_ref(), _make_analyzer(s3, None, device))
+
+    def _need_analyzer(self):
+        if self.analyzer is None or not self.analyzer.tokenizer.available or not self.analyzer.speaker_encoder.available:
+            raise RuntimeError("this S3Gen checkpoint carries no `tokenizer.*` / `speaker_encoder.*` tensors: pass s3_tokens= and a prepared "
+                               "ref_dict instead of waveforms")
 
     def set_target_voice(self, wav_fpath):
-        raise NotImplementedError("reference-voice analysis is a 'next' row (SURVEY.md 8f N2): pass a prepared ref_dict")
+        """reference vc.py:76-81"""
+        from . import frontend as fe
+        self._need_analyzer()
+        w24 = fe.resample(wav_fpath[0], wav_fpath[1], S3GEN_SR) if isinstance(wav_fpath, (tuple, list)) else fe.load_wav(wav_fpath, S3GEN_SR)[0]
+        self.ref_dict = self.analyzer.embed_ref(w24[: self.DEC_COND_LEN], S3GEN_SR)
 
     def generate(self, audio=None, target_voice_path=None, s3_tokens=None):
+        """reference vc.py:83-104.  audio: a WAV path or a (waveform, sample_rate) pair."""
         if target_voice_path:
             self.set_target_voice(target_voice_path)
-        assert self.ref_dict is not None, "Please `prepare_conditionals` first or specify `target_voice_path`"
+        else:
+            assert self.ref_dict is not None, "Please `prepare_conditionals` first or specify `target_voice_path`"
         if s3_tokens is None:
-            raise NotImplementedError("waveform -> S3 tokens (S3TokenizerV2) is a 'next' row (SURVEY.md 8f N1): pass s3_tokens=")
-        wavs, _ = self.engine.vocode([torch.as_tensor(s3_tokens).view(-1).long()], self.ref_dict)
+            from . import frontend as fe
+            self._need_analyzer()
+            w16 = fe.resample(audio[0], audio[1], S3_SR) if isinstance(audio, (tuple, list)) else fe.load_wav(audio, S3_SR)[0]
+            s3_tokens, _ = self.analyzer.tokenizer(torch.from_numpy(w16))
+        wavs, _ = self.engine.vocode([torch.as_tensor(s3_tokens).view(-1).long().cpu()], self.ref_dict)
         wav = wavs[0].detach().float().cpu()
         if self.watermarker is not None:
             wav = torch.from_numpy(self.watermarker.apply_watermark(wav.numpy(), sample_rate=self.sr))

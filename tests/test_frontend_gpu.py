@@ -85,6 +85,7 @@ def test_s3tokenizer_quantize_vs_oracle(dev):
     from chatterbox_amd.frontend import S3TokenizerEngine
     from oracle import ref_frontend as RF
     sd = synth.s3tokenizer_state_dict(0, n_layer=2)
+    digits = lambda t: torch.stack([(t // 3 ** d) % 3 for d in range(8)], -1)
     RF.S3TOK["n_layer"] = 2
     try:
         w16 = synth.prompt_wav(2.0, 16000)
@@ -92,17 +93,16 @@ def test_s3tokenizer_quantize_vs_oracle(dev):
         mel = eng.log_mel(w16)
         ids = eng.quantize(mel).cpu()
         oid, hq = RF.s3tokenizer_quantize(sd, RF.s3_log_mel(w16))
+        tok, n = eng(w16, max_len=20)                    # S3Tokenizer.forward(max_len): the mel is cut to 4 * max_len frames first
+        otok = RF.s3_tokenize(sd, w16, max_len=20)
     finally:
         RF.S3TOK["n_layer"] = 6
     assert ids.shape == oid.shape == (mel.shape[0] // 4,) and int(ids.min()) >= 0 and int(ids.max()) < 6561
-    # digits may differ only where the oracle's pre-rounding value sits on a rounding boundary
-    with torch.inference_mode():
-        x = sd["tokenizer.quantizer._codebook.project_down.weight"]
-    digits = lambda t: torch.stack([(t // 3 ** d) % 3 for d in range(8)], -1)
+    # FSQ digits may differ only where the pre-rounding value sits on a rounding boundary (fp32 accumulation order)
     diff = digits(ids) != digits(oid)
     assert diff.float().mean() <= 0.02, f"{int(diff.sum())} of {diff.numel()} FSQ digits differ from the restatement"
-    tok, n = eng(w16, max_len=20)
-    assert tok.shape == (1, 20) and int(n[0]) == 20 and tok[0].tolist() == ids[:20].tolist()
+    assert tok.shape == (1, 20) and int(n[0]) == 20
+    assert (digits(tok[0].cpu()) != digits(otok)).float().mean() <= 0.02
 
 
 def test_embed_ref_shapes_and_contract(dev):
@@ -118,3 +118,27 @@ def test_embed_ref_shapes_and_contract(dev):
     assert n == 100 and ref["prompt_feat_len"] is None
     spk, ptoks = pa.t3_prompt(synth.prompt_wav(4.0, 16000).numpy(), 150)
     assert spk.shape == (1, 256) and ptoks.shape == (1, 100) and abs(float(spk.norm()) - 1.0) < 1e-3
+
+
+def test_prepare_conditionals_and_vc_end_to_end(dev, tmp_path):
+    """The reference's example flows on synthetic weights: `generate(audio_prompt_path=...)` (tts.py:208-272 -> prepare_conditionals)
+    and `ChatterboxVC.generate(audio, target_voice_path=...)` (vc.py:83-104), from WAV files on disk to a 24 kHz waveform."""
+    from scipy.io import wavfile
+    from chatterbox_amd import synth
+    from chatterbox_amd.api import ChatterboxMultilingualTTS, ChatterboxVC
+    prompt, source = tmp_path / "prompt.wav", tmp_path / "source.wav"
+    wavfile.write(prompt, 22050, (synth.prompt_wav(6.5, 22050).numpy() * 32767).astype(np.int16))  # an odd rate: exercises resampling
+    wavfile.write(source, 16000, synth.prompt_wav(2.0, 16000, seed=3).numpy())
+    m = ChatterboxMultilingualTTS.from_synthetic(dev, t3_layers=2, with_prompt_nets=True, tokenizer_layers=1)
+    m.prepare_conditionals(str(prompt), exaggeration=0.7)
+    c = m.conds
+    assert c.t3.speaker_emb.shape == (1, 256) and c.t3.cond_prompt_speech_tokens.shape == (1, 150) and float(c.t3.emotion_adv) == pytest.approx(0.7)
+    n = c.gen["prompt_token"].shape[1]
+    assert c.gen["prompt_feat"].shape == (1, 2 * n, 80) and c.gen["embedding"].shape == (1, 192) and n == 162  # 6.5 s * 25 tokens/s
+    wav = m._generate(synth.text_tokens(10)[1:-1], drop_last_token=True, temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+    assert wav.dim() == 2 and wav.shape[0] == 1 and torch.isfinite(wav).all()
+    vc = ChatterboxVC.from_synthetic(dev, tokenizer_layers=1)
+    out = vc.generate(str(source), target_voice_path=str(prompt))
+    assert out.shape == (1, 50 * 960) and torch.isfinite(out).all() and out.abs().max() <= 0.99  # 2 s -> 50 tokens -> 48000 samples
+    out2 = vc.generate(s3_tokens=synth.speech_tokens(30))
+    assert out2.shape == (1, 30 * 960)

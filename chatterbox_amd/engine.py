@@ -56,7 +56,8 @@ class ChatterboxEngine:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         same = all(n == Nmax for n in ns)
-        mel_lens = None if same else (2 * lens).to(self.dev)
+        short = 2 * Nmax - mel.shape[1]  # > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195)
+        mel_lens = None if same else (2 * lens - short).to(self.dev)
         wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
         if sync:
             torch.cuda.synchronize()
@@ -65,7 +66,7 @@ class ChatterboxEngine:
         out = []
         for b, n in enumerate(ns):
             keep = max(1, n - 1) if drop_last_token else n
-            out.append(wav[b, : keep * SAMPLES_PER_TOKEN])
+            out.append(wav[b, : min(keep * SAMPLES_PER_TOKEN, (2 * n - short) * (SAMPLES_PER_TOKEN // 2))])
         return out, mel
 
     @ops.on_device

@@ -311,7 +311,8 @@ class FlowEngine:
 
     def _inference(self, tokens, token_lens, ref, z=None, n_steps=10):
         """tokens (B,N) int64 (right-padded), token_lens (B,), ref dict as produced by S3Gen.embed_ref, z optional
-        injected noise (B, 2P+2N, 80) channel-last.  Returns mel (B, 2N, 80) channel-last (frames >= 2*len undefined)."""
+        injected noise (B, 2P+2N, 80) channel-last.  Returns mel (B, 2(P+N) - prompt_feat frames, 80) channel-last: (B, 2N, 80) for a
+        whole-token prompt (frames >= 2*len undefined)."""
         dev = self.dev
         B, N = tokens.shape
         ptok = ref["prompt_token"].to(dev).long().view(1, -1)
@@ -323,9 +324,13 @@ class FlowEngine:
         emb = torch.nn.functional.normalize(ref["embedding"].to(dev).float().view(1, -1), dim=1)
         spk = torch.empty(1, 80, device=dev)
         ops.linear(emb.contiguous(), self.spk_w, spk, bias=self.spk_b)
+        # mel_len1 = prompt_feat.shape[1] (flow.py:170-175): normally 2P; one frame more when the prompt is not a whole number of
+        # 40 ms tokens (embed_ref trims the tokens, not the mel, s3gen.py:152-158) -- the output then has 2N - (mel_len1 - 2P) frames
+        pf = ref["prompt_feat"].to(dev).float().view(1, -1, 80)
+        Pm = pf.shape[1]
         cond = torch.zeros(B, T, 80, device=dev)
-        cond[:, : 2 * P] = ref["prompt_feat"].to(dev).float().view(1, 2 * P, 80)
+        cond[:, :Pm] = pf
         if z is None:
             z = torch.randn(B, T, 80, device=dev)
         x = self.cfm(mu, (2 * lens).to(torch.int32), spk.expand(B, -1), cond, z.to(dev), n_steps)
-        return x[:, 2 * P:, :].contiguous()
+        return x[:, Pm:, :].contiguous()

@@ -106,3 +106,46 @@ def test_meanflow_oracle_matches_reference():
     with torch.inference_mode():
         mel = O.flow_inference(sd, synth.speech_tokens(N, seed=1)[None], torch.tensor([N]), synth.s3gen_ref(n_prompt_tokens=P), z, 2, meanflow=True)
     assert (mel[0] - torch.from_numpy(g["mel"])).abs().mean() < 1e-5
+
+
+def test_frontend_oracle_vs_reference_golden():
+    """oracle/ref_frontend.py against golden vectors of the UNMODIFIED reference (tests/golden/make_golden_frontend.py): S3 log-mel,
+    24 kHz prompt mel, CAMPPlus body, voice-encoder LSTM body.  (S3TokenizerV2.quantize / Kaldi fbank are third-party: unpinned.)"""
+    import numpy as np
+    from chatterbox_amd import synth
+    from oracle import ref_frontend as RF
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend.npz"))
+    w16, w24 = synth.prompt_wav(3.0, 16000), synth.prompt_wav(3.0, 24000)
+    assert (RF.s3_log_mel(w16) - torch.from_numpy(g["s3_logmel"])).abs().max() <= 1e-5
+    assert (RF.mel_spectrogram_24k(w24)[0] - torch.from_numpy(g["mel24k"])).abs().max() <= 1e-5
+    fb = RF.kaldi_fbank(w16)
+    fb = fb - fb.mean(0, keepdim=True)
+    assert (fb - torch.from_numpy(g["fbank"])).abs().max() <= 1e-4  # the stored features ARE this restatement (regression guard)
+    xv = RF.campplus_forward(synth.campplus_state_dict(0, prefix=""), torch.from_numpy(g["fbank"])[None])[0]
+    assert (xv - torch.from_numpy(g["xvector"])).abs().max() <= 1e-4
+    emb = RF.ve_inference(synth.voice_encoder_state_dict(0), torch.from_numpy(g["ve_mel"]))
+    assert (emb - torch.from_numpy(g["ve_embed"])).abs().max() <= 1e-5
+
+
+def test_frontend_host_signal_conditioning(tmp_path):
+    """CPU-side pieces of the prompt path (the reference also runs them on the CPU): WAV decoding, resampling, silence trimming, the
+    voice encoder's partial-utterance arithmetic."""
+    import numpy as np
+    from scipy.io import wavfile
+    from chatterbox_amd import frontend as fe, synth
+    from oracle import ref_frontend as RF
+    w = synth.prompt_wav(1.0, 22050).numpy()
+    wavfile.write(tmp_path / "a.wav", 22050, (w * 32767).astype(np.int16))
+    y, sr = fe.load_wav(tmp_path / "a.wav", 16000)
+    assert sr == 16000 and abs(len(y) - 16000) <= 1 and np.abs(y).max() <= 1.0
+    # a pure tone keeps its frequency and amplitude through the resampler
+    t = np.arange(24000) / 24000.0
+    tone = fe.resample(0.5 * np.sin(2 * np.pi * 440 * t).astype(np.float32), 24000, 16000)
+    spec = np.abs(np.fft.rfft(tone[2000:10000] * np.hanning(8000)))
+    assert abs(np.argmax(spec) * 16000 / 8000 - 440) <= 2.0 and abs(np.abs(tone[2000:10000]).max() - 0.5) < 5e-3
+    padded = np.concatenate([np.zeros(8000, np.float32), w[:8000], np.zeros(6000, np.float32)])
+    tr = fe.trim_silence(padded, 20.0)
+    assert 7000 <= len(tr) <= 10000 and np.array_equal(tr, RF.trim_silence(padded, 20.0))
+    assert fe.VoiceEncoderEngine.frame_step(0.5, 1.3) == RF.ve_frame_step(0.5, 1.3) == 77
+    for n in (1, 159, 160, 161, 301, 1001):
+        assert fe.VoiceEncoderEngine.num_wins(n, 77) == RF.ve_num_wins(n, 77)

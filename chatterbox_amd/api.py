@@ -77,10 +77,16 @@ class Conditionals:
         return self
 
     def save(self, fpath):
+        if str(fpath).endswith(".safetensors"):  # pickle-free container (formats.py); conds.pt stays the reference's torch pickle
+            from . import formats
+            return formats.save_conds(self, fpath)
         torch.save(dict(t3=self.t3.__dict__, gen=self.gen), fpath)
 
     @classmethod
     def load(cls, fpath, map_location="cpu"):
+        if str(fpath).endswith(".safetensors"):
+            from . import formats
+            return formats.load_conds(fpath, map_location)
         kw = torch.load(fpath, map_location=torch.device(map_location) if isinstance(map_location, str) else map_location,
                         weights_only=True)
         return cls(T3Cond(**kw["t3"]), kw["gen"])
@@ -89,8 +95,8 @@ class Conditionals:
 def _load_state(path):
     path = str(path)
     if path.endswith(".safetensors"):
-        from safetensors.torch import load_file
-        sd = load_file(path)
+        from .formats import read_safetensors
+        sd = read_safetensors(path)  # zero-copy views of one memory map (no host copy before the H2D transfer)
     else:
         sd = torch.load(path, map_location="cpu", weights_only=True)
     if "model" in sd and not torch.is_tensor(sd["model"]):  # `{"model": [state]}` wrapper (reference tts.py:146-147)

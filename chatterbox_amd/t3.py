@@ -39,6 +39,8 @@ def llama3_rope_tables(max_pos, head_dim=64, theta=500000.0, factor=8.0, low=1.0
 class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
+    # decode launch geometry: waves per 16-column tile (nw) / cross-workgroup K splits; *2 = the packed-operand (v2) path
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):
@@ -88,7 +90,42 @@ class T3Engine:
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
-        self.tune = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8)
+        self.tune = dict(self._TUNE)
+
+    # ------------------------------------------------------------------ packed device layout <-> disk (formats.save_packed / load_packed)
+    _PLAIN = ("norm", "text_emb", "speech_emb", "text_pos", "speech_pos", "head", "head_pk", "spkr_w", "spkr_b", "emo_w", "pq", "cos", "sin")
+    _PAIRS = ("p_ln", "p_q", "p_kv", "p_out")
+
+    def export_packed(self):
+        """Every tensor this engine holds after load-time packing, under flat stable names."""
+        t = {f"layers.{i}.{k}": v for i, lw in enumerate(self.layers) for k, v in lw.items()}
+        t.update({k: getattr(self, k) for k in self._PLAIN if getattr(self, k) is not None})
+        for k in self._PAIRS:
+            t[k + ".0"], t[k + ".1"] = getattr(self, k)
+        return t
+
+    @classmethod
+    def from_packed(cls, t, device="cuda", max_pos=4608):
+        """Rebuild the engine from `export_packed()` tensors (e.g. memory-mapped by formats.load_packed): no re-packing, one H2D copy each."""
+        self = cls.__new__(cls)
+        self.dev = torch.device(device)
+        d = lambda v: v.to(self.dev) if v.device != self.dev else v
+        n = 0
+        while f"layers.{n}.ln1" in t:
+            n += 1
+        self.L = n
+        self.layers = [{k.split(".", 2)[2]: d(v) for k, v in t.items() if k.startswith(f"layers.{i}.")} for i in range(n)]
+        for k in self._PLAIN:
+            setattr(self, k, d(t[k]) if k in t else None)
+        for k in self._PAIRS:
+            setattr(self, k, (d(t[k + ".0"]), d(t[k + ".1"])))
+        self.V = self.head.shape[0]
+        self.decode_mode = "v2" if self.head_pk is not None else "v1"
+        self.max_pos = self.cos.shape[0]
+        self._state = {}
+        self.time_decode, self.decode_events = False, []
+        self.tune = dict(cls._TUNE)
+        return self
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):

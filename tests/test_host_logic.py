@@ -199,3 +199,30 @@ def test_bench_roofline_assembly_is_pure_and_consistent():
     assert r1["flash_attn_f32"]["peak"] == bench.MFMA_F32_PEAK_TFLOPS and "fp32_equivalent_tflops" not in r1["flash_attn_f32"]
     tr, src = bench.pmc_traffic("gemm_split_kernel")
     assert tr is None or (tr > 1e6 and "profiles/" in src)
+
+
+def test_safetensors_reader_writer_and_conds_container(tmp_path):
+    """formats.py: the container parser interoperates with the `safetensors` package both ways; voices round-trip without pickle."""
+    from safetensors.torch import load_file, save_file
+    from chatterbox_amd import formats
+    from chatterbox_amd.api import Conditionals, T3Cond
+    g = torch.Generator().manual_seed(0)
+    sd = {"a.weight": torch.randn(7, 5, generator=g), "b": torch.randint(0, 100, (3,), generator=g), "c.half": torch.randn(4, generator=g).half(),
+          "d.bf16": torch.randn(6, generator=g).bfloat16(), "e.empty": torch.zeros(0, 3), "f.u8": torch.arange(5, dtype=torch.uint8)}
+    save_file(sd, str(tmp_path / "ref.safetensors"), metadata={"k": "v"})
+    got, meta = formats.read_safetensors(tmp_path / "ref.safetensors", with_metadata=True)
+    assert meta == {"k": "v"} and set(got) == set(sd) and all(torch.equal(got[k], sd[k]) and got[k].dtype == sd[k].dtype for k in sd)
+    formats.write_safetensors(sd, tmp_path / "ours.safetensors", metadata={"x": 1})
+    back = load_file(str(tmp_path / "ours.safetensors"))
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    c = Conditionals(T3Cond(**synth.t3_cond()), synth.s3gen_ref())
+    c.save(tmp_path / "voice.safetensors")
+    d = Conditionals.load(tmp_path / "voice.safetensors")
+    assert torch.equal(d.t3.speaker_emb, c.t3.speaker_emb) and torch.equal(d.t3.cond_prompt_speech_tokens, c.t3.cond_prompt_speech_tokens)
+    assert d.t3.cond_prompt_speech_tokens.dtype == torch.int64 and torch.equal(d.gen["prompt_feat"], c.gen["prompt_feat"])
+    assert d.gen["prompt_feat_len"] is None and d.t3.clap_emb is None and float(d.t3.emotion_adv) == 0.5
+    fp1, fp2 = formats.fingerprint(sd), formats.fingerprint({**sd, "a.weight": sd["a.weight"] + 1})
+    assert fp1 != fp2 and fp1 == formats.fingerprint(dict(reversed(list(sd.items()))))
+    formats.save_packed({"x": torch.ones(3)}, tmp_path / "p.cbxpack", fp1, "kind-a")
+    assert formats.load_packed(tmp_path / "p.cbxpack", fp1, "kind-a") is not None
+    assert formats.load_packed(tmp_path / "p.cbxpack", fp2, "kind-a") is None and formats.load_packed(tmp_path / "p.cbxpack", fp1, "kind-b") is None

@@ -37,7 +37,7 @@ for name, m, n, k, taps in shapes:
             for _ in range(3): run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 100
+            reps = int(os.environ.get('CBX_REPS', '100'))
             e0.record()
             for _ in range(reps): run()
             e1.record(); torch.cuda.synchronize()

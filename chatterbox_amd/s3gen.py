@@ -107,18 +107,22 @@ class FlowEngine:
         self.fin = dict(c=(d(weights.pack_conv(sd[q + "final_block.block.0.weight"])), d(sd[q + "final_block.block.0.bias"])),
                         n=(d(sd[q + "final_block.block.2.weight"]), d(sd[q + "final_block.block.2.bias"])),
                         proj=(d(weights.pack_conv(sd[q + "final_proj.weight"])), d(sd[q + "final_proj.bias"])))
-        self._graphs = {}
+        self._pe_cache, self._tb_cache = {}, {}  # device-resident constants: rel-pos tables per length, time biases per schedule
 
     # ------------------------------------------------------------------ conformer encoder
-    @staticmethod
-    def _rel_pos_table(T, dev, dm=512):
-        """EspnetRelPositionalEncoding (transformer/embedding.py:224-294): row r <-> relative position T-1-r."""
-        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
-        div = torch.exp(torch.arange(0, dm, 2, dtype=torch.float32) * -(math.log(10000.0) / dm))
-        pe = torch.zeros(2 * T - 1, dm)
-        pe[:, 0::2] = torch.sin(pos * div)
-        pe[:, 1::2] = torch.cos(pos * div)
-        return pe.to(dev)
+    def _rel_pos_table(self, T, dev=None, dm=512):
+        """EspnetRelPositionalEncoding (transformer/embedding.py:224-294): row r <-> relative position T-1-r.  A constant of the
+        length: built once and kept on the device (like the RoPE tables), not rebuilt and re-uploaded per call."""
+        if T not in self._pe_cache:
+            pos = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
+            div = torch.exp(torch.arange(0, dm, 2, dtype=torch.float32) * -(math.log(10000.0) / dm))
+            pe = torch.zeros(2 * T - 1, dm)
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            if len(self._pe_cache) >= 16:
+                self._pe_cache.pop(next(iter(self._pe_cache)))
+            self._pe_cache[T] = pe.to(self.dev)
+        return self._pe_cache[T]
 
     def _conformer(self, lw, x, B, T, pe, lens, ws):
         """ConformerEncoderLayer.forward + RelPositionMultiHeadedAttention (encoder_layer.py:160-236, attention.py:249-330)."""
@@ -296,7 +300,9 @@ class FlowEngine:
         t_span = torch.linspace(0, 1, n_steps + 1)
         if not self.meanflow:
             t_span = 1 - torch.cos(t_span * 0.5 * math.pi)
-        tb = self._time_bias(t_span[:-1], t_span[1:] if self.meanflow else None)
+        if n_steps not in self._tb_cache:  # the schedule is a function of n_steps only: every ResNet's time bias is a load-time constant
+            self._tb_cache[n_steps] = self._time_bias(t_span[:-1], t_span[1:] if self.meanflow else None)
+        tb = self._tb_cache[n_steps]
         for k in range(n_steps):
             v = self._estimator(xin, rows, T, lens_r, tb[k], ws)
             ops.cfm_euler(xin, v, B, T, 80, float(t_span[k + 1] - t_span[k]), cfg_rate, cfg=cfg)
@@ -321,9 +327,11 @@ class FlowEngine:
         lens = (token_lens.to(dev).to(torch.int32) + P).contiguous()
         mu = self.encode(tok, lens)
         T = mu.shape[1]
-        emb = torch.nn.functional.normalize(ref["embedding"].to(dev).float().view(1, -1), dim=1)
+        xv = ref["embedding"].to(dev).float().view(1, -1).contiguous()
+        emb = torch.empty_like(xv)  # F.normalize(embedding, dim=1) (flow.py:150): x / ||x|| = rmsnorm(x) / sqrt(C)
+        ops.layernorm(xv, torch.ones(xv.shape[1], device=dev), None, emb, 0.0, rms=True, scale=1.0 / math.sqrt(xv.shape[1]))
         spk = torch.empty(1, 80, device=dev)
-        ops.linear(emb.contiguous(), self.spk_w, spk, bias=self.spk_b)
+        ops.linear(emb, self.spk_w, spk, bias=self.spk_b)
         # mel_len1 = prompt_feat.shape[1] (flow.py:170-175): normally 2P; one frame more when the prompt is not a whole number of
         # 40 ms tokens (embed_ref trims the tokens, not the mel, s3gen.py:152-158) -- the output then has 2N - (mel_len1 - 2P) frames
         pf = ref["prompt_feat"].to(dev).float().view(1, -1, 80)

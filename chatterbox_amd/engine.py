@@ -146,7 +146,92 @@ class ChatterboxEngine:
                 pending = (jobs[k], st, t_start)
 
 
+def _stream_plan(n_tokens, done, exhausted, lookahead):
+    """Per utterance: (final?, mel frames to hold back).  An utterance is final once its EOS was sampled or the step budget is spent;
+    until then the encoder's `lookahead` tokens (2 mel frames each) are not vocoded yet."""
+    fin = [bool(d) or exhausted for d in done]
+    return fin, [0 if f else 2 * lookahead for f in fin]
+
+
+def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, chunk=50, lookahead=3, fade=480, max_new_tokens=1000,
+                      temperature=0.8, top_p=1.0, min_p=0.05, repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False,
+                      ban_from=0, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=True):
+    """Chunked synthesis: first audio after `first_chunk` tokens instead of after the whole utterance.
+
+    The reference is non-streaming; of its vestigial hooks only HiFT's `cache_source` works (hifigan.py:470-472) -- `finalize=False`
+    (flow.py:170-171) raises a shape error there -- so the schedule is this build's own, with its own oracle
+    (tests/test_stream_gpu.py restates it on the CPU oracle):
+      * T3 decodes `first_chunk + lookahead` tokens, then `chunk` more per round (graph replays of the same captured step);
+      * every round re-runs encoder + CFM over ALL tokens so far with the same noise realisation, masking the last
+        2 * lookahead mel frames of unfinished utterances (the encoder looks 3 tokens ahead), and HiFT with the previous round's source
+        as `cache_source` (phase-continuous excitation);
+      * new samples are emitted up to `fade` samples before the end of what the round could vocode; that tail is cross-faded
+        (raised-cosine-free linear ramp) with the next round's re-synthesis of the same samples.
+    The last round is a full synthesis: identical mel to synthesize() for the same noise.  Yields dicts
+    {wavs: [B CPU tensors of NEW samples], final: [B bools], n_tokens: [B]}; concatenating an utterance's pieces gives its waveform."""
+    torch.cuda.set_device(self.dev)
+    dev, B = self.dev, len(text_tokens)
+    P = gen_ref["prompt_token"].shape[-1]
+    N = max_new_tokens
+    assert gen_ref["prompt_feat"].shape[-2] == 2 * P, "chunked synthesis needs a whole-token prompt (embed_ref output trimmed to 2 frames per token)"
+    if z is None:
+        z = torch.randn(B, 2 * (P + N), 80, device=dev)
+    if phase is None:
+        phase = (torch.rand(B, 9, device=dev) * 2 - 1) * 3.141592653589793
+        phase[:, 0] = 0
+    if noise is None:
+        noise = torch.randn(B, 9, SAMPLES_PER_TOKEN * N, device=dev)
+    z, phase, noise = z.to(dev), phase.to(dev).reshape(B, 9), noise.to(dev)
+    h = self.t3.generate(t3_conds, text_tokens, max_new_tokens=N, temperature=temperature, top_p=top_p, min_p=min_p,
+                         repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms, ban_eos=ban_eos, ban_from=ban_from,
+                         async_mode=True, run_steps=first_chunk + lookahead)
+    emitted, tails, closed, src_cache = [0] * B, [None] * B, [False] * B, None
+    ramp = torch.linspace(0.0, 1.0, fade + 2, device=dev)[1:-1]
+    while True:
+        toks, done = self.t3.peek(h)
+        exhausted = h["next_i"] >= h["max_new_tokens"]
+        fin, hold = _stream_plan([t.numel() for t in toks], done, exhausted, lookahead)
+        st = [drop_invalid_tokens(t) for t in toks]
+        st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
+        ns = [int(t.numel()) for t in st]
+        Nk = max(ns)
+        frames = [max(0, 2 * n - hb) for n, hb in zip(ns, hold)]
+        out = [torch.zeros(0)] * B
+        if max(frames) > 0:
+            tok = torch.zeros(B, Nk, dtype=torch.long)
+            for b, t in enumerate(st):
+                tok[b, : ns[b]] = t
+            mel = self.flow.inference(tok.to(dev), torch.tensor(ns, dtype=torch.int32, device=dev), gen_ref, z=z[:, : 2 * (P + Nk)],
+                                      n_steps=n_cfm_timesteps, hold_back=hold)
+            fl = torch.tensor(frames, dtype=torch.int32, device=dev)
+            wav, src = self.hift.inference(mel, phase=phase, noise=noise[:, :, : 480 * mel.shape[1]], lens=fl, fade=True, cache_source=src_cache)
+            src_cache = src[:, : 480 * min(frames)].clone() if min(frames) > 0 else None
+            for b in range(B):
+                if closed[b]:
+                    continue
+                avail = 480 * frames[b]
+                if fin[b]:
+                    keep = max(1, ns[b] - 1) if drop_last_token else ns[b]
+                    avail = min(avail, keep * SAMPLES_PER_TOKEN)
+                end = avail if fin[b] else max(emitted[b], avail - fade)
+                new = wav[b, emitted[b]: end].clone()
+                if tails[b] is not None and new.numel() > 0:
+                    k = min(tails[b].numel(), new.numel())
+                    new[:k] = tails[b][:k] * (1.0 - ramp[:k]) + new[:k] * ramp[:k]
+                tails[b] = None if fin[b] else wav[b, end: min(avail, end + fade)].clone()
+                emitted[b] = end
+                closed[b] = fin[b]
+                out[b] = new.cpu()
+        yield dict(wavs=out, final=list(fin), n_tokens=ns)
+        if all(closed) or exhausted:
+            return
+        self.t3.advance(h, chunk)
+
+
 S3GEN_SIL = 4299  # reference models/s3gen/const.py:2
+
+
+ChatterboxEngine.synthesize_stream = torch.inference_mode()(synthesize_stream)
 
 
 class TurboEngine:

@@ -157,8 +157,9 @@ class HiFTEngine:
 
     @ops.on_device
     @torch.inference_mode()
-    def inference(self, mel, phase=None, noise=None, lens=None, fade=True):
-        """HiFTGenerator.inference + S3Gen trim_fade.  mel (B,T,80) channel-last.  Returns (wav (B,480T), source (B,480T))."""
+    def inference(self, mel, phase=None, noise=None, lens=None, fade=True, cache_source=None):
+        """HiFTGenerator.inference + S3Gen trim_fade.  mel (B,T,80) channel-last.  Returns (wav (B,480T), source (B,480T)).
+        cache_source (B, L): the source of an earlier chunk replaces the first L samples (hifigan.py:470-472)."""
         B, T, _ = mel.shape
         if phase is None:
             phase = (torch.rand(B, 9, device=self.dev) * 2 - 1) * 3.141592653589793
@@ -168,5 +169,7 @@ class HiFTEngine:
         with ops.gemm_precision(1):
             f0 = self.f0_predict(mel, lens)
         s = self.source(f0, phase.to(self.dev).float(), noise.to(self.dev).float())
+        if cache_source is not None and cache_source.shape[1]:
+            s[:, : cache_source.shape[1]] = cache_source.to(self.dev)
         with ops.gemm_precision(self.precision):
             return self.decode(mel, s, lens, fade), s

@@ -311,14 +311,15 @@ class FlowEngine:
     # ------------------------------------------------------------------ flow.inference
     @ops.on_device
     @torch.inference_mode()
-    def inference(self, tokens, token_lens, ref, z=None, n_steps=10):
+    def inference(self, tokens, token_lens, ref, z=None, n_steps=10, hold_back=None):
         with ops.gemm_precision(self.precision):
-            return self._inference(tokens, token_lens, ref, z, n_steps)
+            return self._inference(tokens, token_lens, ref, z, n_steps, hold_back)
 
-    def _inference(self, tokens, token_lens, ref, z=None, n_steps=10):
+    def _inference(self, tokens, token_lens, ref, z=None, n_steps=10, hold_back=None):
         """tokens (B,N) int64 (right-padded), token_lens (B,), ref dict as produced by S3Gen.embed_ref, z optional
         injected noise (B, 2P+2N, 80) channel-last.  Returns mel (B, 2(P+N) - prompt_feat frames, 80) channel-last: (B, 2N, 80) for a
-        whole-token prompt (frames >= 2*len undefined)."""
+        whole-token prompt (frames >= 2*len undefined).  hold_back (B,) ints: chunked synthesis -- the last hold_back[b] frames of
+        utterance b are not generated (`finalize=False` of flow.py:170-171, whose reference branch raises; semantics restated)."""
         dev = self.dev
         B, N = tokens.shape
         ptok = ref["prompt_token"].to(dev).long().view(1, -1)
@@ -340,5 +341,8 @@ class FlowEngine:
         cond[:, :Pm] = pf
         if z is None:
             z = torch.randn(B, T, 80, device=dev)
-        x = self.cfm(mu, (2 * lens).to(torch.int32), spk.expand(B, -1), cond, z.to(dev), n_steps)
+        mel_lens = (2 * lens).to(torch.int32)
+        if hold_back is not None:  # chunked synthesis: the encoder's 3-token lookahead frames are masked out of the CFM like padding
+            mel_lens = (mel_lens - torch.as_tensor(hold_back, dtype=torch.int32).to(dev)).contiguous()
+        x = self.cfm(mu, mel_lens, spk.expand(B, -1), cond, z.to(dev), n_steps)
         return x[:, Pm:, :].contiguous()

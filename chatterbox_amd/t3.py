@@ -274,6 +274,29 @@ class T3Engine:
         return st
 
     @ops.on_device
+    def advance(self, handle, n_steps):
+        """Enqueue up to `n_steps` further decode steps of an async generate() (replays of its captured graph; finished utterances are
+        no-ops inside the sampler).  Returns the number of steps enqueued."""
+        st = handle["st"]
+        n = max(0, min(int(n_steps), handle["max_new_tokens"] - handle["next_i"]))
+        for _ in range(n):
+            if st["graph"] is not None:
+                st["graph"].replay()
+            else:
+                self._decode_step(st)
+        handle["next_i"] += n
+        return n
+
+    @ops.on_device
+    def peek(self, handle):
+        """Tokens sampled so far (synchronises with the launch stream): (list of B 1-D LongTensors, list of B done flags)."""
+        st, B = handle["st"], handle["B"]
+        n = st["n_generated"].tolist()
+        done = st["done"].tolist()
+        toks = st["out_tokens"].cpu()
+        return [toks[b, : n[b]].clone() for b in range(B)], [bool(d) for d in done]
+
+    @ops.on_device
     def collect(self, handle):
         """Fetch the tokens of an (async) generate() call.  Must run on the stream the call was enqueued on."""
         st, B = handle["st"], handle["B"]
@@ -286,10 +309,12 @@ class T3Engine:
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_new_tokens=1000, temperature=0.8, top_p=1.0, min_p=0.05,
                  repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, use_graph=True, poll_every=16,
-                 return_prefill_logits=False, debug_logits=False, async_mode=False, slot=0):
+                 return_prefill_logits=False, debug_logits=False, async_mode=False, slot=0, run_steps=None):
         """conds: one T3 cond dict (shared voice) or a list of B; text_tokens: list of B 1-D LongTensors that already
         carry SOT/EOT (mtl_tts.py:319-322).  Returns a list of B 1-D LongTensors (EOS included if it was sampled).
-        `slot` selects an independent set of workspaces / KV cache / decode graph (pipelined serving keeps two alive)."""
+        `slot` selects an independent set of workspaces / KV cache / decode graph (pipelined serving keeps two alive).
+        Chunked use (streaming synthesis): `async_mode=True, run_steps=k` samples only the first k tokens and returns a handle;
+        `advance(handle, n)` enqueues n more decode steps and `peek(handle)` fetches the tokens sampled so far."""
         dev, B = self.dev, len(text_tokens)
         assert B >= 1, "empty batch"
         if uniforms is not None:
@@ -377,7 +402,8 @@ class T3Engine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         n_replays = 0
-        for i in range(1, max_new_tokens):
+        last = max_new_tokens if run_steps is None else max(1, min(max_new_tokens, int(run_steps)))
+        for i in range(1, last):
             n_replays += 1
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
@@ -393,7 +419,7 @@ class T3Engine:
             ev[1].record()
             self.decode_events.append((ev[0], ev[1], n_replays, list(s0), rows))
         if async_mode:  # everything is enqueued on the current stream; no host synchronisation happened
-            return dict(st=st, B=B)
+            return dict(st=st, B=B, next_i=last, max_new_tokens=max_new_tokens)
         out = self.collect(dict(st=st, B=B))
         if debug_logits:
             return out, torch.stack(step_logits)  # (steps, 2B, V)

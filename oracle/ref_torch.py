@@ -368,10 +368,13 @@ def cfm_solve(sd, z, mu, mask, spks, cond, n_timesteps=10, cfg_rate=0.7, meanflo
     return x
 
 
-def flow_inference(sd, tokens, token_lens, ref, z, n_timesteps=10, meanflow=False):
+def flow_inference(sd, tokens, token_lens, ref, z, n_timesteps=10, meanflow=False, hold_back=None):
     """CausalMaskedDiffWithXvec.inference (flow.py:131-198), finalize=True.  tokens (B,N) padded, token_lens (B,);
     ref: dict prompt_token (1,P), prompt_feat (1,2P,80), embedding (1,192); z (B,80,2P+2N) injected noise.
-    Returns mel (B,80,2N) (padded region beyond 2*token_lens[b] is not meaningful)."""
+    Returns mel (B,80,2N) (padded region beyond 2*token_lens[b] is not meaningful).
+    hold_back (B,) int or None: chunked synthesis -- the last hold_back[b] mel frames of utterance b (the encoder's 3-token lookahead,
+    flow.py:170-171 `finalize=False`; that branch of the reference raises a shape error, so the semantics are restated here: the
+    frames are masked out of the CFM exactly like padding) are not generated."""
     B = tokens.shape[0]
     emb = F.normalize(ref["embedding"].float().view(1, -1), dim=1)
     spk = F.linear(emb, sd["flow.spk_embed_affine_layer.weight"], sd["flow.spk_embed_affine_layer.bias"]).expand(B, -1)
@@ -386,6 +389,9 @@ def flow_inference(sd, tokens, token_lens, ref, z, n_timesteps=10, meanflow=Fals
     cond = torch.zeros(B, 80, T)
     cond[:, :, : 2 * P] = ref["prompt_feat"].float().transpose(1, 2)
     mask = hm.float()[:, None, :]
+    if hold_back is not None:
+        keep = 2 * lens - torch.as_tensor(hold_back)
+        mask = mask * (torch.arange(T)[None] < keep[:, None]).float()[:, None, :]
     mel = cfm_solve(sd, z, mu, mask, spk, cond, n_timesteps, meanflow=meanflow)
     return mel[:, :, 2 * P:]
 
@@ -470,10 +476,14 @@ def hift_decode(sd, mel, s):
     return wav.clamp(-0.99, 0.99)
 
 
-def hift_inference(sd, mel, phase, noise):
-    """HiFTGenerator.inference (hifigan.py:462-474) with injected SineGen phase/noise.  Returns (wav, source)."""
+def hift_inference(sd, mel, phase, noise, cache_source=None):
+    """HiFTGenerator.inference (hifigan.py:462-474) with injected SineGen phase/noise.  Returns (wav, source).
+    cache_source (B,1,L): the source of an earlier chunk overrides the first L samples (hifigan.py:470-472)."""
     f0 = f0_predict(sd, mel)
     s = source_module(sd, f0, phase, noise)
+    if cache_source is not None and cache_source.shape[2]:
+        s = s.clone()
+        s[:, :, : cache_source.shape[2]] = cache_source
     return hift_decode(sd, mel, s), s
 
 

@@ -282,7 +282,7 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
     // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by
     // 5-45 % and 64x64 by 0-15 %
-    int tile = force ? force : (g128 >= 64 && p.N > 64 ? 12864 : 64);
+    int tile = force ? force : (g128 >= 64 && p.N >= 64 ? 12864 : 64);
     if (planes == 2) {
         if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1>(p, st);
         if (tile == 1286401) return launch_split<128, 64, 4, 2, 2, 1>(p, st);

@@ -56,6 +56,7 @@ def parse():
                     help="skip the extra steps measured after the timed region at the other S3Gen precisions (default: bf16x3 is measured "
                          "and reported under audio_s_per_wall_s_at_other_precisions; --all-precisions adds exact fp32)")
     ap.add_argument("--all-precisions", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the chunked-synthesis latency measurement after the timed region")
     ap.add_argument("--config3", action="store_true",
                     help="after the timed region also run configs[3]: 256 utterances strong-sharded over the ranks (32 per GPU at 8 GPUs); "
                          "default on when WORLD_SIZE == 8")
@@ -403,7 +404,7 @@ def main():
 
     # ---- outside the timed region: (a) eager replay of the decode step for the gemv roofline, (b) one step at each of the other
     # S3Gen precisions so that the exact-fp32 figure is reported by the same run
-    alt, gemv, dstep, cfg3 = {}, None, None, None
+    alt, gemv, dstep, cfg3, stream = {}, None, None, None, None
     if not turbo:
         eng.t3.time_decode = False
     run_cfg3 = (args.config3 or world == 8) and not turbo
@@ -460,6 +461,27 @@ def main():
                     torch.cuda.synchronize()
                     alt[f"s3gen_precision_{pr}"] = round(a / (time.perf_counter() - ta), 2)
                 eng.flow.precision = eng.hift.precision = s3_prec
+        stream = None
+        if not turbo and world == 1 and not args.no_streaming:
+            # chunked synthesis (engine.synthesize_stream): wall time until the first audio chunk is on the host, and the cost of the
+            # whole chunked run, on the benched batch (first chunk = 1 s of audio, then 2 s chunks)
+            fl, tl = [], []
+            for rep in range(3):
+                g = torch.Generator(device=dev).manual_seed(99 + rep)
+                us = torch.rand(B, N, generator=g, device=dev)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                first = None
+                for r in eng.synthesize_stream(texts, t3c, gen, first_chunk=25, chunk=50, max_new_tokens=N, uniforms=us, ban_eos=True, ban_from=6561):
+                    if first is None:
+                        first = time.perf_counter() - ts
+                torch.cuda.synchronize()
+                fl.append(first)
+                tl.append(time.perf_counter() - ts)
+            fl.sort(), tl.sort()
+            stream = dict(schedule="first chunk 25 tokens (1 s of audio) + 3 lookahead, then 50-token chunks; every round re-runs encoder + CFM over all "
+                                   "tokens so far", p50_first_audio_latency_ms=round(1e3 * fl[1], 1), p50_total_ms=round(1e3 * tl[1], 1),
+                          audio_s_per_wall_s=round(B * (N - 1) / 25.0 / tl[1], 2))
         roofs = roofline_entries(summ, elapsed, args.steps, timed_steps, s3_prec, N - 1, gemv)
         dom = args.roofline_kernel
         if dom == "auto":
@@ -495,6 +517,8 @@ def main():
                  .replace("s3gen_precision_1", "s3gen_exact_fp32_mfma").replace("s3gen_precision_6", "s3gen_bf16x6"): v for k, v in alt.items()}
         if cfg3:
             out["configs3"] = cfg3
+        if stream:
+            out["streaming"] = stream
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)

@@ -55,6 +55,19 @@ class SamplerParams(ctypes.Structure):
     ]
 
 
+class T3Layer(ctypes.Structure):
+    _fields_ = [("ln1", c_f), ("ln2", c_f), ("wqkv", c_f), ("wo", c_f), ("wgu", c_f), ("wd", c_f)]
+
+
+class T3Step(ctypes.Structure):
+    _fields_ = [("n_layers", c_int), ("rows", c_int), ("dim", c_int), ("ffn", c_int), ("n_heads", c_int), ("vocab", c_int),
+                ("o_nw", c_int), ("gu_nw", c_int), ("d_nw", c_int), ("d_ksplit", c_int), ("eps", c_float), ("attn_scale", c_float),
+                ("layers", ctypes.POINTER(T3Layer)), ("speech_emb", c_f), ("speech_pos", c_f), ("final_norm", c_f), ("head", c_f),
+                ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("kv_row_stride", c_long), ("kv_head_stride", c_long),
+                ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f), ("x_a", c_f), ("x_b", c_f), ("qkv", c_f), ("att", c_f),
+                ("g", c_f), ("pd", c_f), ("logits", c_f), ("ld_logits", c_long), ("sampler", ctypes.POINTER(SamplerParams))]
+
+
 _SIGS = {
     "cbx_abi_version": ([], c_int),
     "cbx_last_error": ([], ctypes.c_char_p),
@@ -86,6 +99,7 @@ _SIGS = {
     "cbx_seg_gate_mul_f32": ([c_f, c_f, c_int, c_int, c_int, c_long, c_long, c_f], c_int),
     "cbx_stats_pool_f32": ([c_f, c_f, c_int, c_int, c_long, c_f], c_int),
     "cbx_fsq_index": ([c_f, c_f, c_long, c_long, c_f], c_int),
+    "cbx_t3_decode_step": ([ctypes.POINTER(T3Step), c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
     "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),

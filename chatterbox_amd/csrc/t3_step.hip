@@ -1,0 +1,57 @@
+// Stage-level C entry point of the T3 decode loop (SURVEY.md 8b "what the C-ABI replacement must export": the body of
+// T3.inference's loop, reference models/t3/t3.py:338-386, for every row at once).  One call enqueues ONE token step of the Llama stack
+// -- embedding gather, 30 x [q/k/v GEMV with RMSNorm and the partial-sum operand folded in, fused RoPE + cache append + attention,
+// o GEMV + residual, gate/up GEMV with RMSNorm + SwiGLU, down GEMV as split-K partial images], head GEMV, device sampler -- on the
+// caller's stream, with no allocation and no synchronisation, so a C / C++ host can capture it in a hipGraph and replay it per token
+// exactly as chatterbox_amd/t3.py does (which calls this function when CBX_T3_CSTEP=1).  It only sequences the kernel-level entry
+// points of this library; all state is caller-owned device memory described by cbx_t3_step_t.
+#include "cbx_common.h"
+
+extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
+    CBX_REQUIRE(d && d->layers && d->n_layers > 0, "t3_decode_step: null descriptor");
+    CBX_REQUIRE(d->rows >= 1 && d->rows <= 16, "t3_decode_step: rows=%d (this entry point serves the packed <= 16-row path)", d->rows);
+    CBX_REQUIRE(d->d_ksplit == 2 || d->d_ksplit == 4, "t3_decode_step: d_ksplit must be 2 or 4");
+    const int D = d->dim, F = d->ffn, H = d->n_heads;
+    float* cur = d->x_a;
+    float* nxt = d->x_b;
+    int rc = cbx_embed_f32(d->next_ids, d->speech_emb, d->speech_pos, d->next_pos_ids, cur, d->rows, D, D, 1.0f, 3, stream);
+    if (rc) return rc;
+    cbx_gemv_t g;
+    auto base = [&](const float* x, const float* W, float* out, int N, int K) {
+        g = cbx_gemv_t{};
+        g.x = x, g.W = W, g.out = out, g.M = d->rows, g.N = N, g.K = K, g.ksplit = 1, g.nw = 8;
+        g.w_packed = g.x_packed = 1, g.eps = d->eps, g.ldx = K, g.ldw = K, g.ldo = N;
+    };
+    const long img = (long)((d->rows + 15) / 16 * 16) * D;  // floats per packed residual / partial image
+    bool pending = false;                                     // split-K partial images of the previous down projection waiting to be summed
+    for (int i = 0; i < d->n_layers; ++i) {
+        const cbx_t3_layer_t& L = d->layers[i];
+        base(cur, L.wqkv, d->qkv, 3 * D, D);
+        g.norm_w = L.ln1;
+        if (pending) g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nxt;
+        if ((rc = cbx_gemv_f32(&g, stream))) return rc;
+        if (pending) {
+            float* t = cur;
+            cur = nxt, nxt = t;
+        }
+        const long kv_layer = (long)d->rows * d->kv_row_stride;
+        if ((rc = cbx_decode_attn_rope_f32(d->qkv, d->positions, d->cos_t, d->sin_t, d->kc + i * kv_layer, d->vc + i * kv_layer, d->att, d->rows,
+                                           H, 3 * D, D, 1, d->kv_row_stride, d->kv_head_stride, d->attn_scale, stream)))
+            return rc;
+        base(d->att, L.wo, cur, D, D);
+        g.nw = d->o_nw, g.res = cur, g.out_packed = 1;
+        if ((rc = cbx_gemv_f32(&g, stream))) return rc;
+        base(cur, L.wgu, d->g, F, D);
+        g.norm_w = L.ln2, g.swiglu = 1, g.out_packed = 1, g.nw = d->gu_nw;
+        if ((rc = cbx_gemv_f32(&g, stream))) return rc;
+        base(d->g, L.wd, d->pd, D, F);
+        g.ksplit = d->d_ksplit, g.nw = d->d_nw, g.out_packed = 1, g.part_stride = img, g.ldo = D;
+        if ((rc = cbx_gemv_f32(&g, stream))) return rc;
+        pending = true;
+    }
+    base(cur, d->head, d->logits, d->vocab, D);
+    g.norm_w = d->final_norm, g.ldo = d->ld_logits;
+    g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nullptr;
+    if ((rc = cbx_gemv_f32(&g, stream))) return rc;
+    return d->sampler ? cbx_t3_sample(d->sampler, stream) : 0;
+}

@@ -89,6 +89,7 @@ class T3Engine:
         self.max_pos = max_pos
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
+        self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"  # token step through the stage-level C entry point (same kernels)
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
         self.tune = dict(self._TUNE)
 
@@ -124,6 +125,7 @@ class T3Engine:
         self.max_pos = self.cos.shape[0]
         self._state = {}
         self.time_decode, self.decode_events = False, []
+        self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"
         self.tune = dict(cls._TUNE)
         return self
 
@@ -232,8 +234,41 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (2, 4):
+            return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
+
+    def _decode_step_c(self, st):
+        """The same token step through the stage-level C entry point cbx_t3_decode_step (include/cbx.h): one ctypes call enqueues the
+        153 launches that _forward_decode_v2 + _sample issue one by one."""
+        import ctypes
+        from ._lib import SamplerParams, T3Layer, T3Step, check, lib
+        if "cstep" not in st:
+            p = lambda t: t.data_ptr()
+            ws, tn = st["dws"], self.tune
+            layers = (T3Layer * self.L)()
+            for i, lw in enumerate(self.layers):
+                layers[i].ln1, layers[i].ln2 = p(lw["ln1"]), p(lw["ln2"])
+                layers[i].wqkv, layers[i].wo, layers[i].wgu, layers[i].wd = p(lw["wqkv_pk"]), p(lw["wo_pk"]), p(lw["wgu_pk"]), p(lw["wd_pk"])
+            sp = SamplerParams()
+            for k, v in dict(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, order=0, eos_token=STOP_SPEECH,
+                             dev_params=st["samp_dev"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
+                             out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
+                             next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"]).items():
+                setattr(sp, k, v.data_ptr() if torch.is_tensor(v) else v)
+            d = T3Step()
+            d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = self.L, st["rows"], self.D, self.F, self.H, self.V
+            d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.eps, d.attn_scale = tn["o_nw2"], tn["gu_nw"], tn["d_nw2"], tn["d_ks2"], 1e-5, 0.125
+            d.layers = layers
+            d.speech_emb, d.speech_pos, d.final_norm, d.head = p(self.speech_emb), p(self.speech_pos), p(self.norm), p(self.head_pk)
+            d.cos_t, d.sin_t, d.kc, d.vc = p(self.cos), p(self.sin), p(st["kc"]), p(st["vc"])
+            d.kv_row_stride, d.kv_head_stride = st["kc"].stride(1), st["kc"].stride(2)
+            d.next_ids, d.next_pos_ids, d.positions = p(st["next_ids"]), p(st["next_pos_ids"]), p(st["positions"])
+            d.x_a, d.x_b, d.qkv, d.att, d.g, d.pd = p(ws["x_pk"]), p(ws["x2_pk"]), p(ws["qkv"]), p(ws["att_pk"]), p(ws["g_pk"]), p(ws["pd_pk"])
+            d.logits, d.ld_logits, d.sampler = p(st["logits"]), st["logits"].stride(0), ctypes.pointer(sp)
+            st["cstep"] = (d, layers, sp)  # keep the host structures alive
+        check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
 
     def _sample(self, st):
         # the sampling parameters are read from device memory (st["samp_dev"], one row per utterance): a request with other settings

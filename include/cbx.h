@@ -209,6 +209,33 @@ typedef struct cbx_sampler_t {
 } cbx_sampler_t;
 int cbx_t3_sample(const cbx_sampler_t* p, void* stream);
 
+/* ---- stage-level entry point: ONE token step of T3.inference's loop for every row (t3.py:338-386) ----
+ * Sequences the kernel-level entry points above on `stream` (embedding gather, n_layers x 5 launches, head, sampler): no allocation,
+ * no synchronisation, hipGraph-capturable.  rows <= 16 (the packed-operand path); all weights are cbx_pack_gemv_weight_f32 images
+ * (wgu with swiglu = 1), all buffers caller-owned device memory. */
+typedef struct cbx_t3_layer_t {
+    const float *ln1, *ln2;               /* [dim] RMSNorm weights (input_layernorm, post_attention_layernorm) */
+    const float *wqkv, *wo, *wgu, *wd;    /* packed images: [3*dim][dim], [dim][dim], gate|up [2*ffn][dim], [dim][ffn] */
+} cbx_t3_layer_t;
+typedef struct cbx_t3_step_t {
+    int n_layers, rows, dim, ffn, n_heads, vocab;
+    int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 8 / 4 */
+    float eps, attn_scale;
+    const cbx_t3_layer_t* layers;         /* HOST array [n_layers] */
+    const float *speech_emb, *speech_pos, *final_norm, *head; /* embeddings [V][dim], [P][dim]; tfmr.norm; packed head [ceil16(vocab)][dim] */
+    const float *cos_t, *sin_t;           /* RoPE tables [max_pos][64] */
+    float *kc, *vc;                       /* KV cache [n_layers][rows][n_heads][max_ctx][64] */
+    long kv_row_stride, kv_head_stride;   /* floats: n_heads*max_ctx*64, max_ctx*64 */
+    const long long* next_ids;            /* [rows] token to embed (written by the sampler) */
+    const int *next_pos_ids, *positions;  /* [rows] learned position index; RoPE / cache position */
+    float *x_a, *x_b;                     /* packed residual images [ceil16(rows)][dim] (ping-pong), pad rows zero */
+    float *qkv, *att, *g, *pd;            /* [rows][3*dim]; packed [ceil16(rows)][dim]; packed [..][ffn]; partial images [d_ksplit][ceil16(rows)][dim] */
+    float* logits;                        /* [rows][ld_logits] */
+    long ld_logits;
+    const cbx_sampler_t* sampler;         /* sampler descriptor (host struct) run at the end of the step, or NULL */
+} cbx_t3_step_t;
+int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
+
 /* ---- HiFT source + (i)STFT (hifigan.py:201-231,267-283,396-410) ---- */
 int cbx_hift_source_f32(const float* f0, const float* phase, const float* noise, const float* lin_w, float lin_b,
                         float* s, double* frame_cum, int B, int T, int up, float sr, void* stream);

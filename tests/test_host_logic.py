@@ -34,7 +34,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     from chatterbox_amd import _lib
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
-    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams,
+    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
                "cbx_sampler_t": _lib.SamplerParams}
     lines = []
     for cname, cls in structs.items():

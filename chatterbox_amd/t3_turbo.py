@@ -34,11 +34,16 @@ class T3TurboEngine:
                 wo=tw(sd[p + "attn.c_proj.weight"]), bo=d(sd[p + "attn.c_proj.bias"]),
                 wfc=tw(sd[p + "mlp.c_fc.weight"]), bfc=d(sd[p + "mlp.c_fc.bias"]),
                 wpr=tw(sd[p + "mlp.c_proj.weight"]), bpr=d(sd[p + "mlp.c_proj.bias"])))
+        # decode path: lane-ordered packed images of the streamed weights (every wave-level load = 1 KiB contiguous, cbx.h)
+        for lw in self.layers:
+            for k in ("wqkv", "wo", "wfc", "wpr"):
+                lw[k + "_pk"] = ops.pack_gemv_weight(lw[k])
         self.lnf = (d(sd["tfmr.ln_f.weight"]), d(sd["tfmr.ln_f.bias"]))
         self.wpe = d(sd["tfmr.wpe.weight"])
         self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
         self.head, self.head_b = d(sd["speech_head.weight"]), d(sd["speech_head.bias"])
         self.V = self.head.shape[0]
+        self.head_pk = ops.pack_gemv_weight(self.head)
         self.spkr_w, self.spkr_b = d(sd["cond_enc.spkr_enc.weight"]), d(sd["cond_enc.spkr_enc.bias"])
         # split-K factors of the two down-projections: K must be a multiple of 32 * ksplit * 4
         self.ks_o = 4 if self.D % 512 == 0 else 2
@@ -52,15 +57,15 @@ class T3TurboEngine:
         part = None
         for i, lw in enumerate(self.layers):
             ops.add_rmsnorm(x, part, lw["ln1"][0], h, bias=lw["ln1"][1], rms=False)
-            ops.gemv(h, lw["wqkv"], qkv, bias=lw["bqkv"], nw=8)
+            ops.gemv(h, lw["wqkv_pk"], qkv, N=3 * self.D, bias=lw["bqkv"], nw=8, w_packed=True)
             ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125)
-            ops.gemv(att, lw["wo"], po, bias=lw["bo"], ksplit=self.ks_o, nw=4)
+            ops.gemv(att, lw["wo_pk"], po, N=self.D, bias=lw["bo"], ksplit=self.ks_o, nw=4, w_packed=True)
             ops.add_rmsnorm(x, po, lw["ln2"][0], h, bias=lw["ln2"][1], rms=False)
-            ops.gemv(h, lw["wfc"], g, bias=lw["bfc"], nw=8, act=ops.GELU_TANH)
-            ops.gemv(g, lw["wpr"], pd, bias=lw["bpr"], ksplit=self.ks_p, nw=4)
+            ops.gemv(h, lw["wfc_pk"], g, N=4 * self.D, bias=lw["bfc"], nw=8, act=ops.GELU_TANH, w_packed=True)
+            ops.gemv(g, lw["wpr_pk"], pd, N=self.D, bias=lw["bpr"], ksplit=self.ks_p, nw=4, w_packed=True)
             part = pd
         ops.add_rmsnorm(x, part, self.lnf[0], h, bias=self.lnf[1], rms=False)
-        ops.gemv(h, self.head, st["logits"], bias=self.head_b, nw=4)
+        ops.gemv(h, self.head_pk, st["logits"], N=self.V, bias=self.head_b, nw=4, w_packed=True)
 
     def _sample(self, st):
         ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, order=1, eos_token=STOP_SPEECH,

@@ -41,7 +41,7 @@ class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("out_packed", c_int), ("reserved0", c_int),
-                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f)]
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("ln_cw", c_f), ("ln_cb", c_f)]
 
 
 class SamplerParams(ctypes.Structure):

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
     __shared__ float ssq[RMS ? NW * MT * 16 : 1];
+    __shared__ float ssx[RMS ? NW * MT * 16 : 1];  // row sums (LayerNorm form only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, ks = blockIdx.y;
@@ -75,13 +76,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     }
 
     const float* nwp = RMS ? p.norm_w + kbeg + 8 * q : nullptr;  // this lane's k indices: kbeg + 32*blk + 8*q + 4*h + s
-    float ss[MT];
+    float ss[MT], sx[MT];
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         ss[t] = 0.f;
+        sx[t] = 0.f;
     }
     constexpr int DEPTH = (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                     xq = (on[d] && xok[t]) ? xq : zero4;
                     if constexpr (RMS) {
                         ss[t] += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
+                        sx[t] += (xq[0] + xq[1]) + (xq[2] + xq[3]);
                         xq *= nv[d][h];
                     }
 #pragma unroll
@@ -171,7 +174,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             float v = ss[t];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (q == 0) ssq[(w * MT + t) * 16 + c] = v;
+            float u = sx[t];
+            u += __shfl_xor(u, 16);
+            u += __shfl_xor(u, 32);
+            if (q == 0) {
+                ssq[(w * MT + t) * 16 + c] = v;
+                ssx[(w * MT + t) * 16 + c] = u;
+            }
         }
     }
     __syncthreads();
@@ -189,9 +198,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             float sq = 0.f;
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) sq += ssq[(ww * MT + t) * 16 + row];
-            const float rstd = rsqrtf(sq / (float)p.K + p.eps);
-            v *= rstd;
-            v2 *= rstd;
+            if (p.ln_cw) {  // LayerNorm form (GPT-2): y = (x - mean) rstd w + b  =>  out = rstd (acc - mean cw[n]) + cb[n]
+                float su = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) su += ssx[(ww * MT + t) * 16 + row];
+                const float mean = su / (float)p.K;
+                const float rstd = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.f) + p.eps);
+                v = rstd * (v - mean * p.ln_cw[n]) + p.ln_cb[n];
+            } else {
+                const float rstd = rsqrtf(sq / (float)p.K + p.eps);
+                v *= rstd;
+                v2 *= rstd;
+            }
         }
         if constexpr (SWIGLU) {
             v = (v / (1.0f + __expf(-v))) * v2;
@@ -382,6 +400,7 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
     CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && p.ksplit == 1), "gemv: norm_w needs w_packed, x_packed and ksplit == 1");
     CBX_REQUIRE(!p.res || p.ksplit == 1, "gemv: res needs ksplit == 1");
+    CBX_REQUIRE(!p.ln_cw || (p.norm_w && p.ln_cb && !p.swiglu && !p.bias), "gemv: the LayerNorm form needs norm_w, ln_cb, no swiglu, bias folded into ln_cb");
     CBX_REQUIRE(p.n_xpart == 0 || (p.norm_w && p.xpart && p.M <= 16 && (p.n_xpart == 2 || (p.n_xpart == 4 && !p.swiglu)) && p.nw == 8 && p.x_out != p.x),
                 "gemv: xpart needs norm_w, M <= 16, n_xpart in {2, 4}, nw == 8 and x_out != x");
     CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv: out_packed needs N %% 32 == 0");

@@ -178,7 +178,7 @@ def pack_gemv_weight(w, swiglu=False):
 
 
 def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None):
+         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
@@ -195,6 +195,7 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     p.ldx, p.ldw = x.stride(0), w.stride(0)
     p.w_packed, p.x_packed = int(w_packed), int(x_packed)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
+    p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
     if xpart is not None:
         p.n_xpart, p.xpart, p.xpart_stride, p.x_out = xpart.shape[0], _p(_f32(xpart, "xpart")), xpart.stride(0), _p(x_out)
     if ksplit > 1:

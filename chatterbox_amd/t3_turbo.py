@@ -2,8 +2,11 @@
 configuration tts_turbo.py:153-167).  Same kernel set as the Llama path with other epilogues: LayerNorm(+bias) instead of
 RMSNorm, fused c_attn with bias (HF Conv1D weights are stored [in,out] and transposed once at load), no RoPE (learned wpe is
 added when the token is embedded), gelu_new in the c_fc epilogue, speech head with bias, no CFG (rows = utterances), sampler
-in the Temperature -> TopK -> TopP -> RepetitionPenalty order.  One decode step is a hipGraph (6 kernels per layer).
+in the Temperature -> TopK -> TopP -> RepetitionPenalty order.  One decode step is a hipGraph: 5 launches per layer for <= 16 rows
+(LayerNorm folded into the consuming GEMVs, _forward_decode_v2), 7 beyond.
 """
+import os
+
 import torch
 
 from . import ops
@@ -39,11 +42,23 @@ class T3TurboEngine:
             for k in ("wqkv", "wo", "wfc", "wpr"):
                 lw[k + "_pk"] = ops.pack_gemv_weight(lw[k])
         self.lnf = (d(sd["tfmr.ln_f.weight"]), d(sd["tfmr.ln_f.bias"]))
+        self.decode_mode = os.environ.get("CBX_T3_DECODE", "v2")
         self.wpe = d(sd["tfmr.wpe.weight"])
         self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
         self.head, self.head_b = d(sd["speech_head.weight"]), d(sd["speech_head.bias"])
         self.V = self.head.shape[0]
         self.head_pk = ops.pack_gemv_weight(self.head)
+        # LayerNorm folded into the consuming GEMV (cbx_gemv_t.ln_cw / ln_cb): out = rstd (sum_k x w W - mean cw) + cb with the layer
+        # constants cw[n] = sum_k w[k] W[n][k], cb[n] = sum_k b[k] W[n][k] + bias[n]
+        def ln_consts(ln, W, bias):
+            cw, cb = torch.empty(1, W.shape[0], device=dev), torch.empty(1, W.shape[0], device=dev)
+            ops.gemv(ln[0].view(1, -1), W, cw, nw=4)
+            ops.gemv(ln[1].view(1, -1), W, cb, bias=bias, nw=4)
+            return cw.view(-1), cb.view(-1)
+        for lw in self.layers:
+            lw["c_qkv"] = ln_consts(lw["ln1"], lw["wqkv"], lw["bqkv"])
+            lw["c_fc"] = ln_consts(lw["ln2"], lw["wfc"], lw["bfc"])
+        self.c_head = ln_consts(self.lnf, self.head, self.head_b)
         self.spkr_w, self.spkr_b = d(sd["cond_enc.spkr_enc.weight"]), d(sd["cond_enc.spkr_enc.bias"])
         # split-K factors of the two down-projections: K must be a multiple of 32 * ksplit * 4
         self.ks_o = 4 if self.D % 512 == 0 else 2
@@ -67,14 +82,42 @@ class T3TurboEngine:
         ops.add_rmsnorm(x, part, self.lnf[0], h, bias=self.lnf[1], rms=False)
         ops.gemv(h, self.head_pk, st["logits"], N=self.V, bias=self.head_b, nw=4, w_packed=True)
 
+    def _forward_decode_v2(self, st):
+        """5 launches per GPT-2 layer (rows <= 16): LayerNorm folded into the c_attn / c_fc / head GEMVs, the attention projection adds
+        bias + residual in its epilogue, the MLP projection emits split-K partial images that the next consumer sums into its operand
+        (same structure as T3Engine._forward_decode_v2)."""
+        ws, D = st["dws"], self.D
+        B, dks = st["B"], 4
+        cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"]
+        pk = dict(w_packed=True, x_packed=True, M=B)
+        ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.wpe, ids2=st["positions"], out_packed=True)
+        red = {}
+        for i, lw in enumerate(self.layers):
+            ops.gemv(cur, lw["wqkv_pk"], qkv, N=3 * D, K=D, nw=8, norm_w=lw["ln1"][0], ln_cw=lw["c_qkv"][0], ln_cb=lw["c_qkv"][1], **red, **pk)
+            if red:
+                cur, nxt = nxt, cur
+            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
+            ops.gemv(att, lw["wo_pk"], cur, N=D, K=D, nw=8, bias=lw["bo"], res=cur, out_packed=True, **pk)
+            ops.gemv(cur, lw["wfc_pk"], g, N=4 * D, K=D, nw=8, norm_w=lw["ln2"][0], ln_cw=lw["c_fc"][0], ln_cb=lw["c_fc"][1],
+                     act=ops.GELU_TANH, out_packed=True, **pk)
+            ops.gemv(g, lw["wpr_pk"], pd, N=D, K=4 * D, ksplit=dks, nw=8, bias=lw["bpr"], out_packed=True, **pk)
+            red = dict(xpart=pd, x_out=nxt)
+        red["x_out"] = None
+        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1], **red, **pk)
+
     def _sample(self, st):
         ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, order=1, eos_token=STOP_SPEECH,
                       dev_params=st["samp_dev"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
                       out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
                       next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
 
-    def _decode_step(self, st):
+    def _forward(self, st):
+        if self.decode_mode == "v2" and st["B"] <= 16:
+            return self._forward_decode_v2(st)
         self._forward_decode(st)
+
+    def _decode_step(self, st):
+        self._forward(st)
         self._sample(st)
 
     def _get_state(self, B, max_ctx, max_steps):
@@ -90,7 +133,11 @@ class T3TurboEngine:
                   logits=f(B, self.V), seen=torch.zeros(B, self.V, dtype=torch.uint8, device=dev), uniforms=f(B, max_steps), step=i32(B),
                   out_tokens=torch.zeros(B, max_steps, dtype=torch.int64, device=dev), done=i32(B), n_generated=i32(B),
                   next_ids=torch.zeros(B, dtype=torch.int64, device=dev), next_pos_ids=i32(B), positions=i32(B), ctx_lens=i32(B),
-                  dws=dict(x=f(B, D), h=f(B, D), qkv=f(B, 3 * D), att=f(B, D), g=f(B, 4 * D), po=f(self.ks_o, B, D), pd=f(self.ks_p, B, D)),
+                  dws=dict(x=f(B, D), h=f(B, D), qkv=f(B, 3 * D), att=f(B, D), g=f(B, 4 * D), po=f(self.ks_o, B, D), pd=f(self.ks_p, B, D),
+                           # packed operand images of the v2 path (rows padded to a 16-row tile, pad rows stay 0)
+                           x_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), x2_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev),
+                           att_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), g_pk=torch.zeros((B + 15) // 16 * 16, 4 * D, device=dev),
+                           pd_pk=torch.zeros(4, (B + 15) // 16 * 16, D, device=dev)),
                   graph=None, samp_dev=torch.zeros(B, 8, device=dev))
         self._state[key] = st
         return st
@@ -192,7 +239,7 @@ class T3TurboEngine:
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
             elif debug_logits:
-                self._forward_decode(st)
+                self._forward(st)
                 step_logits.append(st["logits"].clone())
                 self._sample(st)
             else:

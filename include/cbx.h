@@ -93,6 +93,9 @@ typedef struct cbx_gemv_t {
     const float* xpart;  /* [n_xpart] images, xpart_stride floats apart */
     long xpart_stride;
     float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it) */
+    const float* ln_cw;  /* or NULL: LayerNorm instead of RMSNorm (GPT-2 ln_1 / ln_2 / ln_f): with norm_w = LN weight w, ln_cw[n] = */
+    const float* ln_cb;  /* sum_k w[k] W[n][k] and ln_cb[n] = sum_k b[k] W[n][k] + bias[n] (constants of the layer, computed at load): */
+                         /* out[m][n] = rstd[m] (sum_k x w W - mean[m] ln_cw[n]) + ln_cb[n], then `act` */
 } cbx_gemv_t;
 /* Packed GEMV weight layout (decode path; the weights are constants, so they are laid out once for the MFMA lane order):
  *   dst[(((tile * (K/32) + kb) * 2 + h) * 64 + lane) * 4 + s] = src[tile*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + h*4 + s]

@@ -568,3 +568,30 @@ def test_decode_attn_packed_output_and_embed_packed(dev):
     ops.embed(ids, t1, e1, table2=t2, ids2=ids2)
     ops.embed(ids, t1, e2, table2=t2, ids2=ids2, out_packed=True)
     assert torch.equal(_unpack_operand(e2, 7, 256), e1)
+
+
+@pytest.mark.parametrize("M,N,K,npart,act", [(16, 3072, 1024, 0, False), (5, 2304, 768, 4, False), (16, 4096, 1024, 0, True), (1, 6563, 1024, 4, False)])
+def test_gemv_layernorm_fused(dev, M, N, K, npart, act):
+    """GPT-2 form of the fused decode GEMV: out = act(LayerNorm(x + sum partials) W^T + bias) with the LayerNorm folded in as
+    rstd (sum_k x w W - mean cw) + cb (cbx_gemv_t.ln_cw / ln_cb), against torch fp32."""
+    from chatterbox_amd import ops
+    x, parts = _r((M, K), 1) + 0.3, _r((max(npart, 1), M, K), 2, 0.3)
+    lw, lb = 1 + 0.1 * _r((K,), 3), 0.1 * _r((K,), 4)
+    w, b = _r((N, K), 5, 1 / math.sqrt(K)), _r((N,), 6)
+    h = x.clone()
+    for j in range(npart):
+        h = h + parts[j]
+    ref = F.linear(F.layer_norm(h, (K,), lw, lb, 1e-5), w, b)
+    if act:
+        ref = F.gelu(ref, approximate="tanh")
+    wd = w.to(dev)
+    cw, cb = torch.empty(1, N, device=dev), torch.empty(1, N, device=dev)
+    ops.gemv(lw.view(1, -1).to(dev), wd, cw, nw=4)
+    ops.gemv(lb.view(1, -1).to(dev), wd, cb, bias=b.to(dev), nw=4)
+    out = torch.empty(M, N, device=dev)
+    kw = {}
+    if npart:
+        kw = dict(xpart=torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(npart)]), x_out=torch.zeros(16, K, device=dev))
+    ops.gemv(ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(wd), out, N=N, M=M, K=K, nw=8, w_packed=True, x_packed=True,
+             norm_w=lw.to(dev), ln_cw=cw.view(-1), ln_cb=cb.view(-1), act=ops.GELU_TANH if act else ops.NONE, **kw)
+    _close(out, ref, 5e-5, "gemv layernorm-fused")

@@ -40,7 +40,7 @@ class GemmParams(ctypes.Structure):
 class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
-                ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("out_packed", c_int), ("reserved0", c_int),
+                ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("half_tile", c_int), ("out_packed", c_int),
                 ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("ln_cw", c_f), ("ln_cb", c_f)]
 
 
@@ -61,7 +61,8 @@ class T3Layer(ctypes.Structure):
 
 class T3Step(ctypes.Structure):
     _fields_ = [("n_layers", c_int), ("rows", c_int), ("dim", c_int), ("ffn", c_int), ("n_heads", c_int), ("vocab", c_int),
-                ("o_nw", c_int), ("gu_nw", c_int), ("d_nw", c_int), ("d_ksplit", c_int), ("eps", c_float), ("attn_scale", c_float),
+                ("o_nw", c_int), ("gu_nw", c_int), ("d_nw", c_int), ("d_ksplit", c_int), ("half_tiles", c_int), ("reserved0", c_int),
+                ("eps", c_float), ("attn_scale", c_float),
                 ("layers", ctypes.POINTER(T3Layer)), ("speech_emb", c_f), ("speech_pos", c_f), ("final_norm", c_f), ("head", c_f),
                 ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("kv_row_stride", c_long), ("kv_head_stride", c_long),
                 ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f), ("x_a", c_f), ("x_b", c_f), ("qkv", c_f), ("att", c_f),

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     __shared__ float ssx[RMS ? NW * MT * 16 : 1];  // row sums (LayerNorm form only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, ks = blockIdx.y;
+    const bool ht = PK && p.half_tile;  // 8-column output tiles: twice the workgroups per projection (lanes c >= 8 idle in the B operand)
+    const int n0 = blockIdx.x * (ht ? 8 : 16), ks = blockIdx.y;
     const int kper = p.K / (p.ksplit * NW);
     const int kbeg = (ks * NW + w) * kper;
     const int nit = kper / 32;
@@ -41,15 +42,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     long wrow;
     bool wok;
     const float *wp, *wp2;
-    constexpr int WBLK = PK ? 512 : 32;  // floats between consecutive 32-deep K blocks of this lane's stream
-    constexpr int WHALF = PK ? 256 : 4;  // floats between the two 16-B halves of a block
+    const int WBLK = PK ? (ht ? 256 : 512) : 32;  // floats between consecutive 32-deep K blocks of this lane's stream
+    const int WHALF = PK ? (ht ? 128 : 256) : 4;  // floats between the two 16-B halves of a block
     if constexpr (PK) {
         // packed image: tile-major [tile][K/32][2][64 lanes][4]; swiglu: feature tile f -> tiles 2f (gate), 2f+1 (up); N is padded
         // to whole tiles by the packer, so every load is in range
         const long kb = p.K >> 5;
         const long tile = SWIGLU ? 2L * blockIdx.x : (long)blockIdx.x;
-        wok = true;
-        wp = p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
+        wok = !ht || c < 8;
+        wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 256 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
         wp2 = wp + kb * 512;
     } else {
         if constexpr (SWIGLU) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     for (int e = tid; e < MT * 256; e += NW * 64) {
         const int t = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
         const int m = t * 16 + row, n = n0 + col;
-        if (m >= p.M || n >= p.N) continue;
+        if (m >= p.M || n >= p.N || (ht && col >= 8)) continue;
         float v = 0.f, v2 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 
 template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
-    dim3 grid((p.N + 15) / 16, p.ksplit);
+    const int tc = (PK && p.half_tile) ? 8 : 16;
+    dim3 grid((p.N + tc - 1) / tc, p.ksplit);
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
             hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0>), grid, dim3(1024), 0, st, p);
@@ -351,9 +353,22 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* x, const float*
 
 // one thread per float4 of the packed image (layout: include/cbx.h "Packed GEMV weight layout")
 __global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K,
-                                                               long ld, int swiglu, long n4) {
+                                                               long ld, int swiglu, long n4, int half_tile) {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= n4) return;
+    if (half_tile) {  // 8-row tiles: [tile][K/32][2][32 lanes = q*8 + c][4]
+        const int l32 = i4 & 31, h = (i4 >> 5) & 1;
+        const long tb = i4 >> 6;
+        const int KB = K >> 5;
+        const long tile = tb / KB;
+        const int kb = (int)(tb - tile * KB);
+        const long r = tile * 8 + (l32 & 7);
+        const int k = kb * 32 + (l32 >> 3) * 8 + h * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < N) v = *reinterpret_cast<const f32x4*>(src + r * ld + k);
+        *reinterpret_cast<f32x4*>(dst + i4 * 4) = v;
+        return;
+    }
     const int lane = i4 & 63, h = (i4 >> 6) & 1;
     const long tb = i4 >> 7;  // tile * KB + kb
     const int KB = K >> 5;
@@ -380,10 +395,12 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const float* __re
 extern "C" int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream) {
     CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight: bad args (K %% 32, ld %% 4)");
     CBX_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "pack_gemv_weight: alignment");
-    const long tiles = (long)((N + 15) / 16) * (swiglu ? 2 : 1);
-    const long n4 = tiles * (K / 32) * 128;
+    const int half_tile = swiglu == 8;  // swiglu == 8 selects the 8-row-tile image (cbx_gemv_t.half_tile) of a plain weight
+    if (half_tile) swiglu = 0;
+    const long tiles = half_tile ? (N + 7) / 8 : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
+    const long n4 = tiles * (K / 32) * (half_tile ? 64 : 128);
     hipLaunchKernelGGL(pack_gemv_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N, K,
-                       ld_src, swiglu, n4);
+                       ld_src, swiglu, n4, half_tile);
     return cbx_check_launch("pack_gemv_weight");
 }
 

@@ -39,13 +39,13 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
                                            H, 3 * D, D, 1, d->kv_row_stride, d->kv_head_stride, d->attn_scale, stream)))
             return rc;
         base(d->att, L.wo, cur, D, D);
-        g.nw = d->o_nw, g.res = cur, g.out_packed = 1;
+        g.nw = d->o_nw, g.res = cur, g.out_packed = 1, g.half_tile = d->half_tiles;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
         base(cur, L.wgu, d->g, F, D);
         g.norm_w = L.ln2, g.swiglu = 1, g.out_packed = 1, g.nw = d->gu_nw;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
         base(d->g, L.wd, d->pd, D, F);
-        g.ksplit = d->d_ksplit, g.nw = d->d_nw, g.out_packed = 1, g.part_stride = img, g.ldo = D;
+        g.ksplit = d->d_ksplit, g.nw = d->d_nw, g.out_packed = 1, g.part_stride = img, g.ldo = D, g.half_tile = d->half_tiles;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
         pending = true;
     }

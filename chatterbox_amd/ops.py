@@ -165,20 +165,20 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
-def pack_gemv_weight(w, swiglu=False):
+def pack_gemv_weight(w, swiglu=False, half_tile=False):
     """(N, K) fp32 weight [swiglu: (2F, K) = gate rows then up rows] -> lane-ordered packed image of cbx_gemv_f32 (w_packed = 1):
     (ceil(N/16)*16, K) floats [swiglu: (2*ceil(F/16)*16, K)].  Done once at load (weights are constants)."""
     w = _f32(w, "w").contiguous()
     R, K = w.shape
     N = R // 2 if swiglu else R
-    rows = (N + 15) // 16 * 16 * (2 if swiglu else 1)
+    rows = (N + 7) // 8 * 8 if half_tile else (N + 15) // 16 * 16 * (2 if swiglu else 1)
     out = torch.empty(rows, K, device=w.device)
-    check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
+    check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), 8 if half_tile else int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
     return out
 
 
 def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None):
+         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
@@ -193,7 +193,7 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
     p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu, p.act = M, N, K, ksplit, nw, int(swiglu), act
     p.ldx, p.ldw = x.stride(0), w.stride(0)
-    p.w_packed, p.x_packed = int(w_packed), int(x_packed)
+    p.w_packed, p.x_packed, p.half_tile = int(w_packed), int(x_packed), int(half_tile)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
     if xpart is not None:

@@ -40,7 +40,7 @@ class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
     # decode launch geometry: waves per 16-column tile (nw) / cross-workgroup K splits; *2 = the packed-operand (v2) path
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8, half_tiles=1)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):
@@ -69,6 +69,9 @@ class T3Engine:
                 lw["wo_pk"] = ops.pack_gemv_weight(lw["wo"])
                 lw["wgu_pk"] = ops.pack_gemv_weight(d(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)), swiglu=True)
                 lw["wd_pk"] = ops.pack_gemv_weight(lw["wd"])
+                if self._TUNE.get("half_tiles"):  # 8-column tiles for the two N = 1024 projections (128 instead of 64 output tiles)
+                    lw["wo_pk8"] = ops.pack_gemv_weight(lw["wo"], half_tile=True)
+                    lw["wd_pk8"] = ops.pack_gemv_weight(lw["wd"], half_tile=True)
         self.norm = d(sd["tfmr.norm.weight"])
         self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
         self.text_pos, self.speech_pos = d(sd["text_pos_emb.emb.weight"]), d(sd["speech_pos_emb.emb.weight"])
@@ -217,10 +220,11 @@ class T3Engine:
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ops.gemv(att, lw["wo_pk"], cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, **pk)
+            ht = bool(tn.get("half_tiles")) and "wo_pk8" in lw
+            ops.gemv(att, lw["wo_pk8"] if ht else lw["wo_pk"], cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ht, **pk)
             ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
             if dks > 1:
-                ops.gemv(g, lw["wd_pk"], pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, **pk)
+                ops.gemv(g, lw["wd_pk8"] if ht else lw["wd_pk"], pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ht, **pk)
                 red = dict(xpart=pd, x_out=nxt)
             else:
                 ops.gemv(g, lw["wd_pk"], cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, **pk)
@@ -250,7 +254,9 @@ class T3Engine:
             layers = (T3Layer * self.L)()
             for i, lw in enumerate(self.layers):
                 layers[i].ln1, layers[i].ln2 = p(lw["ln1"]), p(lw["ln2"])
-                layers[i].wqkv, layers[i].wo, layers[i].wgu, layers[i].wd = p(lw["wqkv_pk"]), p(lw["wo_pk"]), p(lw["wgu_pk"]), p(lw["wd_pk"])
+                ht = bool(tn.get("half_tiles")) and "wo_pk8" in lw
+                layers[i].wqkv, layers[i].wgu = p(lw["wqkv_pk"]), p(lw["wgu_pk"])
+                layers[i].wo, layers[i].wd = (p(lw["wo_pk8"]), p(lw["wd_pk8"])) if ht else (p(lw["wo_pk"]), p(lw["wd_pk"]))
             sp = SamplerParams()
             for k, v in dict(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, order=0, eos_token=STOP_SPEECH,
                              dev_params=st["samp_dev"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
@@ -260,6 +266,7 @@ class T3Engine:
             d = T3Step()
             d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = self.L, st["rows"], self.D, self.F, self.H, self.V
             d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.eps, d.attn_scale = tn["o_nw2"], tn["gu_nw"], tn["d_nw2"], tn["d_ks2"], 1e-5, 0.125
+            d.half_tiles = int(bool(tn.get("half_tiles")) and "wo_pk8" in self.layers[0])
             d.layers = layers
             d.speech_emb, d.speech_pos, d.final_norm, d.head = p(self.speech_emb), p(self.speech_pos), p(self.norm), p(self.head_pk)
             d.cos_t, d.sin_t, d.kc, d.vc = p(self.cos), p(self.sin), p(st["kc"]), p(st["vc"])

@@ -81,9 +81,10 @@ typedef struct cbx_gemv_t {
     int w_packed;    /* W is the lane-ordered packed image written by cbx_pack_gemv_weight_f32 (ldw ignored; swiglu: tiles
                         2f = gate, 2f+1 = up of feature tile f) */
     int x_packed;    /* x is in the same packed layout (rows padded to 16, ldx ignored); needs w_packed */
+    int half_tile;   /* (was reserved0) W is the 8-row-tile packed image (cbx_pack_gemv_weight_f32 with swiglu = 8): 8 output columns per
+                        workgroup, i.e. twice the workgroups for projections with few output tiles (N = 1024: 128 instead of 64) */
     int out_packed;  /* out (and res) use the packed operand layout of the CONSUMING gemv (its K = this N; N % 32 == 0); with ksplit > 1
                         the partial images are part_stride floats apart */
-    int reserved0;
     const float* norm_w; /* [K] or NULL: LlamaRMSNorm(x) folded in (x * norm_w feeds the MFMAs, rstd applied in the epilogue);
                             needs w_packed, x_packed, ksplit == 1 */
     const float* res;    /* or NULL: out = res + x W^T, res in the same layout as out (in place allowed); ksplit == 1 */
@@ -101,7 +102,8 @@ typedef struct cbx_gemv_t {
  *   dst[(((tile * (K/32) + kb) * 2 + h) * 64 + lane) * 4 + s] = src[tile*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + h*4 + s]
  * i.e. each (16-row tile, 32-deep K block) is 2 KiB of contiguous memory in exactly the order the 64 lanes of a wave load it
  * (two 1-KiB instructions).  Rows are zero-padded to a multiple of 16.  swiglu = 1: src holds [gate (F rows); up (F rows)] and
- * the tiles are interleaved gate/up per 16 features.  dst must hold ceil(N/16)*16*K floats. */
+ * the tiles are interleaved gate/up per 16 features.  dst must hold ceil(N/16)*16*K floats.
+ * swiglu = 8: the half-tile image (8-row tiles, 32 lanes per half block) for cbx_gemv_t.half_tile; dst holds ceil(N/8)*8*K floats. */
 int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
@@ -222,7 +224,8 @@ typedef struct cbx_t3_layer_t {
 } cbx_t3_layer_t;
 typedef struct cbx_t3_step_t {
     int n_layers, rows, dim, ffn, n_heads, vocab;
-    int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 8 / 4 */
+    int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 8 / 2 */
+    int half_tiles, reserved0;            /* 1: wo / wd are the 8-row-tile images (cbx_gemv_t.half_tile) */
     float eps, attn_scale;
     const cbx_t3_layer_t* layers;         /* HOST array [n_layers] */
     const float *speech_emb, *speech_pos, *final_norm, *head; /* embeddings [V][dim], [P][dim]; tfmr.norm; packed head [ceil16(vocab)][dim] */

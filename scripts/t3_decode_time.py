@@ -15,7 +15,8 @@ B, N = 8, 250
 texts = [synth.text_tokens(64, seed=b) for b in range(B)]
 u = synth.rand((B, N), seed=1)
 res = {}
-VARIANTS = [("v1", {}), ("v2", {}), ("v2", dict(d_ks2=2, d_nw2=8)), ("v2", dict(o_nw2=16)), ("v2", dict(gu_nw=4))]
+VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_ks2=4)), ("v2", dict(half_tiles=1, d_ks2=2)),
+            ("v2", dict(half_tiles=1, d_ks2=2, d_nw2=16)), ("v2", dict(half_tiles=0, d_ks2=2))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:

@@ -595,3 +595,27 @@ def test_gemv_layernorm_fused(dev, M, N, K, npart, act):
     ops.gemv(ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(wd), out, N=N, M=M, K=K, nw=8, w_packed=True, x_packed=True,
              norm_w=lw.to(dev), ln_cw=cw.view(-1), ln_cb=cb.view(-1), act=ops.GELU_TANH if act else ops.NONE, **kw)
     _close(out, ref, 5e-5, "gemv layernorm-fused")
+
+
+@pytest.mark.parametrize("M,N,K,ks,nw,res", [(16, 1024, 4096, 2, 8, False), (16, 1024, 1024, 1, 8, True), (9, 40, 256, 1, 4, False), (16, 1024, 4096, 2, 16, False)])
+def test_gemv_half_tile(dev, M, N, K, ks, nw, res):
+    """8-column output tiles (cbx_gemv_t.half_tile + the swiglu = 8 packed image): same results as the 16-column form, bit for bit."""
+    from chatterbox_amd import ops
+    x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, (N + 31) // 32 * 32), 3)
+    xp = ops.pack_gemv_weight(x.to(dev))
+    w16, w8 = ops.pack_gemv_weight(w.to(dev)), ops.pack_gemv_weight(w.to(dev), half_tile=True)
+    shape = (ks, M, N) if ks > 1 else (M, N)
+    a, b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+    kw = dict(N=N, M=M, K=K, ksplit=ks, nw=nw, w_packed=True, x_packed=True)
+    if res and N % 32 == 0:
+        ra, rb = ops.pack_gemv_weight(r.to(dev)), ops.pack_gemv_weight(r.to(dev))
+        ops.gemv(xp, w16, ra, res=ra, out_packed=True, **kw)
+        ops.gemv(xp, w8, rb, res=rb, out_packed=True, half_tile=True, **kw)
+        assert torch.equal(ra, rb)
+        _close(_unpack_operand(ra, M, N), r[:, :N] + F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "half-tile gemv + residual")
+    else:
+        ops.gemv(xp, w16, a, **kw)
+        ops.gemv(xp, w8, b, half_tile=True, **kw)
+        assert torch.equal(a, b)
+        got = b.sum(0) if ks > 1 else b
+        _close(got, F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "half-tile gemv")

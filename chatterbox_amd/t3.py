@@ -40,7 +40,7 @@ class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
     # decode launch geometry: waves per 16-column tile (nw) / cross-workgroup K splits; *2 = the packed-operand (v2) path
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=4, d_nw2=8, half_tiles=1)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):

@@ -41,7 +41,7 @@ class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("half_tile", c_int), ("out_packed", c_int),
-                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("ln_cw", c_f), ("ln_cb", c_f)]
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("w_bf16", c_int), ("reserved1", c_int), ("ln_cw", c_f), ("ln_cb", c_f)]
 
 
 class SamplerParams(ctypes.Structure):
@@ -61,7 +61,7 @@ class T3Layer(ctypes.Structure):
 
 class T3Step(ctypes.Structure):
     _fields_ = [("n_layers", c_int), ("rows", c_int), ("dim", c_int), ("ffn", c_int), ("n_heads", c_int), ("vocab", c_int),
-                ("o_nw", c_int), ("gu_nw", c_int), ("d_nw", c_int), ("d_ksplit", c_int), ("half_tiles", c_int), ("reserved0", c_int),
+                ("o_nw", c_int), ("gu_nw", c_int), ("d_nw", c_int), ("d_ksplit", c_int), ("half_tiles", c_int), ("w_bf16", c_int),
                 ("eps", c_float), ("attn_scale", c_float),
                 ("layers", ctypes.POINTER(T3Layer)), ("speech_emb", c_f), ("speech_pos", c_f), ("final_norm", c_f), ("head", c_f),
                 ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("kv_row_stride", c_long), ("kv_head_stride", c_long),
@@ -75,6 +75,7 @@ _SIGS = {
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
     "cbx_pack_gemv_weight_f32": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
+    "cbx_pack_gemv_weight_bf16": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
     "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),

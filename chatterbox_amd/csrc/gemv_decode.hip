@@ -24,9 +24,19 @@ namespace {
 // projection are reduced (fixed order) on the way to the MFMA instead of by a separate kernel; workgroup 0 also writes the sum
 // (the new residual stream) to x_out.  Every workgroup re-reads the NP + 1 images from L2: NP * 64 KiB extra per workgroup,
 // which is cheaper than a dependent launch (~1.8 us boundary + a cross-XCD round trip) only for small NP.
-template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP>
+// WB: the packed weight image holds bf16 (cbx_pack_gemv_weight_bf16): half the streamed bytes; a lane's 8 k of a block are ONE 16-byte
+// load, widened to fp32 by a shift (exact), the products stay bf16-weight x fp32-activation in the exact fp32 MFMA.  Opt-in numerics
+// (the weights are rounded): not the parity path.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bf16x4_widen(const u32x4 u, int h) {
+    const unsigned a = h ? u[2] : u[0], b = h ? u[3] : u[1];
+    return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+
+template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
+    static_assert(!WB || (PK && XPK), "bf16 weights: packed operands only");
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
     __shared__ float ssq[RMS ? NW * MT * 16 : 1];
     __shared__ float ssx[RMS ? NW * MT * 16 : 1];  // row sums (LayerNorm form only)
@@ -42,16 +52,23 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     long wrow;
     bool wok;
     const float *wp, *wp2;
-    const int WBLK = PK ? (ht ? 256 : 512) : 32;  // floats between consecutive 32-deep K blocks of this lane's stream
-    const int WHALF = PK ? (ht ? 128 : 256) : 4;  // floats between the two 16-B halves of a block
+    // floats between consecutive 32-deep K blocks of this lane's stream / between the two 16-B halves of a block; the bf16 image is half
+    // as large (one 16-byte load per block: 8 bf16 per lane)
+    const int WBLK = PK ? (ht ? 256 : 512) / (WB ? 2 : 1) : 32;
+    const int WHALF = PK ? (ht ? 128 : 256) : 4;
     if constexpr (PK) {
         // packed image: tile-major [tile][K/32][2][64 lanes][4]; swiglu: feature tile f -> tiles 2f (gate), 2f+1 (up); N is padded
         // to whole tiles by the packer, so every load is in range
         const long kb = p.K >> 5;
         const long tile = SWIGLU ? 2L * blockIdx.x : (long)blockIdx.x;
         wok = !ht || c < 8;
-        wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 256 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
-        wp2 = wp + kb * 512;
+        if constexpr (WB) {  // [tile][K/32][lanes][8 bf16] = 4 floats per lane per block
+            wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 128 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 256 + lane * 4;
+            wp2 = wp + kb * 256;
+        } else {
+            wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 256 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
+            wp2 = wp + kb * 512;
+        }
     } else {
         if constexpr (SWIGLU) {
             const int f = n0 + c;  // feature index
@@ -100,10 +117,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             const int blk = on[d] ? (it0 + d) : 0;
             const int off = blk * WBLK;
             wv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off));
-            wv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + WHALF));
+            if constexpr (!WB) wv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + off + WHALF));
             if constexpr (SWIGLU) {
                 uv[d][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off));
-                uv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + WHALF));
+                if constexpr (!WB) uv[d][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp2 + off + WHALF));
             }
             const int xoff = blk * (XPK ? 512 : 32);
 #pragma unroll
@@ -130,9 +147,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             const bool won = on[d] && wok;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 wq = won ? wv[d][h] : zero4;
-                f32x4 uq = zero4;
-                if constexpr (SWIGLU) uq = won ? uv[d][h] : zero4;
+                f32x4 wq, uq = zero4;
+                if constexpr (WB) {
+                    wq = won ? bf16x4_widen(__builtin_bit_cast(u32x4, wv[d][0]), h) : zero4;
+                    if constexpr (SWIGLU) uq = won ? bf16x4_widen(__builtin_bit_cast(u32x4, uv[d][0]), h) : zero4;
+                } else {
+                    wq = won ? wv[d][h] : zero4;
+                    if constexpr (SWIGLU) uq = won ? uv[d][h] : zero4;
+                }
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     f32x4 xq = xv[d][t][h];
@@ -228,26 +250,38 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     }
 }
 
-template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0>
+template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0, bool WB = false>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     const int tc = (PK && p.half_tile) ? 8 : 16;
     dim3 grid((p.N + tc - 1) / tc, p.ksplit);
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
-            hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0>), grid, dim3(1024), 0, st, p);
+            hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0, WB>), grid, dim3(1024), 0, st, p);
             return cbx_check_launch("gemv");
         }
     }
     if (p.nw >= 8 || NP > 0) {
-        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU, PK, XPK, RMS, NP>), grid, dim3(512), 0, st, p);
+        hipLaunchKernelGGL((gemv_kernel<MT, 8, SWIGLU, PK, XPK, RMS, NP, WB>), grid, dim3(512), 0, st, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU, PK, XPK, RMS, 0>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemv_kernel<MT, 4, SWIGLU, PK, XPK, RMS, 0, WB>), grid, dim3(256), 0, st, p);
     }
     return cbx_check_launch("gemv");
 }
 
 template <int MT, bool SWIGLU>
 int launch_pk(const cbx_gemv_t& p, hipStream_t st) {
+    if (p.w_bf16) {  // checked: w_packed && x_packed, rows <= 16
+        if constexpr (MT == 1) {
+            if (p.norm_w) {
+                if (p.n_xpart == 2) return launch_nw<1, SWIGLU, true, true, true, 2, true>(p, st);
+                if constexpr (!SWIGLU)
+                    if (p.n_xpart == 4) return launch_nw<1, false, true, true, true, 4, true>(p, st);
+                return launch_nw<1, SWIGLU, true, true, true, 0, true>(p, st);
+            }
+            return launch_nw<1, SWIGLU, true, true, false, 0, true>(p, st);
+        }
+        return cbx_set_error(CBX_EINVAL, "gemv: bf16 weights serve M <= 16");
+    }
     if (p.norm_w) {  // checked: w_packed && x_packed && ksplit == 1
         if constexpr (MT == 1) {
             if (p.n_xpart == 2) return launch_nw<1, SWIGLU, true, true, true, 2>(p, st);
@@ -390,7 +424,55 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const float* __re
     *reinterpret_cast<f32x4*>(dst + i4 * 4) = v;
 }
 
+// bf16 image: [tile][K/32][lanes][8 bf16], lane (c, q) holds k = 8q .. 8q+7 of row c; RNE rounding (__float2bfloat16 semantics)
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__global__ __launch_bounds__(256) void pack_gemv_weight_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int N,
+                                                                    int K, long ld, int swiglu, long nl, int half_tile) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (tile, kb, lane): 8 bf16
+    if (i >= nl) return;
+    const int lanes = half_tile ? 32 : 64, rows_t = half_tile ? 8 : 16;
+    const int l = (int)(i % lanes);
+    const long tb = i / lanes;
+    const int KB = K >> 5;
+    const long tile = tb / KB;
+    const int kb = (int)(tb - tile * KB);
+    const int c = l % rows_t, q = l / rows_t;
+    long r;
+    bool ok;
+    if (swiglu) {
+        const long f = (tile >> 1) * 16 + c;
+        ok = f < N;
+        r = (tile & 1) * (long)N + f;
+    } else {
+        r = tile * rows_t + c;
+        ok = r < N;
+    }
+    const float* sp = src + r * ld + kb * 32 + q * 8;
+    unsigned short o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ok ? f32_to_bf16_rne(sp[e]) : (unsigned short)0;
+    uint4 pk;
+    pk.x = o[0] | ((unsigned)o[1] << 16), pk.y = o[2] | ((unsigned)o[3] << 16), pk.z = o[4] | ((unsigned)o[5] << 16), pk.w = o[6] | ((unsigned)o[7] << 16);
+    *reinterpret_cast<uint4*>(dst + i * 8) = pk;
+}
+
 }  // namespace
+
+extern "C" int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream) {
+    CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight_bf16: bad args (K %% 32, ld %% 4)");
+    const int half_tile = swiglu == 8;
+    if (half_tile) swiglu = 0;
+    const long tiles = half_tile ? (N + 7) / 8 : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
+    const long nl = tiles * (K / 32) * (half_tile ? 32 : 64);
+    hipLaunchKernelGGL(pack_gemv_weight_bf16_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (unsigned short*)dst, N, K, ld_src, swiglu, nl, half_tile);
+    return cbx_check_launch("pack_gemv_weight_bf16");
+}
 
 extern "C" int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream) {
     CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight: bad args (K %% 32, ld %% 4)");
@@ -415,6 +497,7 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(!p.swiglu || (p.ksplit == 1 && p.N % 32 == 0), "gemv: swiglu needs ksplit == 1 and N %% 32 == 0");
     CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
     CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
+    CBX_REQUIRE(!p.w_bf16 || (p.w_packed && p.x_packed && p.M <= 16), "gemv: w_bf16 needs w_packed, x_packed and M <= 16");
     CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && p.ksplit == 1), "gemv: norm_w needs w_packed, x_packed and ksplit == 1");
     CBX_REQUIRE(!p.res || p.ksplit == 1, "gemv: res needs ksplit == 1");
     CBX_REQUIRE(!p.ln_cw || (p.norm_w && p.ln_cb && !p.swiglu && !p.bias), "gemv: the LayerNorm form needs norm_w, ln_cb, no swiglu, bias folded into ln_cb");

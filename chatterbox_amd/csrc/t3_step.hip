@@ -20,7 +20,7 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     auto base = [&](const float* x, const float* W, float* out, int N, int K) {
         g = cbx_gemv_t{};
         g.x = x, g.W = W, g.out = out, g.M = d->rows, g.N = N, g.K = K, g.ksplit = 1, g.nw = 8;
-        g.w_packed = g.x_packed = 1, g.eps = d->eps, g.ldx = K, g.ldw = K, g.ldo = N;
+        g.w_packed = g.x_packed = 1, g.eps = d->eps, g.ldx = K, g.ldw = K, g.ldo = N, g.w_bf16 = d->w_bf16;
     };
     const long img = (long)((d->rows + 15) / 16 * 16) * D;  // floats per packed residual / partial image
     bool pending = false;                                     // split-K partial images of the previous down projection waiting to be summed

@@ -31,8 +31,9 @@ def drop_invalid_tokens(x):
 
 
 class ChatterboxEngine:
-    def __init__(self, t3_sd, s3gen_sd, device="cuda", n_t3_layers=None, meanflow=False):
+    def __init__(self, t3_sd, s3gen_sd, device="cuda", n_t3_layers=None, meanflow=False, t3_weights=None):
         self.dev = torch.device(device)
+        self.t3_weights = t3_weights  # None / "fp32" (parity path) or "bf16" (opt-in: decode weight images rounded to bf16)
         self.t3 = self._build_t3(t3_sd, n_t3_layers)
         self.flow = FlowEngine(s3gen_sd, self.dev, meanflow=meanflow)
         self.hift = HiFTEngine(s3gen_sd, self.dev)
@@ -43,15 +44,15 @@ class ChatterboxEngine:
         keyed by a fingerprint of the checkpoint, and map it straight to the device on later starts (formats.py)."""
         cache = os.environ.get("CBX_PACK_CACHE")
         if not cache:
-            return T3Engine(t3_sd, self.dev, n_layers=n_layers)
+            return T3Engine(t3_sd, self.dev, n_layers=n_layers, weights=self.t3_weights)
         from . import formats
         fp = formats.fingerprint(t3_sd) + f"-L{n_layers}"
         path = os.path.join(cache, f"t3_{fp}.cbxpack")
-        kind = "t3-llama-" + os.environ.get("CBX_T3_DECODE", "v2")
+        kind = "t3-llama-" + os.environ.get("CBX_T3_DECODE", "v2") + "-" + (self.t3_weights or os.environ.get("CBX_T3_WEIGHTS", "fp32"))
         t = formats.load_packed(path, fp, kind)
         if t is not None:
             return T3Engine.from_packed(t, self.dev)
-        eng = T3Engine(t3_sd, self.dev, n_layers=n_layers)
+        eng = T3Engine(t3_sd, self.dev, n_layers=n_layers, weights=self.t3_weights)
         os.makedirs(cache, exist_ok=True)
         formats.save_packed(eng.export_packed(), path, fp, kind)
         return eng

@@ -165,13 +165,17 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
-def pack_gemv_weight(w, swiglu=False, half_tile=False):
+def pack_gemv_weight(w, swiglu=False, half_tile=False, bf16=False):
     """(N, K) fp32 weight [swiglu: (2F, K) = gate rows then up rows] -> lane-ordered packed image of cbx_gemv_f32 (w_packed = 1):
     (ceil(N/16)*16, K) floats [swiglu: (2*ceil(F/16)*16, K)].  Done once at load (weights are constants)."""
     w = _f32(w, "w").contiguous()
     R, K = w.shape
     N = R // 2 if swiglu else R
     rows = (N + 7) // 8 * 8 if half_tile else (N + 15) // 16 * 16 * (2 if swiglu else 1)
+    if bf16:  # opt-in decode numerics: weights rounded to bf16 (cbx_gemv_t.w_bf16), half the streamed bytes
+        out = torch.empty(rows, K, dtype=torch.bfloat16, device=w.device)
+        check(lib.cbx_pack_gemv_weight_bf16(_p(w), _p(out), N, K, w.stride(0), 8 if half_tile else int(swiglu), _stream()), "cbx_pack_gemv_weight_bf16")
+        return out
     out = torch.empty(rows, K, device=w.device)
     check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), 8 if half_tile else int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
     return out
@@ -190,10 +194,12 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
         M, K = x.shape
     N = N or (w.shape[0] // 2 if swiglu else w.shape[0])
     p = GemvParams()
-    p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
+    w_bf16 = w.dtype == torch.bfloat16
+    assert not w_bf16 or (w_packed and x_packed), "bf16 weights are a packed-operand feature"
+    p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(w if w_bf16 else _f32(w, "w")), _p(bias), _p(_f32(out, "out"))
     p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu, p.act = M, N, K, ksplit, nw, int(swiglu), act
     p.ldx, p.ldw = x.stride(0), w.stride(0)
-    p.w_packed, p.x_packed, p.half_tile = int(w_packed), int(x_packed), int(half_tile)
+    p.w_packed, p.x_packed, p.half_tile, p.w_bf16 = int(w_packed), int(x_packed), int(half_tile), int(w_bf16)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
     if xpart is not None:

@@ -43,7 +43,7 @@ class T3Engine:
     _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1)
 
     @ops.on_device
-    def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608):
+    def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weights=None):
         self.dev = torch.device(device)
         if n_layers is None:
             n_layers = 0
@@ -62,22 +62,28 @@ class T3Engine:
                 wd=d(sd[p + "mlp.down_proj.weight"])))
         # decode path: the same weights in the lane-ordered packed layout of cbx_gemv_f32 (every wave-level load is 1 KiB contiguous)
         self.decode_mode = os.environ.get("CBX_T3_DECODE", "v2")
+        # OPT-IN decode numerics (CBX_T3_WEIGHTS=bf16 / T3Engine(weights="bf16")): the decode-step weight images are rounded to bf16
+        # (half the streamed bytes; activations, accumulation, KV cache and the prefill stay fp32).  Not the parity path: sampled
+        # tokens differ from the fp32 reference's; stated bound: first-step logits within 5e-2 (SURVEY.md 8d bf16 mode).
+        self.weight_dtype = weights or os.environ.get("CBX_T3_WEIGHTS", "fp32")
+        assert self.weight_dtype in ("fp32", "bf16") and (self.weight_dtype == "fp32" or self.decode_mode == "v2")
+        bf = self.weight_dtype == "bf16"
         if self.decode_mode == "v2":
             for i, lw in enumerate(self.layers):
                 p = f"tfmr.layers.{i}."
-                lw["wqkv_pk"] = ops.pack_gemv_weight(lw["wqkv"])
-                lw["wo_pk"] = ops.pack_gemv_weight(lw["wo"])
-                lw["wgu_pk"] = ops.pack_gemv_weight(d(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)), swiglu=True)
-                lw["wd_pk"] = ops.pack_gemv_weight(lw["wd"])
+                lw["wqkv_pk"] = ops.pack_gemv_weight(lw["wqkv"], bf16=bf)
+                lw["wo_pk"] = ops.pack_gemv_weight(lw["wo"], bf16=bf)
+                lw["wgu_pk"] = ops.pack_gemv_weight(d(torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)), swiglu=True, bf16=bf)
+                lw["wd_pk"] = ops.pack_gemv_weight(lw["wd"], bf16=bf)
                 if self._TUNE.get("half_tiles"):  # 8-column tiles for the two N = 1024 projections (128 instead of 64 output tiles)
-                    lw["wo_pk8"] = ops.pack_gemv_weight(lw["wo"], half_tile=True)
-                    lw["wd_pk8"] = ops.pack_gemv_weight(lw["wd"], half_tile=True)
+                    lw["wo_pk8"] = ops.pack_gemv_weight(lw["wo"], half_tile=True, bf16=bf)
+                    lw["wd_pk8"] = ops.pack_gemv_weight(lw["wd"], half_tile=True, bf16=bf)
         self.norm = d(sd["tfmr.norm.weight"])
         self.text_emb, self.speech_emb = d(sd["text_emb.weight"]), d(sd["speech_emb.weight"])
         self.text_pos, self.speech_pos = d(sd["text_pos_emb.emb.weight"]), d(sd["speech_pos_emb.emb.weight"])
         self.head = d(sd["speech_head.weight"])
         self.V = self.head.shape[0]
-        self.head_pk = ops.pack_gemv_weight(self.head) if self.decode_mode == "v2" else None
+        self.head_pk = ops.pack_gemv_weight(self.head, bf16=bf) if self.decode_mode == "v2" else None
         c = "cond_enc."
         self.spkr_w, self.spkr_b = d(sd[c + "spkr_enc.weight"]), d(sd[c + "spkr_enc.bias"])
         self.emo_w = d(sd[c + "emotion_adv_fc.weight"].view(-1))
@@ -125,6 +131,7 @@ class T3Engine:
             setattr(self, k, (d(t[k + ".0"]), d(t[k + ".1"])))
         self.V = self.head.shape[0]
         self.decode_mode = "v2" if self.head_pk is not None else "v1"
+        self.weight_dtype = "bf16" if (self.head_pk is not None and self.head_pk.dtype == torch.bfloat16) else "fp32"
         self.max_pos = self.cos.shape[0]
         self._state = {}
         self.time_decode, self.decode_events = False, []
@@ -267,6 +274,7 @@ class T3Engine:
             d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = self.L, st["rows"], self.D, self.F, self.H, self.V
             d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.eps, d.attn_scale = tn["o_nw2"], tn["gu_nw"], tn["d_nw2"], tn["d_ks2"], 1e-5, 0.125
             d.half_tiles = int(bool(tn.get("half_tiles")) and "wo_pk8" in self.layers[0])
+            d.w_bf16 = int(self.head_pk.dtype == torch.bfloat16)
             d.layers = layers
             d.speech_emb, d.speech_pos, d.final_norm, d.head = p(self.speech_emb), p(self.speech_pos), p(self.norm), p(self.head_pk)
             d.cos_t, d.sin_t, d.kc, d.vc = p(self.cos), p(self.sin), p(st["kc"]), p(st["vc"])

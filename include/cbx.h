@@ -94,6 +94,8 @@ typedef struct cbx_gemv_t {
     const float* xpart;  /* [n_xpart] images, xpart_stride floats apart */
     long xpart_stride;
     float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it) */
+    int w_bf16;          /* W is a cbx_pack_gemv_weight_bf16 image (opt-in: weights rounded to bf16, half the streamed bytes; M <= 16) */
+    int reserved1;
     const float* ln_cw;  /* or NULL: LayerNorm instead of RMSNorm (GPT-2 ln_1 / ln_2 / ln_f): with norm_w = LN weight w, ln_cw[n] = */
     const float* ln_cb;  /* sum_k w[k] W[n][k] and ln_cb[n] = sum_k b[k] W[n][k] + bias[n] (constants of the layer, computed at load): */
                          /* out[m][n] = rstd[m] (sum_k x w W - mean[m] ln_cw[n]) + ln_cb[n], then `act` */
@@ -105,6 +107,8 @@ typedef struct cbx_gemv_t {
  * the tiles are interleaved gate/up per 16 features.  dst must hold ceil(N/16)*16*K floats.
  * swiglu = 8: the half-tile image (8-row tiles, 32 lanes per half block) for cbx_gemv_t.half_tile; dst holds ceil(N/8)*8*K floats. */
 int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream);
+/* the same image with the weights rounded (RNE) to bf16: [tile][K/32][lanes][8 bf16] (cbx_gemv_t.w_bf16); dst holds half the bytes */
+int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
@@ -225,7 +229,7 @@ typedef struct cbx_t3_layer_t {
 typedef struct cbx_t3_step_t {
     int n_layers, rows, dim, ffn, n_heads, vocab;
     int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 8 / 2 */
-    int half_tiles, reserved0;            /* 1: wo / wd are the 8-row-tile images (cbx_gemv_t.half_tile) */
+    int half_tiles, w_bf16;               /* 1: wo / wd are the 8-row-tile images (cbx_gemv_t.half_tile); 1: all weight images are bf16 */
     float eps, attn_scale;
     const cbx_t3_layer_t* layers;         /* HOST array [n_layers] */
     const float *speech_emb, *speech_pos, *final_norm, *head; /* embeddings [V][dim], [P][dim]; tfmr.norm; packed head [ceil16(vocab)][dim] */

@@ -619,3 +619,40 @@ def test_gemv_half_tile(dev, M, N, K, ks, nw, res):
         assert torch.equal(a, b)
         got = b.sum(0) if ks > 1 else b
         _close(got, F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "half-tile gemv")
+
+
+@pytest.mark.parametrize("case", ["plain", "rms_swiglu", "half_ks2", "rms_np2"])
+def test_gemv_bf16_weights_equal_rounded_fp32(dev, case):
+    """Opt-in bf16 decode weights (cbx_pack_gemv_weight_bf16 / cbx_gemv_t.w_bf16): bit-identical to the fp32 kernel run on the
+    bf16-ROUNDED weights (the widening is exact and the MFMA order is the same), i.e. the only deviation is the rounding itself."""
+    from chatterbox_amd import ops
+    M, K = 16, 1024
+    x = _r((M, K), 1)
+    xp = ops.pack_gemv_weight(x.to(dev))
+    kw = dict(M=M, K=K, w_packed=True, x_packed=True, nw=8)
+    if case == "rms_swiglu":
+        N = 4096
+        w = _r((2 * N, K), 2, 1 / math.sqrt(K))
+        kw.update(N=N, swiglu=True, norm_w=(1 + 0.1 * _r((K,), 3)).to(dev))
+        pk = dict(swiglu=True)
+    elif case == "half_ks2":
+        N, K = 1024, 4096
+        x = _r((M, K), 1)
+        xp = ops.pack_gemv_weight(x.to(dev))
+        w = _r((N, K), 2, 1 / math.sqrt(K))
+        kw.update(N=N, K=K, ksplit=2, half_tile=True)
+        pk = dict(half_tile=True)
+    else:
+        N = 3072
+        w = _r((N, K), 2, 1 / math.sqrt(K))
+        kw.update(N=N)
+        pk = {}
+        if case == "rms_np2":
+            parts = torch.stack([ops.pack_gemv_weight(_r((M, K), 5 + j, 0.3).to(dev)) for j in range(2)])
+            kw.update(norm_w=(1 + 0.1 * _r((K,), 3)).to(dev), xpart=parts, x_out=torch.zeros(16, K, device=dev))
+    wr = w.bfloat16().float()
+    shape = (2, M, N) if kw.get("ksplit", 1) > 1 else (M, N)
+    a, b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+    ops.gemv(xp, ops.pack_gemv_weight(w.to(dev), bf16=True, **pk), a, **kw)
+    ops.gemv(xp, ops.pack_gemv_weight(wr.to(dev), **pk), b, **kw)
+    assert torch.equal(a, b), f"{case}: bf16-weight kernel != fp32 kernel on rounded weights (max {float((a - b).abs().max()):.3e})"

@@ -44,7 +44,7 @@ class ChatterboxEngine:
         keyed by a fingerprint of the checkpoint, and map it straight to the device on later starts (formats.py)."""
         cache = os.environ.get("CBX_PACK_CACHE")
         if not cache:
-            return T3Engine(t3_sd, self.dev, n_layers=n_layers, weights=self.t3_weights)
+            return T3Engine(t3_sd, self.dev, n_layers=n_layers, weight_dtype=self.t3_weights)
         from . import formats
         fp = formats.fingerprint(t3_sd) + f"-L{n_layers}"
         path = os.path.join(cache, f"t3_{fp}.cbxpack")
@@ -52,7 +52,7 @@ class ChatterboxEngine:
         t = formats.load_packed(path, fp, kind)
         if t is not None:
             return T3Engine.from_packed(t, self.dev)
-        eng = T3Engine(t3_sd, self.dev, n_layers=n_layers, weights=self.t3_weights)
+        eng = T3Engine(t3_sd, self.dev, n_layers=n_layers, weight_dtype=self.t3_weights)
         os.makedirs(cache, exist_ok=True)
         formats.save_packed(eng.export_packed(), path, fp, kind)
         return eng

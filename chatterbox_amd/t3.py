@@ -43,7 +43,7 @@ class T3Engine:
     _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1)
 
     @ops.on_device
-    def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weights=None):
+    def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
         self.dev = torch.device(device)
         if n_layers is None:
             n_layers = 0
@@ -62,10 +62,10 @@ class T3Engine:
                 wd=d(sd[p + "mlp.down_proj.weight"])))
         # decode path: the same weights in the lane-ordered packed layout of cbx_gemv_f32 (every wave-level load is 1 KiB contiguous)
         self.decode_mode = os.environ.get("CBX_T3_DECODE", "v2")
-        # OPT-IN decode numerics (CBX_T3_WEIGHTS=bf16 / T3Engine(weights="bf16")): the decode-step weight images are rounded to bf16
+        # OPT-IN decode numerics (CBX_T3_WEIGHTS=bf16 / T3Engine(weight_dtype="bf16")): the decode-step weight images are rounded to bf16
         # (half the streamed bytes; activations, accumulation, KV cache and the prefill stay fp32).  Not the parity path: sampled
         # tokens differ from the fp32 reference's; stated bound: first-step logits within 5e-2 (SURVEY.md 8d bf16 mode).
-        self.weight_dtype = weights or os.environ.get("CBX_T3_WEIGHTS", "fp32")
+        self.weight_dtype = weight_dtype or os.environ.get("CBX_T3_WEIGHTS", "fp32")
         assert self.weight_dtype in ("fp32", "bf16") and (self.weight_dtype == "fp32" or self.decode_mode == "v2")
         bf = self.weight_dtype == "bf16"
         if self.decode_mode == "v2":

@@ -79,13 +79,26 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
                                                                const float* __restrict__ post_add, long rows, long ldx, long ldy,
                                                                float eps, int rms, int act, float out_scale) {
     constexpr int C = 64 * NV;
+    constexpr int RPT = 2;  // rows per 16-lane group: 2 x NV float4 loads in flight per lane (8 KiB per wave per round trip)
     const int l16 = threadIdx.x & 15;
-    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = row < rows;
-    const float* xr = x + (live ? row : rows - 1) * ldx;  // unconditional loads on a clamped row
-    f32x4 v[NV];
+    const long row0 = (long)blockIdx.x * (16 * RPT) + (threadIdx.x >> 4);
+    f32x4 v[RPT][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 16 + l16) * 4);
+    for (int r = 0; r < RPT; ++r) {
+        const long row = row0 + 16 * r;
+        const float* xr = x + (row < rows ? row : rows - 1) * ldx;  // unconditional loads on a clamped row
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[r][i] = *reinterpret_cast<const f32x4*>(xr + (i * 16 + l16) * 4);
+    }
+    // per-channel parameters: loaded once, shared by both rows
+    f32x4 wv[NV], bv[NV], pv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 16 + l16) * 4;
+        wv[i] = *reinterpret_cast<const f32x4*>(w + c);
+        bv[i] = b ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pv[i] = post_add ? *reinterpret_cast<const f32x4*>(post_add + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto group_sum = [](float t) {
         t += __shfl_xor(t, 8);
         t += __shfl_xor(t, 4);
@@ -93,44 +106,45 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
         t += __shfl_xor(t, 1);
         return t;
     };
-    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        s += rms ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
-                 : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
-    s = group_sum(s);
-    float mean = 0.f, rstd;
-    if (rms) {
-        rstd = rsqrtf(s / C + eps);
-    } else {
-        mean = s / C;
-        float q = 0.f;
+    for (int r = 0; r < RPT; ++r) {
+        const long row = row0 + 16 * r;
+        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
+            s += rms ? (v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1] + v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3])
+                     : (v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3]);
+        s = group_sum(s);
+        float mean = 0.f, rstd;
+        if (rms) {
+            rstd = rsqrtf(s / C + eps);
+        } else {
+            mean = s / C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[r][i][e] - mean;
+                    q += d * d;
+                }
+            q = group_sum(q);
+            rstd = rsqrtf(q / C + eps);
+        }
+        if (row >= rows) continue;
+        float* yr = y + row * ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 16 + l16) * 4;
+            f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                q += d * d;
+                float t = (v[r][i][e] - mean) * rstd * wv[i][e] + bv[i][e];
+                t = cbx_act(t, act, 0.f, 0.f);
+                o[e] = t * out_scale + pv[i][e];
             }
-        q = group_sum(q);
-        rstd = rsqrtf(q / C + eps);
-    }
-    float* yr = y + row * ldy;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 16 + l16) * 4;
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
-        if (b) bv = *reinterpret_cast<const f32x4*>(b + c);
-        if (post_add) pv = *reinterpret_cast<const f32x4*>(post_add + c);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = (v[i][e] - mean) * rstd * wv[e] + bv[e];
-            t = cbx_act(t, act, 0.f, 0.f);
-            o[e] = t * out_scale + pv[e];
+            *reinterpret_cast<f32x4*>(yr + c) = o;
         }
-        if (live) *reinterpret_cast<f32x4*>(yr + c) = o;
     }
 }
 
@@ -144,7 +158,7 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     if (rows <= 0) return 0;
     static const int narrow = getenv("CBX_LN_NARROW") ? atoi(getenv("CBX_LN_NARROW")) : 1;
     if (narrow && C == 256 && rows >= 64) {
-        hipLaunchKernelGGL(layernorm_narrow_kernel<4>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+        hipLaunchKernelGGL(layernorm_narrow_kernel<4>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, y, w,
                            b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
         return cbx_check_launch("layernorm");
     }

@@ -7,8 +7,9 @@ generate() = T3 -> S3Gen (10-step CFM, CFG) -> HiFT, Multilingual-V3 500M archit
 A "step" is one pass of the whole hot path over one batch of synthetic utterances: 64 text tokens,
 250 speech tokens (10 s of audio, EOS banned so the length is fixed), 150-token T3 voice prompt, 250-token / 500-frame
 S3Gen prompt, seeded random-init weights in the reference's checkpoint layout (no network => no pretrained weights).
-Prints ONE JSON line (rank 0).  The headline `value` runs S3Gen in the fp32-level numerics mode (bf16x6 split operands; T3 is exact
-fp32 MFMA); the opt-in bf16x3 fast mode is measured by the same run and reported beside it, clearly labelled.  `roofline` is the
+Prints ONE JSON line (rank 0).  The headline `value` runs S3Gen in the default fp32-level numerics mode (f16x3: two fp16 planes per fp32
+operand, range-checked on the device; T3 is exact fp32 MFMA); the other fp32-level mode (bf16x6) and the opt-in bf16x3 fast mode are
+measured by the same run and reported beside it, clearly labelled.  `roofline` is the
 dominant kernel class (T3 decode weight streaming); `decode_step` is the whole decode step (weights + KV cache) timed with HIP events
 INSIDE the timed region; `cpu_baseline` is the reference itself (kind "reference", when /root/reference is present) or the oracle
 (kind "port", a CPU restatement pinned against the reference) on ONE utterance of the benched workload.
@@ -49,9 +50,10 @@ def parse():
     ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "gemm_split", "flash_attn_f32", "gemv_f32"],
                     help="kernel class reported as `roofline` (auto: the one with the largest share of a step); the others go to "
                          "`roofline_secondary`.  All three are timed with HIP events on the launch stream")
-    ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6],
-                    help="numerics of the S3Gen GEMMs / attention: 1 exact fp32 MFMA, 6 bf16x6 (default: fp32-level error, every fp32 parity "
-                         "tolerance holds), 3 bf16x3 (opt-in fast mode, bf16-mode tolerances).  T3 is always exact fp32")
+    ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6, 16],
+                    help="numerics of the S3Gen GEMMs / attention: 1 exact fp32 MFMA, 16 f16x3 (default: fp32-level error, every fp32 parity "
+                         "tolerance holds; fp16 operand range, checked on the device), 6 bf16x6 (fp32-level, fp32 range), 3 bf16x3 (opt-in "
+                         "fast mode, bf16-mode tolerances).  T3 is always exact fp32")
     ap.add_argument("--no-alt-precisions", action="store_true",
                     help="skip the extra steps measured after the timed region at the other S3Gen precisions (default: bf16x3 is measured "
                          "and reported under audio_s_per_wall_s_at_other_precisions; --all-precisions adds exact fp32)")
@@ -166,11 +168,12 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
     stream.  gemv: the decode step's projections replayed from a hipGraph (the form they run in inside the timed region, where
     events cannot see individual graph nodes) -- one graph per projection type sweeping the 30 layers' weights, events around it."""
     out = {}
-    nprod = {3: 3, 6: 6}.get(s3_prec, 1)
+    nprod = {3: 3, 6: 6, 16: 3}.get(s3_prec, 1)
+    pname = {3: "bf16x3", 6: "bf16x6", 16: "f16x3"}.get(s3_prec, "")
     names = {"gemm_f32": ("gemm_f32_kernel (exact fp32 MFMA implicit GEMM: T3 prefill, shapes the split kernel does not serve)",
                           "gemm_f32_kernel", 1),
-             "gemm_split": ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, bf16x%d)" % nprod, "gemm_split_kernel", nprod),
-             "flash_attn_f32": (("flash_attn_split_kernel (bf16x%d)" % nprod) if nprod > 1 else "flash_attn_f32_kernel",
+             "gemm_split": ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, %s)" % pname, "gemm_split_kernel", nprod),
+             "flash_attn_f32": (("flash_attn_split_kernel (%s)" % pname) if nprod > 1 else "flash_attn_f32_kernel",
                                 "flash_attn_split_kernel" if nprod > 1 else "flash_attn_f32_kernel", nprod)}
     for kind, (kname, sub, npr) in names.items():
         ks = summ.get(kind)
@@ -189,9 +192,10 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
                  share_of_step=round(ks["ms"] * 1e-3 / timed_steps / (elapsed / steps), 3))
         if npr > 1:
             e["fp32_equivalent_tflops"] = round(tf, 2)
-            e["note"] = (f"achieved = algorithmic fp32 FLOPs x {npr} bf16 MFMA products per fp32 product (the work the matrix cores "
-                         f"execute), priced against the dense bf16 peak; {round(tf, 1)} TFLOP/s fp32-equivalent = "
-                         f"{round(tf / MFMA_F32_PEAK_TFLOPS, 2)}x the exact-fp32 MFMA peak")
+            e["note"] = (f"achieved = algorithmic fp32 FLOPs x {npr} 16-bit MFMA products per fp32 product (the work the matrix cores "
+                         f"execute), priced against the dense bf16 / fp16 peak; {round(tf, 1)} TFLOP/s fp32-equivalent = "
+                         f"{round(tf / MFMA_F32_PEAK_TFLOPS, 2)}x the exact-fp32 MFMA peak.  f16x3 issues half the products of bf16x6 for the "
+                         f"same fp32-level result, so its fraction of the 16-bit peak is lower while its time per launch is 1.45x shorter")
         tr, src = pmc_traffic(sub, "t3_eager" if kind == "gemm_f32" else "flow_only")
         e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
         out[kind] = e
@@ -454,7 +458,7 @@ def main():
             dstep = decode_step_entry(eng.t3, args.t3_layers)
             gemv = gemv_sweeps(eng.t3, 2 * B)
             if not args.no_alt_precisions and world == 1:  # one_step() contains the C2 collective: single-rank runs only
-                for pr in ((1, 6, 3) if args.all_precisions else (6, 3)):
+                for pr in ((1, 16, 6, 3) if args.all_precisions else (16, 6, 3)):
                     if pr == s3_prec:
                         continue
                     eng.flow.precision = eng.hift.precision = pr
@@ -509,7 +513,10 @@ def main():
             "value": round(audio / elapsed, 3), "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if s3_prec == 1 else
-                     ("f32 (T3: exact fp32 MFMA; S3Gen: every fp32 operand = 3 bf16 planes = all 24 significand bits, 6 MFMA products per fp32 product, "
+                     ("f32 (T3: exact fp32 MFMA; S3Gen: every fp32 operand = 2 fp16 planes h + l/2048 = 22 significand bits, 3 fp16 MFMA products "
+                      "per fp32 product in two fp32 accumulators: error at or below the exact-fp32 MFMA path; operand range checked on the "
+                      "device, bf16x6 repeat otherwise)" if s3_prec == 16 else
+                      "f32 (T3: exact fp32 MFMA; S3Gen: every fp32 operand = 3 bf16 planes = all 24 significand bits, 6 MFMA products per fp32 product, "
                       "fp32 accumulate: error at or below the exact-fp32 MFMA path)" if s3_prec == 6 else
                       "f32 operands, bf16x3 FAST MODE for S3Gen (2 bf16 planes, 3 MFMA products: 16 significand bits per operand; narrower than the "
                       "reference's fp32 -- not the headline configuration)"),
@@ -529,7 +536,8 @@ def main():
         }
         if alt:
             labels = {"s3gen_precision_3": "s3gen_bf16x3_fast_mode (narrower than the reference's fp32; bf16-mode tolerances)",
-                      "s3gen_precision_1": "s3gen_exact_fp32_mfma", "s3gen_precision_6": "s3gen_bf16x6",
+                      "s3gen_precision_1": "s3gen_exact_fp32_mfma", "s3gen_precision_6": "s3gen_bf16x6 (fp32-level, fp32 exponent range)",
+                      "s3gen_precision_16": "s3gen_f16x3 (fp32-level)",
                       "fast_mode": "full_fast_mode: s3gen bf16x3 + T3 decode weights rounded to bf16 (NOT fp32 parity: tokens differ from the reference's)"}
             out["audio_s_per_wall_s_at_other_precisions"] = {labels.get(k, k): v for k, v in alt.items()}
         if cfg3:

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 4  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 5  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -85,6 +85,7 @@ _SIGS = {
     "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
     "cbx_set_split_tile": ([c_int], c_int),
+    "cbx_set_range_flag": ([c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
     "cbx_axpby_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_float, c_f], c_int),

@@ -1,6 +1,7 @@
 // Flash attention (head_dim 64) on the bf16 matrix cores with split fp32 operands ("bf16x3" / "bf16x6", see
 // gemm_split.hip for the arithmetic): same swapped formulation, tiling and masking semantics as flash_attn_f32_kernel
-// (attention.hip), 5.3x / 2.7x fewer matrix-core cycles per KV tile.
+// (attention.hip), 5.3x / 2.7x fewer matrix-core cycles per KV tile.  F16 = the f16x3 form (two fp16 planes, the second scaled by
+// 2048 and its products kept in a second accumulator; fp32-level at the bf16x3 cost, fp16 operand range -> cbx_set_range_flag).
 //
 //   S^T = K Q^T : A = K tile from LDS planes [key][d]   (lane: key = lane&31, d = 16kc + 8*(lane>>5) .. +8)
 //                 B = Q^T held in registers as planes   (lane: query = lane&31, same d)
@@ -16,6 +17,8 @@ namespace {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int FKT = 64;   // keys per tile
 constexpr int FLD = 72;   // LDS row stride in bf16 (144 B: odd multiple of 16 B -> conflict-free ds_read_b128)
@@ -29,8 +32,15 @@ struct FlashSplitArgs {
     int causal;
 };
 
-template <int NP>
+template <int NP, bool F16>
 __device__ __forceinline__ void split8(const f32x8 v, bf16x8 (&out)[NP]) {
+    if constexpr (F16) {
+        const f16x8 h = __builtin_convertvector(v, f16x8);
+        const f32x8 r = (v - __builtin_convertvector(h, f32x8)) * CBX_F16_LO_SCALE;
+        out[0] = __builtin_bit_cast(bf16x8, h);
+        out[1] = __builtin_bit_cast(bf16x8, __builtin_convertvector(r, f16x8));
+        return;
+    }
     out[0] = __builtin_convertvector(v, bf16x8);
     f32x8 r = v - __builtin_convertvector(out[0], f32x8);
     out[1] = __builtin_convertvector(r, bf16x8);
@@ -41,6 +51,19 @@ __device__ __forceinline__ void split8(const f32x8 v, bf16x8 (&out)[NP]) {
 }
 
 // acc += sum over the plane products above the fp32 rounding level (smallest first)
+__device__ __forceinline__ unsigned out_of_f16(const f32x4 v) {
+    return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f ? 1u : 0u;
+}
+
+// F16: acc += h*h, accc += h*l + l*h (2048 times too large)
+__device__ __forceinline__ void mma_f16(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16& acc, f32x16& accc) {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a[0]), al = __builtin_bit_cast(f16x8, a[1]);
+    const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[1]);
+    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc, 0, 0, 0);
+    accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
 template <int NP>
 __device__ __forceinline__ f32x16 mma_split(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 acc) {
     if constexpr (NP == 3) {
@@ -54,8 +77,10 @@ __device__ __forceinline__ f32x16 mma_split(const bf16x8 (&a)[NP], const bf16x8 
     return acc;
 }
 
-template <int NP>
-__global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSplitArgs a) {
+template <int NP, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSplitArgs a, int* range_flag) {
+    static_assert(!F16 || NP == 2, "the fp16 form has two planes");
+    unsigned oor = 0;
     // planes: K [NP][64 keys][FLD], then V^T [NP][64 d][FLD]
     __shared__ __attribute__((aligned(16))) __bf16 Ks[NP * FPLANE];
     __shared__ __attribute__((aligned(16))) __bf16 Vt[NP * FPLANE];
@@ -84,15 +109,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
             const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * kc + 4);
             f32x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
             t *= sc;
-            split8<NP>(t, qf[kc]);
+            if constexpr (F16) oor |= out_of_f16(t0 * sc) | out_of_f16(t1 * sc);
+            split8<NP, F16>(t, qf[kc]);
         }
     }
 
-    f32x16 ot[2];
+    f32x16 ot[2], otc[2];  // otc: cross-product accumulator of the F16 form
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+        for (int r = 0; r < 16; ++r) ot[d][r] = otc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     int kend = klen;
@@ -134,7 +160,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
             const f32x4 x0 = kok ? kreg[2 * c2] : zero, x1 = kok ? kreg[2 * c2 + 1] : zero;
             const f32x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             bf16x8 pl[NP];
-            split8<NP>(x, pl);
+            if constexpr (F16) oor |= out_of_f16(x0) | out_of_f16(x1);
+            split8<NP, F16>(x, pl);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(&Ks[q * FPLANE + k_row * FLD + k_c + 8 * c2]) = pl[q];
         }
@@ -145,10 +172,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const f32x4 col = {vv[0][e], vv[1][e], vv[2][e], vv[3][e]};  // keys 4g..4g+3 at d = 4dq + e
+            __bf16* dst = &Vt[(4 * v_dq + e) * FLD + v_pos];
+            if constexpr (F16) {
+                const f16x4 hh = __builtin_convertvector(col, f16x4);
+                const f32x4 rr = (col - __builtin_convertvector(hh, f32x4)) * CBX_F16_LO_SCALE;
+                *reinterpret_cast<f16x4*>(dst) = hh;
+                *reinterpret_cast<f16x4*>(dst + FPLANE) = __builtin_convertvector(rr, f16x4);
+                oor |= out_of_f16(col);
+                continue;
+            }
             bf16x4 h = __builtin_convertvector(col, bf16x4);
             f32x4 r = col - __builtin_convertvector(h, f32x4);
             bf16x4 m = __builtin_convertvector(r, bf16x4);
-            __bf16* dst = &Vt[(4 * v_dq + e) * FLD + v_pos];
             *reinterpret_cast<bf16x4*>(dst) = h;
             *reinterpret_cast<bf16x4*>(dst + FPLANE) = m;
             if constexpr (NP == 3) {
@@ -169,16 +204,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
         f32x16 st[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            f32x16 stc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+            for (int r = 0; r < 16; ++r) st[t][r] = stc[r] = 0.f;
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 bf16x8 kf[NP];
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
                     kf[q] = *reinterpret_cast<const bf16x8*>(&Ks[q * FPLANE + (t * 32 + lr) * FLD + 16 * kc + 8 * lh]);
-                st[t] = mma_split<NP>(kf, qf[kc], st[t]);
+                if constexpr (F16) mma_f16(kf, qf[kc], st[t], stc);
+                else st[t] = mma_split<NP>(kf, qf[kc], st[t]);
             }
+            if constexpr (F16) st[t] += stc * (1.0f / CBX_F16_LO_SCALE);
         }
 
         // ---- mask + online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
@@ -211,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                ot[d][r] *= alpha;
+                if constexpr (F16) otc[d][r] *= alpha;
+            }
 
         // ---- O^T += V^T P^T : chunk c = 2t + u contracts the 16 keys held in registers 8u..8u+7 of both half-waves
 #pragma unroll
@@ -221,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
                 const f32x8 pv = {st[t][8 * u + 0], st[t][8 * u + 1], st[t][8 * u + 2], st[t][8 * u + 3],
                                   st[t][8 * u + 4], st[t][8 * u + 5], st[t][8 * u + 6], st[t][8 * u + 7]};
                 bf16x8 pf[NP];
-                split8<NP>(pv, pf);
+                split8<NP, F16>(pv, pf);
                 const int c = 2 * t + u;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -229,12 +270,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
                         vf[q] = *reinterpret_cast<const bf16x8*>(&Vt[q * FPLANE + (dt * 32 + lr) * FLD + 16 * c + 8 * lh]);
-                    ot[dt] = mma_split<NP>(vf, pf, ot[dt]);
+                    if constexpr (F16) mma_f16(vf, pf, ot[dt], otc[dt]);
+                    else ot[dt] = mma_split<NP>(vf, pf, ot[dt]);
                 }
             }
         __syncthreads();
     }
 
+    if constexpr (F16) {
+        if (oor && range_flag) atomicOr(range_flag, 1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
+    }
     // ---- finalise: both half-waves hold partial sums of the same query
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -258,15 +305,18 @@ extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const fl
                                         void* stream) {
     CBX_REQUIRE(q && k && v && o, "flash_attn_split: null operand");
     CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn_split: bad shape");
-    CBX_REQUIRE(precision == 3 || precision == 6, "flash_attn_split: precision must be 3 or 6 (got %d)", precision);
+    CBX_REQUIRE(precision == 3 || precision == 6 || precision == 16, "flash_attn_split: precision must be 3, 6 or 16 (got %d)", precision);
     CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb) % 4 == 0, "flash_attn_split: strides must be multiples of 4");
     CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn_split: 16-byte alignment");
     FlashSplitArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
-    if (precision == 3) {
-        hipLaunchKernelGGL(flash_attn_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    int* flag = cbx_range_flag();
+    if (precision == 16) {
+        hipLaunchKernelGGL((flash_attn_split_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, a, flag);
+    } else if (precision == 3) {
+        hipLaunchKernelGGL((flash_attn_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a, flag);
     } else {
-        hipLaunchKernelGGL(flash_attn_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((flash_attn_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a, flag);
     }
     return cbx_check_launch("flash_attn_split");
 }

@@ -7,6 +7,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CBX_F16_LO_SCALE 2048.0f  /* scale of the second fp16 plane of the f16x3 forms (gemm_split.hip) */
+int* cbx_range_flag();            /* gemm_split.hip: device word of cbx_set_range_flag, or NULL */
 
 extern thread_local char cbx_err_buf[512];
 int cbx_set_error(int code, const char* fmt, ...);

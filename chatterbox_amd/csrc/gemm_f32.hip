@@ -283,12 +283,12 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
     {
         // precision 0 = library default (CBX_GEMM_PRECISION, else exact); 1 = exact fp32 MFMA; 3 / 6 = fp32 rebuilt from
-        // 3 / 6 bf16 plane products on the 16x faster bf16 matrix cores (gemm_split.hip)
+        // 3 / 6 bf16 plane products on the 16x faster bf16 matrix cores, 16 = from 3 fp16 plane products (gemm_split.hip)
         static const int env_prec = getenv("CBX_GEMM_PRECISION") ? atoi(getenv("CBX_GEMM_PRECISION")) : 1;
         const int prec = p.precision ? p.precision : env_prec;
-        CBX_REQUIRE(prec == 1 || prec == 3 || prec == 6, "gemm: precision must be 0, 1, 3 or 6 (got %d)", prec);
+        CBX_REQUIRE(prec == 1 || prec == 3 || prec == 6 || prec == 16, "gemm: precision must be 0, 1, 3, 6 or 16 (got %d)", prec);
         if (prec != 1) {
-            int rc = cbx_gemm_split_dispatch(p, prec == 3 ? 2 : 3, st);
+            int rc = cbx_gemm_split_dispatch(p, prec == 16 ? 16 : prec == 3 ? 2 : 3, st);
             if (rc != -1) return rc;
         }
     }

@@ -6,6 +6,13 @@
 //   plane products whose weight is above the fp32 rounding level, accumulated in fp32 by the MFMA:
 //       NP = 2 (bf16x3):  a0b0 + a0b1 + a1b0                              rel. error ~4e-6  (3 MFMA per k16, 5.3x fp32 rate)
 //       NP = 3 (bf16x6):  a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1         rel. error ~1e-7  (6 MFMA per k16, 2.7x fp32 rate)
+//   F16 (f16x3): two fp16 planes, the second one SCALED: a = h + l / 2048 with h = RNE fp16(a), l = RNE fp16(2048 (a - h)).  h and l carry
+//   11 significand bits each and the scaling keeps l normal whenever h is, so the pair represents a to 2^-24 |a| like fp32 does;
+//   hh goes to one accumulator, hl + lh to a second one that is folded in as acc + acc_c / 2048 in the epilogue (ll < 2^-24 |ab| is
+//   dropped).  rel. error ~8e-8 of the plane arithmetic (below the fp32 MFMA's own ~2.5e-7) at the cost of bf16x3: 3 MFMA per k16 and
+//   two planes of LDS traffic.  Range: |a| <= 65504 (fp16); an operand beyond that sets *range_flag (cbx_set_range_flag) so that the
+//   caller can repeat the computation with bf16x6, which has the fp32 exponent range.  |a| < 6e-5 degrades gracefully (absolute
+//   precision 3e-11), a concern only for tensors that are tiny throughout.
 //   (fp32 MFMA itself: ~2.5e-7 at K = 256.)  Same address generator / epilogue contract as gemm_f32.hip: Linear, Conv1d,
 //   upsample+conv, phase-packed ConvTranspose1d, ragged masking -- only W in [N][K] layout, K tiles of 32.
 //
@@ -20,12 +27,23 @@ namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SBK = 32;       // K tile (fp32 elements)
 constexpr int SLD = SBK + 8;  // LDS row stride in bf16 elements (80 B)
 
-template <int NP>
-__device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plane_stride) {
+template <int NP, bool F16>
+__device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plane_stride, unsigned& oor) {
+    if constexpr (F16) {
+        const f16x4 h = __builtin_convertvector(v, f16x4);
+        *reinterpret_cast<f16x4*>(dst) = h;
+        const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CBX_F16_LO_SCALE;
+        *reinterpret_cast<f16x4*>(dst + plane_stride) = __builtin_convertvector(r, f16x4);
+        const float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        oor |= mx > 65504.f ? 1u : 0u;
+        return;
+    }
     bf16x4 h = __builtin_convertvector(v, bf16x4);
     *reinterpret_cast<bf16x4*>(dst) = h;
     f32x4 r = v - __builtin_convertvector(h, f32x4);
@@ -40,8 +58,9 @@ __device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plan
 // NS = LDS stages.  2: one barrier per K tile (the next tile is written to the other stage while this one is read).  1: half the
 // LDS (two workgroups per CU also with three planes) at the price of a second barrier per K tile -- the co-resident workgroup fills
 // the bubbles; the register prefetch (two K tiles ahead) is the same.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p) {
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p, int* range_flag) {
+    static_assert(!F16 || NP == 2, "the fp16 form has two planes");
     constexpr int BK = SBK;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -134,24 +153,29 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
         }
     };
 
+    unsigned oor = 0;  // F16: an operand outside the fp16 range was seen
     auto store_tiles = [&](int buf, const f32x4(&ra)[A_IT], const f32x4(&rb)[B_IT], unsigned okmask) {
         __bf16* st = smem + buf * STAGE;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            split_store<NP>((okmask >> i) & 1u ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE);
+            split_store<NP, F16>((okmask >> i) & 1u ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE, oor);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            split_store<NP>((okmask >> (16 + i)) & 1u ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE);
+            split_store<NP, F16>((okmask >> (16 + i)) & 1u ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE, oor);
     };
 
     f32x16 acc[TM][TN];
+    f32x16 accc[F16 ? TM : 1][F16 ? TN : 1];  // F16: the cross products h*l + l*h, 2048 times too large
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (F16) accc[i][j][r] = 0.f;
+            }
 
     const int lr = lane & 31, lh = lane >> 5;
     auto compute = [&](int buf) {
@@ -172,6 +196,14 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    if constexpr (F16) {
+                        const f16x8 ah = __builtin_bit_cast(f16x8, af[i][0]), al = __builtin_bit_cast(f16x8, af[i][1]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, bf[j][0]), bl = __builtin_bit_cast(f16x8, bf[j][1]);
+                        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[i][j], 0, 0, 0);
+                        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                        continue;
+                    }
                     // smallest-weight products first
                     if constexpr (NP == 3) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
@@ -208,6 +240,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
         __syncthreads();
     }
 
+    if constexpr (F16) {
+        if (oor && range_flag) atomicOr(range_flag, 1);
+    }
+
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cb = p.C + (long)z1 * p.c_s1 + (long)z2 * p.c_s2;
     const float* Rb = p.R ? p.R + (long)z1 * p.r_s1 + (long)z2 * p.r_s2 : nullptr;
@@ -235,7 +271,9 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bia;
+                float v = acc[i][j][r];
+                if constexpr (F16) v += accc[i][j][r] * (1.0f / CBX_F16_LO_SCALE);
+                v += bia;
                 v = cbx_act(v, p.act1, p.act1_slope, a1);
                 if (Rb) v += res[r];
                 v *= p.alpha;
@@ -249,10 +287,12 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2>
+int* g_range_flag = nullptr;
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false>
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * NP * (BM + BN) * SLD * sizeof(__bf16);
-    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS>;
+    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16>;
     static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -260,7 +300,7 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
         configured = true;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
-    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, g_range_flag);
     return cbx_check_launch("gemm_split");
 }
 
@@ -273,7 +313,15 @@ extern "C" int cbx_set_split_tile(int t) {
     return 0;
 }
 
-// Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3) or 3 (bf16x6).  Returns -1 when the shape is not
+// Device word that the fp16 forms (precision 16, here and in attention_split.hip) OR a 1 into when an operand exceeds the fp16 range.
+// NULL (default) = not reported.  Process-global like the current device; the word has to outlive the launches.
+int* cbx_range_flag() { return g_range_flag; }
+extern "C" int cbx_set_range_flag(int* dev_flag) {
+    g_range_flag = dev_flag;
+    return 0;
+}
+
+// Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3), 3 (bf16x6) or 16 (f16x3).  Returns -1 when the shape is not
 // served by this kernel (caller falls back to the exact fp32 MFMA kernel).
 int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     if (p.w_kn || p.swiglu) return -1;
@@ -283,6 +331,13 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by
     // 5-45 % and 64x64 by 0-15 %
     int tile = force ? force : (g128 >= 64 && p.N >= 64 ? 12864 : 64);
+    if (planes == 16) {
+        if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1, true>(p, st);
+        if (tile == 1286401) return launch_split<128, 64, 4, 2, 2, 1, true>(p, st);
+        if (tile == 128) return launch_split<128, 128, 2, 4, 2, 2, true>(p, st);
+        if (tile == 12864) return launch_split<128, 64, 4, 2, 2, 2, true>(p, st);
+        return launch_split<64, 64, 2, 2, 2, 2, true>(p, st);
+    }
     if (planes == 2) {
         if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1>(p, st);
         if (tile == 1286401) return launch_split<128, 64, 4, 2, 2, 1>(p, st);

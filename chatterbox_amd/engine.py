@@ -7,6 +7,7 @@ token's 40 ms, mtl_tts.py:348-352).
 """
 import os
 import time
+import warnings
 
 import torch
 
@@ -17,6 +18,22 @@ from .t3 import T3Engine, START_SPEECH, STOP_SPEECH
 
 SPEECH_VOCAB = 6561
 SAMPLES_PER_TOKEN = 960  # 24 kHz / 25 tokens per second
+
+
+def _range_checked(eng, run, check=True):
+    """S3Gen's default numerics (precision 16 = f16x3) need operands inside the fp16 range; a launch that meets one outside it raises a
+    device flag (ops.enable_range_flag).  Then the result is not meaningful and the work is repeated at bf16x6, which has the fp32
+    exponent range.  check=False: the caller looks at ops.range_flag_tripped() itself at its next synchronisation point."""
+    out = run()
+    if check and 16 in (eng.flow.precision, eng.hift.precision) and ops.range_flag_tripped():
+        warnings.warn("an S3Gen operand exceeded the fp16 range: repeating flow matching + vocoder at bf16x6")
+        saved = eng.flow.precision, eng.hift.precision
+        eng.flow.precision, eng.hift.precision = (6 if p == 16 else p for p in saved)
+        try:
+            out = run()
+        finally:
+            eng.flow.precision, eng.hift.precision = saved
+    return out
 
 
 def drop_invalid_tokens(x):
@@ -69,19 +86,24 @@ class ChatterboxEngine:
         for b, t in enumerate(speech_tokens):
             tok[b, : ns[b]] = t
         lens = torch.tensor(ns, dtype=torch.int32)
-        t0 = time.perf_counter()
-        mel = self.flow.inference(tok.to(self.dev), lens.to(self.dev), gen_ref, z=z, n_steps=n_cfm_timesteps)
-        if sync:  # per-stage wall times; the pipelined mode never blocks the host between stages
-            torch.cuda.synchronize()
-        t1 = time.perf_counter()
         same = all(n == Nmax for n in ns)
-        short = 2 * Nmax - mel.shape[1]  # > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195)
-        mel_lens = None if same else (2 * lens - short).to(self.dev)
-        wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
-        if sync:
-            torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        self.last_timing.update(flow_s=t1 - t0, hift_s=t2 - t1)
+
+        def run():
+            t0 = time.perf_counter()
+            mel = self.flow.inference(tok.to(self.dev), lens.to(self.dev), gen_ref, z=z, n_steps=n_cfm_timesteps)
+            if sync:  # per-stage wall times; the pipelined mode never blocks the host between stages
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            short = 2 * Nmax - mel.shape[1]  # > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195)
+            mel_lens = None if same else (2 * lens - short).to(self.dev)
+            wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
+            if sync:
+                torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            self.last_timing.update(flow_s=t1 - t0, hift_s=t2 - t1)
+            return wav, mel, short
+
+        wav, mel, short = _range_checked(self, run, check=sync)
         out = []
         for b, n in enumerate(ns):
             keep = max(1, n - 1) if drop_last_token else n
@@ -133,10 +155,12 @@ class ChatterboxEngine:
             if pending is not None:
                 job, st, t0 = pending
                 with torch.cuda.stream(self._s_voc):
-                    wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
-                                          n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
-                                          drop_last_token=kw.get("drop_last_token", True), sync=False)
-                    host = [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
+                    def voc():
+                        wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
+                                              n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
+                                              drop_last_token=kw.get("drop_last_token", True), sync=False)
+                        return [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
+                    host = _range_checked(self, voc)
                 yield host, st, time.perf_counter() - t0
             pending = None
             if handle is not None:
@@ -202,10 +226,14 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
             tok = torch.zeros(B, Nk, dtype=torch.long)
             for b, t in enumerate(st):
                 tok[b, : ns[b]] = t
-            mel = self.flow.inference(tok.to(dev), torch.tensor(ns, dtype=torch.int32, device=dev), gen_ref, z=z[:, : 2 * (P + Nk)],
-                                      n_steps=n_cfm_timesteps, hold_back=hold)
             fl = torch.tensor(frames, dtype=torch.int32, device=dev)
-            wav, src = self.hift.inference(mel, phase=phase, noise=noise[:, :, : 480 * mel.shape[1]], lens=fl, fade=True, cache_source=src_cache)
+
+            def run():
+                mel = self.flow.inference(tok.to(dev), torch.tensor(ns, dtype=torch.int32, device=dev), gen_ref, z=z[:, : 2 * (P + Nk)],
+                                          n_steps=n_cfm_timesteps, hold_back=hold)
+                return self.hift.inference(mel, phase=phase, noise=noise[:, :, : 480 * mel.shape[1]], lens=fl, fade=True,
+                                           cache_source=src_cache)
+            wav, src = _range_checked(self, run)
             src_cache = src[:, : 480 * min(frames)].clone() if min(frames) > 0 else None
             for b in range(B):
                 if closed[b]:

@@ -27,7 +27,8 @@ class HiFTEngine:
         self.dev = dev = torch.device(device)
         # numerics policy of the decoder convs; the F0 predictor always runs exact (its output is integrated into a phase
         # over ~10^5 samples, which amplifies any error in f0)
-        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "6")) if precision is None else int(precision)
+        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "16")) if precision is None else int(precision)
+        ops.enable_range_flag(dev)  # raised by a precision-16 launch that meets an operand outside the fp16 range (engine.py repeats at 6)
         d = lambda t: t.float().contiguous().to(dev)
         h = "mel2wav."
         fw = lambda p: weights.fold_weight_norm(sd, p)

@@ -78,7 +78,7 @@ def _f32(t, name):
     return t
 
 
-GEMM_PRECISION = 0  # cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued while set: 0 default, 1 exact, 3 / 6 split-bf16
+GEMM_PRECISION = 0  # cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued while set: 0 default, 1 exact, 3 / 6 split-bf16, 16 split-fp16
 
 
 class gemm_precision:
@@ -95,6 +95,29 @@ class gemm_precision:
     def __exit__(self, *exc):
         global GEMM_PRECISION
         GEMM_PRECISION = self._prev
+
+
+_RANGE_FLAG = None
+
+
+def enable_range_flag(device):
+    """Allocate (once) the device word the f16x3 kernels (precision 16) raise when an operand exceeds the fp16 range, and register it
+    with the library (cbx_set_range_flag).  One process drives one GPU, so one word per process."""
+    global _RANGE_FLAG
+    if _RANGE_FLAG is None or _RANGE_FLAG.device != torch.device(device):
+        _RANGE_FLAG = torch.zeros(1, dtype=torch.int32, device=device)
+        check(lib.cbx_set_range_flag(_p(_RANGE_FLAG)), "cbx_set_range_flag")
+    return _RANGE_FLAG
+
+
+def range_flag_tripped():
+    """True when a precision-16 launch since the last call saw an operand outside the fp16 range (synchronises; clears the flag)."""
+    if _RANGE_FLAG is None:
+        return False
+    hit = bool(_RANGE_FLAG.item())
+    if hit:
+        _RANGE_FLAG.zero_()
+    return hit
 
 
 def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, ldc2=0, act1=NONE, act2=NONE,
@@ -119,7 +142,7 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
     p.precision = GEMM_PRECISION
     nz = nz1 * nz2
-    split = GEMM_PRECISION in (3, 6) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
+    split = GEMM_PRECISION in (3, 6, 16) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
     kind = "gemm_f32_skinny" if M <= 32 else ("gemm_split" if split else "gemm_f32")  # mirrors the dispatch in gemm_f32.hip
     _timed(kind, 2.0 * M * N * K * nz, 4.0 * nz * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32"))
@@ -240,7 +263,7 @@ def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
         assert t.stride(3) == 1 and t.stride(2) == 64
     args = (_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
             v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale, int(causal))
-    if GEMM_PRECISION in (3, 6):  # same numerics policy as the GEMMs issued in this scope
+    if GEMM_PRECISION in (3, 6, 16):  # same numerics policy as the GEMMs issued in this scope
         fn = lambda: check(lib.cbx_flash_attn_split_f32(*args, GEMM_PRECISION, _stream()), "cbx_flash_attn_split_f32")
     else:
         fn = lambda: check(lib.cbx_flash_attn_f32(*args, _stream()), "cbx_flash_attn_f32")

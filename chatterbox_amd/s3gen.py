@@ -25,11 +25,13 @@ class FlowEngine:
     def __init__(self, sd, device="cuda", meanflow=False, precision=None):
         self.dev = dev = torch.device(device)
         self.meanflow = meanflow
-        # numerics policy of the encoder / CFM GEMMs and attention (cbx_gemm_t.precision): 1 exact fp32 MFMA; 6 bf16x6 = the DEFAULT
-        # (fp32-level error: every parity tolerance of the fp32 path holds at every BASELINE shape incl. the 60 s waveform); 3 bf16x3 =
-        # opt-in fast mode (mel-L1 ~1e-5; meets the mel tolerances everywhere but the 60 s WAVEFORM only at the bf16-mode tolerance,
-        # because the F0 -> phase integration amplifies the mel error over 1.4 M samples -- DESIGN.md section 1)
-        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "6")) if precision is None else int(precision)
+        # numerics policy of the encoder / CFM GEMMs and attention (cbx_gemm_t.precision): 1 exact fp32 MFMA; 16 f16x3 = the DEFAULT
+        # (two fp16 planes, fp32-level error at the bf16x3 cost: every parity tolerance of the fp32 path holds at every BASELINE shape incl.
+        # the 60 s waveform; operands must stay inside the fp16 range, which is checked on the device -- engine.py repeats at 6 otherwise);
+        # 6 bf16x6 = fp32-level with the fp32 exponent range, 1.45x the matrix-core time; 3 bf16x3 = opt-in (mel-L1 ~1e-5; the 60 s
+        # WAVEFORM only at the bf16-mode tolerance, because the F0 -> phase integration amplifies the mel error -- DESIGN.md section 1)
+        self.precision = int(os.environ.get("CBX_S3GEN_PRECISION", "16")) if precision is None else int(precision)
+        ops.enable_range_flag(dev)  # raised by a precision-16 launch that meets an operand outside the fp16 range (engine.py repeats at 6)
         d = lambda t: _dev(t, dev)
         self.emb = d(sd["flow.input_embedding.weight"])
         self.spk_w, self.spk_b = d(sd["flow.spk_embed_affine_layer.weight"]), d(sd["flow.spk_embed_affine_layer.bias"])

@@ -15,7 +15,8 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 4  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32 */
+#define CBX_ABI_VERSION 5  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+                              5: precision 16 (f16x3) + cbx_set_range_flag */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -59,11 +60,17 @@ typedef struct cbx_gemm_t {
     int precision;            /* 0 = library default (exact unless CBX_GEMM_PRECISION is set); 1 = exact fp32 MFMA
                                  (bitwise an fmaf chain); 3 = "bf16x3", 6 = "bf16x6": every fp32 operand split into 2 / 3
                                  bf16 planes and the product rebuilt from 3 / 6 bf16-MFMA plane products with fp32
-                                 accumulation (rel. error ~4e-6 / ~1e-7; fp32 MFMA ~2.5e-7).  Shapes the split kernel does
+                                 accumulation (rel. error ~4e-6 / ~1e-7; fp32 MFMA ~2.5e-7); 16 = "f16x3": two fp16 planes
+                                 a = h + l/2048, three fp16-MFMA products in two fp32 accumulators (rel. error ~1e-7 at the cost of
+                                 bf16x3; operands must satisfy |a| <= 65504, see cbx_set_range_flag).  Shapes the split kernel does
                                  not serve (w_kn, swiglu, M <= 32, conv Cin % 32 != 0) run exact. */
     int reserved0;
 } cbx_gemm_t;
 int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
+/* Device word that every precision-16 launch (GEMM and flash attention) ORs a 1 into when it meets an operand outside the fp16 range
+ * (its result is then not meaningful and the caller repeats the computation at precision 6, which has the fp32 exponent range).
+ * NULL (the default) = not reported.  Process-global; the word must stay allocated while such launches are in flight. */
+int cbx_set_range_flag(int* dev_flag);
 
 /* ---- skinny-M weight-streaming GEMM for decode (M = 2*B rows <= 64), HBM-roofline kernel ----
  * out[ks][m][n] = sum_{k in slice ks} x[m][k] * W[n][k]  (+ bias on slice 0);  ksplit > 1 leaves partial sums that
@@ -133,8 +140,9 @@ int cbx_layernorm_f32(const float* x, float* y, const float* w, const float* b, 
 int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, void* stream);
-/* Same contract on the bf16 matrix cores with split fp32 operands: precision 3 ("bf16x3", rel. error ~4e-6 per
- * contraction) or 6 ("bf16x6", fp32-level), see cbx_gemm_t.precision.  5.3x / 2.7x fewer matrix-core cycles. */
+/* Same contract on the bf16 / fp16 matrix cores with split fp32 operands: precision 3 ("bf16x3", rel. error ~4e-6 per
+ * contraction), 6 ("bf16x6", fp32-level) or 16 ("f16x3", fp32-level, fp16 operand range), see cbx_gemm_t.precision.
+ * 5.3x / 2.7x / 5.3x fewer matrix-core cycles. */
 int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
                              int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                              long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,

@@ -163,10 +163,10 @@ def test_flash_attn(dev, Tq, Tk, causal):
 
 # ---- split-bf16 modes (cbx_gemm_t.precision 3 / 6, cbx_flash_attn_split_f32): fp32 operands rebuilt from bf16 planes on
 # the 16x faster bf16 matrix cores.  Stated tolerances: precision 6 = the fp32 tolerances above; precision 3 = 1e-4.
-_SPLIT_TOL = {6: 3e-5, 3: 1e-4}
+_SPLIT_TOL = {6: 3e-5, 16: 3e-5, 3: 1e-4}  # 16 = f16x3 (two fp16 planes, second one scaled): fp32-level like 6
 
 
-@pytest.mark.parametrize("prec", [3, 6])
+@pytest.mark.parametrize("prec", [3, 6, 16])
 def test_split_gemm_linear(dev, prec):
     from chatterbox_amd import ops
     with ops.gemm_precision(prec):
@@ -186,7 +186,7 @@ def test_split_gemm_linear(dev, prec):
         _close(out2, ref + (1.0 / (ap[None] + 1e-9)) * torch.sin(ref * ap[None]) ** 2, 2 * _SPLIT_TOL[prec], "split second output")
 
 
-@pytest.mark.parametrize("prec", [3, 6])
+@pytest.mark.parametrize("prec", [3, 6, 16])
 def test_split_gemm_conv(dev, prec):
     from chatterbox_amd import ops, weights
     B = 3
@@ -216,7 +216,7 @@ def test_split_gemm_conv(dev, prec):
         _close(out.transpose(1, 2), ref, _SPLIT_TOL[prec], "split upsample conv")
 
 
-@pytest.mark.parametrize("prec", [3, 6])
+@pytest.mark.parametrize("prec", [3, 6, 16])
 @pytest.mark.parametrize("Tq,Tk,causal", [(200, 200, False), (1000, 1000, False), (103, 103, True), (64, 64, True), (130, 130, False)])
 def test_split_flash_attn(dev, Tq, Tk, causal, prec):
     from chatterbox_amd import ops
@@ -235,7 +235,40 @@ def test_split_flash_attn(dev, Tq, Tk, causal, prec):
     out = torch.empty(Z, Tq, H, 64, device=dev)
     with ops.gemm_precision(prec):
         ops.flash_attn(d[:, :, 0], d[:, :, 1], d[:, :, 2], out, 0.125, key_lens=kl, causal=causal)
-    _close(out, ref.transpose(1, 2), {6: 2e-5, 3: 1e-4}[prec], f"split flash_attn p{prec}")
+    _close(out, ref.transpose(1, 2), {6: 2e-5, 16: 2e-5, 3: 1e-4}[prec], f"split flash_attn p{prec}")
+
+
+def test_f16x3_accuracy_and_range_flag(dev):
+    """precision 16 against an fp64 product: as close as the exact fp32 MFMA kernel over 8 decades of operand scale; operands beyond
+    the fp16 range raise the device flag (and only they do)."""
+    from chatterbox_amd import ops
+    M, N, K = 512, 256, 512
+    ops.enable_range_flag(dev)
+    assert not ops.range_flag_tripped()
+    for sa, sw in [(1.0, 0.05), (300.0, 1.0), (1e-3, 1e-2), (3e4 / 5, 1.0)]:
+        x, w = _r((M, K), 1, sa), _r((N, K), 2, sw)
+        ref = x.double() @ w.double().t()
+        errs = {}
+        for prec in (1, 16, 3):
+            out = torch.empty(M, N, device=dev)
+            with ops.gemm_precision(prec):
+                ops.linear(x.to(dev), w.to(dev), out)
+            errs[prec] = float((out.cpu().double() - ref).abs().mean() / ref.abs().mean())
+        assert errs[16] <= 1.5 * errs[1] + 1e-9, (sa, sw, errs)
+        assert errs[16] < 0.2 * errs[3], (sa, sw, errs)
+    assert not ops.range_flag_tripped()
+    x = _r((M, K), 1)
+    x[17, 33] = 7.0e4
+    with ops.gemm_precision(16):
+        ops.linear(x.to(dev), _r((N, K), 2).to(dev), torch.empty(M, N, device=dev))
+    assert ops.range_flag_tripped()
+    assert not ops.range_flag_tripped()  # reading clears it
+    q = _r((1, 128, 3, 2, 64), 3)
+    q[0, 5, 1, 0, 7] = -1e5  # a key
+    d, out = q.to(dev), torch.empty(1, 128, 2, 64, device=dev)
+    with ops.gemm_precision(16):
+        ops.flash_attn(d[:, :, 0], d[:, :, 1], d[:, :, 2], out, 0.125)
+    assert ops.range_flag_tripped()
 
 
 def test_decode_attn(dev):

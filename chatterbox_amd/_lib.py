@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcbx_hip.so")
+LIB_PATH = os.environ.get("CBX_LIB_PATH") or os.path.join(_HERE, "libcbx_hip.so")  # CBX_LIB_PATH: developer builds (scripts/diag_gemm.sh)
 
 c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float

@@ -36,7 +36,10 @@ template <int NP, bool F16>
 __device__ __forceinline__ void split8(const f32x8 v, bf16x8 (&out)[NP]) {
     if constexpr (F16) {
         const f16x8 h = __builtin_convertvector(v, f16x8);
-        const f32x8 r = (v - __builtin_convertvector(h, f32x8)) * CBX_F16_LO_SCALE;
+        const f32x8 t = v * CBX_F16_LO_SCALE;
+        f32x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = __builtin_fmaf((float)h[e], -CBX_F16_LO_SCALE, t[e]);  // 2048 (v - h), exact
         out[0] = __builtin_bit_cast(bf16x8, h);
         out[1] = __builtin_bit_cast(bf16x8, __builtin_convertvector(r, f16x8));
         return;
@@ -51,10 +54,6 @@ __device__ __forceinline__ void split8(const f32x8 v, bf16x8 (&out)[NP]) {
 }
 
 // acc += sum over the plane products above the fp32 rounding level (smallest first)
-__device__ __forceinline__ unsigned out_of_f16(const f32x4 v) {
-    return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f ? 1u : 0u;
-}
-
 // F16: acc += h*h, accc += h*l + l*h (2048 times too large)
 __device__ __forceinline__ void mma_f16(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16& acc, f32x16& accc) {
     const f16x8 ah = __builtin_bit_cast(f16x8, a[0]), al = __builtin_bit_cast(f16x8, a[1]);
@@ -77,10 +76,16 @@ __device__ __forceinline__ f32x16 mma_split(const bf16x8 (&a)[NP], const bf16x8 
     return acc;
 }
 
+// VALU diet of the KV loop (the loop was VALU-bound: 735 vector instructions against 48 MFMAs per tile and wave):
+//   * K / V rows come through raw buffer loads whose offset is pushed past num_records for keys >= klen: the hardware returns zeros, so
+//     neither the fetch nor the staging selects anything;
+//   * tiles that no lane has to mask (all but the last one without causality) take a softmax path without compares / selects;
+//   * scores are kept in the log2 domain (log2 e folded into the Q scale): p = exp2(s - m) is one subtract and one v_exp_f32;
+//   * O is only rescaled when some lane's running maximum moved.
 template <int NP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSplitArgs a, int* range_flag) {
     static_assert(!F16 || NP == 2, "the fp16 form has two planes");
-    unsigned oor = 0;
+    float amax = 0.f;  // F16: largest |operand| (fp16 range check at the end)
     // planes: K [NP][64 keys][FLD], then V^T [NP][64 d][FLD]
     __shared__ __attribute__((aligned(16))) __bf16 Ks[NP * FPLANE];
     __shared__ __attribute__((aligned(16))) __bf16 Vt[NP * FPLANE];
@@ -97,19 +102,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
     const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
     const int coff = a.Tk - a.Tq;
 
-    // Q planes: chunk kc covers d = 16kc + 8lh .. +8, pre-scaled
+    // Q planes: chunk kc covers d = 16kc + 8lh .. +8, pre-scaled by scale * log2(e)
     bf16x8 qf[4][NP];
     {
         const bool ok = qi < a.Tq;
         const float* qp = qb + (long)(ok ? qi : 0) * a.q_st + 8 * lh;
-        const float sc = ok ? a.scale : 0.f;
+        const float sc = ok ? a.scale * 1.4426950408889634f : 0.f;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp + 16 * kc);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * kc + 4);
-            f32x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            t *= sc;
-            if constexpr (F16) oor |= out_of_f16(t0 * sc) | out_of_f16(t1 * sc);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp + 16 * kc) * sc;
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * kc + 4) * sc;
+            const f32x8 t = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            if constexpr (F16) {
+                cbx_amax4(amax, t0);
+                cbx_amax4(amax, t1);
+            }
             split8<NP, F16>(t, qf[kc]);
         }
     }
@@ -132,53 +139,54 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
     // position of key 4g inside the V^T row: bits 2 and 3 of the key index swapped
     const int v_pos = (v_g & ~3) * 4 + (v_g & 1) * 8 + ((v_g >> 1) & 1) * 4;
 
+    constexpr int OOB = (int)0x80000000;  // byte offset >= num_records: the buffer load returns 0 (host checks that real offsets fit 31 bits)
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, OOB, 0x00020000);
+    const int k_st4 = (int)a.k_st * 4, v_st4 = (int)a.v_st * 4;
+    const int k_lin = k_row * k_st4 + k_c * 4, v_lin = 4 * v_g * v_st4 + 16 * v_dq;  // byte offsets inside tile 0
+
     f32x4 kreg[4], vreg[4];
-    unsigned kok = 0, vok = 0;
     auto fetch = [&](int j0) {
-        {
-            const int j = j0 + k_row;
-            const bool ok = j < klen;
-            const float* kp = kb + (long)(ok ? j : 0) * a.k_st + k_c;
+        const int kvo = j0 + k_row < klen ? k_lin : OOB;
+        const int ks = j0 * k_st4, vs = j0 * v_st4;  // scalar part of the address
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kreg[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
-            kok = ok ? 1u : 0u;
-        }
-        vok = 0;
+        for (int c = 0; c < 4; ++c)
+            kreg[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, kvo + 16 * c, ks, 0));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int j = j0 + 4 * v_g + i;
-            const bool ok = j < klen;
-            vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)(ok ? j : 0) * a.v_st + 4 * v_dq);
-            vok |= ok ? (1u << i) : 0u;
+            const int vvo = j0 + 4 * v_g + i < klen ? v_lin + i * v_st4 : OOB;
+            vreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rs, vvo, vs, 0));
         }
     };
     auto stage = [&]() {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         // K planes: 16 d of one key -> two 16-B stores per plane
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-            const f32x4 x0 = kok ? kreg[2 * c2] : zero, x1 = kok ? kreg[2 * c2 + 1] : zero;
+            const f32x4 x0 = kreg[2 * c2], x1 = kreg[2 * c2 + 1];
             const f32x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             bf16x8 pl[NP];
-            if constexpr (F16) oor |= out_of_f16(x0) | out_of_f16(x1);
+            if constexpr (F16) {
+                cbx_amax4(amax, x0);
+                cbx_amax4(amax, x1);
+            }
             split8<NP, F16>(x, pl);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(&Ks[q * FPLANE + k_row * FLD + k_c + 8 * c2]) = pl[q];
         }
         // V^T planes: for each of the thread's 4 d, the 4 keys of its group are contiguous (8 B)
-        f32x4 vv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vv[i] = (vok >> i) & 1u ? vreg[i] : zero;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4 col = {vv[0][e], vv[1][e], vv[2][e], vv[3][e]};  // keys 4g..4g+3 at d = 4dq + e
+            const f32x4 col = {vreg[0][e], vreg[1][e], vreg[2][e], vreg[3][e]};  // keys 4g..4g+3 at d = 4dq + e
             __bf16* dst = &Vt[(4 * v_dq + e) * FLD + v_pos];
             if constexpr (F16) {
                 const f16x4 hh = __builtin_convertvector(col, f16x4);
-                const f32x4 rr = (col - __builtin_convertvector(hh, f32x4)) * CBX_F16_LO_SCALE;
+                const f32x4 tt = col * CBX_F16_LO_SCALE;
+                f32x4 rr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rr[q] = __builtin_fmaf((float)hh[q], -CBX_F16_LO_SCALE, tt[q]);
                 *reinterpret_cast<f16x4*>(dst) = hh;
                 *reinterpret_cast<f16x4*>(dst + FPLANE) = __builtin_convertvector(rr, f16x4);
-                oor |= out_of_f16(col);
+                cbx_amax4(amax, col);
                 continue;
             }
             bf16x4 h = __builtin_convertvector(col, bf16x4);
@@ -194,13 +202,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
     };
     if (kend > 0) fetch(0);
 
+    const int q_lo = q0 + wid * 32 + coff;  // causal: the wave's first query sees keys <= q_lo
+    const int jmax = a.causal ? min(klen - 1, qi + coff) : klen - 1;  // last key this lane's query sees
     for (int j0 = 0; j0 < kend; j0 += FKT) {
         stage();
         __syncthreads();
-        // unconditional prefetch (rows past the end read row 0 and are masked at staging): keeps hipcc's vmcnt exact
+        // unconditional prefetch (rows past the end return zeros): keeps hipcc's vmcnt exact
         fetch(j0 + FKT);
 
-        // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, 4 d-chunks of 16)
+        // ---- S^T = K Q^T  (2 sub-tiles of 32 keys, 4 d-chunks of 16), in units of log2
         f32x16 st[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -219,40 +229,47 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
             if constexpr (F16) st[t] += stc * (1.0f / CBX_F16_LO_SCALE);
         }
 
-        // ---- mask + online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
+        // ---- online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
+        const bool full = j0 + FKT <= klen && (!a.causal || j0 + FKT - 1 <= q_lo);  // wave-uniform: nothing to mask in this tile
         float mt = -INFINITY;
+        if (full) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int j = j0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                bool vis = j < klen && (!a.causal || j <= qi + coff);
-                float sv = vis ? st[t][r] : -INFINITY;
-                st[t][r] = sv;
-                mt = fmaxf(mt, sv);
-            }
+                for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, st[t][r]), st[t][r + 1]);
+        } else {
+            const int jl = jmax - j0 - 4 * lh;  // key offset inside the tile (without the lane's 4*lh) up to which this query sees
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sv = t * 32 + (r & 3) + 8 * (r >> 2) <= jl ? st[t][r] : -INFINITY;
+                    st[t][r] = sv;
+                    mt = fmaxf(mt, sv);
+                }
+        }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        float alpha = 1.f;
-        if (m_new > -INFINITY) alpha = __expf(m_run - m_new);
+        const float m_sub = m_new > -INFINITY ? m_new : 0.f;  // a row that has seen no key yet: exp2(-inf - 0) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
         float ls = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = (m_new > -INFINITY) ? __expf(st[t][r] - m_new) : 0.f;
+                const float pv = __builtin_amdgcn_exp2f(st[t][r] - m_sub);
                 st[t][r] = pv;
                 ls += pv;
             }
         l_run = l_run * alpha + ls;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ot[d][r] *= alpha;
-                if constexpr (F16) otc[d][r] *= alpha;
+            for (int d = 0; d < 2; ++d) {
+                ot[d] *= alpha;
+                if constexpr (F16) otc[d] *= alpha;
             }
+        }
 
         // ---- O^T += V^T P^T : chunk c = 2t + u contracts the 16 keys held in registers 8u..8u+7 of both half-waves
 #pragma unroll
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
     }
 
     if constexpr (F16) {
-        if (oor && range_flag) atomicOr(range_flag, 1);
+        if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
 #pragma unroll
         for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
     }
@@ -308,6 +325,8 @@ extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const fl
     CBX_REQUIRE(precision == 3 || precision == 6 || precision == 16, "flash_attn_split: precision must be 3, 6 or 16 (got %d)", precision);
     CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb) % 4 == 0, "flash_attn_split: strides must be multiples of 4");
     CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn_split: 16-byte alignment");
+    CBX_REQUIRE((long)(Tk + 64) * k_st * 4 < 0x7fffffffL && (long)(Tk + 64) * v_st * 4 < 0x7fffffffL && k_st > 0 && v_st > 0,
+                "flash_attn_split: one (batch, head) slice of K / V must span less than 2 GiB");
     FlashSplitArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     int* flag = cbx_range_flag();

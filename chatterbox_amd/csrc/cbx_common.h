@@ -9,6 +9,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CBX_F16_LO_SCALE 2048.0f  /* scale of the second fp16 plane of the f16x3 forms (gemm_split.hip) */
 int* cbx_range_flag();            /* gemm_split.hip: device word of cbx_set_range_flag, or NULL */
+#ifdef __HIPCC__
+// amax = max(amax, |v0..3|) in two instructions (fmaxf chains compile to one canonicalising v_max per operand)
+__device__ __forceinline__ void cbx_amax4(float& amax, const f32x4 v) {
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
+}
+#endif
 
 extern thread_local char cbx_err_buf[512];
 int cbx_set_error(int code, const char* fmt, ...);

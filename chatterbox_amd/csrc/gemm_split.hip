@@ -34,14 +34,25 @@ constexpr int SBK = 32;       // K tile (fp32 elements)
 constexpr int SLD = SBK + 8;  // LDS row stride in bf16 elements (80 B)
 
 template <int NP, bool F16>
-__device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plane_stride, unsigned& oor) {
+__device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plane_stride, float& amax, bool raw) {
+#ifdef CBX_DIAG
+    if (raw) {  // diagnosis: no conversion arithmetic, raw halves of the fp32 words
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(dst + plane_stride) = f32x2{v[2], v[3]};
+        return;
+    }
+#endif
     if constexpr (F16) {
+        // 12 VALU per 4 elements: 2 cvt_pk (h), 2 pk_mul + 4 cvt + 2 pk_fma (2048 v - 2048 h, exact), 2 cvt_pk (l); + 2 max3 (range check)
         const f16x4 h = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(dst) = h;
-        const f32x4 r = (v - __builtin_convertvector(h, f32x4)) * CBX_F16_LO_SCALE;
+        const f32x4 t = v * CBX_F16_LO_SCALE;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf((float)h[e], -CBX_F16_LO_SCALE, t[e]);
         *reinterpret_cast<f16x4*>(dst + plane_stride) = __builtin_convertvector(r, f16x4);
-        const float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        oor |= mx > 65504.f ? 1u : 0u;
+        cbx_amax4(amax, v);
         return;
     }
     bf16x4 h = __builtin_convertvector(v, bf16x4);
@@ -58,7 +69,13 @@ __device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plan
 // NS = LDS stages.  2: one barrier per K tile (the next tile is written to the other stage while this one is read).  1: half the
 // LDS (two workgroups per CU also with three planes) at the price of a second barrier per K tile -- the co-resident workgroup fills
 // the bubbles; the register prefetch (two K tiles ahead) is the same.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false>
+//
+// LD = loader.  0: generic (per-lane pointers, validity mask per K tile, operands zeroed on the way to LDS; serves upsampled inputs and
+// K % 32 != 0).  1 / 2 (Linear / Conv1d with up == 1, K % 32 == 0): raw buffer loads -- the row offsets are 32-bit VGPRs computed once
+// (per tap for convolutions), the K advance is a scalar offset, and rows outside the tensor / past the ragged length / past K get an
+// offset beyond num_records, for which the hardware returns zeros: no address arithmetic, no mask and no select in the K loop
+// (the generic loader spends ~180 VALU instructions per K tile and wave, of which ~45 are the plane conversion itself).
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p, int* range_flag) {
     static_assert(!F16 || NP == 2, "the fp16 form has two planes");
     constexpr int BK = SBK;
@@ -153,16 +170,65 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
         }
     };
 
-    unsigned oor = 0;  // F16: an operand outside the fp16 range was seen
+    float amax = 0.f;  // F16: largest operand magnitude seen (fp16 range check)
+    bool raw = false;
+#ifdef CBX_DIAG
+    raw = p.reserved0 & 2;
+#endif
+    // ---- fast loader (LD != 0)
+    constexpr int OOB = (int)0x80000000;  // >= num_records: the load returns 0
+    const int nk = (K + BK - 1) / BK;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t a_rs, b_rs;
+    [[maybe_unused]] int a_vo[A_IT], b_vo[B_IT], a_rr[A_IT], a_lin[A_IT];
+    if constexpr (LD != 0) {
+        a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, OOB, 0x00020000);
+        b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            a_rr[i] = a_ok[i] ? a_row[i] : OOB;                         // input row of tap 0 (negative: never valid)
+            a_lin[i] = (a_row[i] * (int)p.lda + a_c4) * 4;              // its byte offset (dispatch guarantees 31 bits)
+            a_vo[i] = (a_rr[i] >= 0 && a_rr[i] < lim) ? a_lin[i] : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_vo[i] = b_ok[i] ? ((n0 + l_row + RP * i) * (int)p.ldw + a_c4) * 4 : OOB;
+    }
+    const int tap_bytes = p.dil * (int)p.lda * 4;
+    auto load_fast = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT]) {
+        const int pe = ld_kt < nk ? 0 : OOB;  // the unrolled loop touches up to three tiles past the end: zeros
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[i] | pe, ld_c0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[i] | pe, ld_kt * (BK * 4), 0));
+        ld_kt += 1;
+        ld_c0 += BK;
+        if constexpr (LD == 2) {  // next tap: rows move by dil, validity is re-derived (branch-free: the K loop stays one basic block)
+            const bool wrap = ld_c0 >= p.Cin;
+            ld_c0 = wrap ? 0 : ld_c0;
+            const int dr = wrap ? p.dil : 0, db = wrap ? tap_bytes : 0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                a_rr[i] += dr;
+                a_lin[i] += db;
+                a_vo[i] = (a_rr[i] >= 0 && a_rr[i] < lim) ? a_lin[i] : OOB;
+            }
+        }
+    };
+    auto load_any = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT], unsigned& okmask) {
+        if constexpr (LD != 0) load_fast(ra, rb);
+        else load_tiles(ra, rb, okmask);
+    };
+
     auto store_tiles = [&](int buf, const f32x4(&ra)[A_IT], const f32x4(&rb)[B_IT], unsigned okmask) {
         __bf16* st = smem + buf * STAGE;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            split_store<NP, F16>((okmask >> i) & 1u ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE, oor);
+            split_store<NP, F16>(LD || ((okmask >> i) & 1u) ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE, amax, raw);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            split_store<NP, F16>((okmask >> (16 + i)) & 1u ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE, oor);
+            split_store<NP, F16>(LD || ((okmask >> (16 + i)) & 1u) ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE, amax, raw);
     };
 
     f32x16 acc[TM][TN];
@@ -218,30 +284,36 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     };
 
     // ---- main loop: registers hold tiles kt+1 and kt+2 in flight while tile kt is consumed from LDS
-    const int nk = (K + BK - 1) / BK;
     f32x4 ra[2][A_IT], rb[2][B_IT];
     unsigned ok0 = 0, ok1 = 0;
-    load_tiles(ra[0], rb[0], ok0);
+    load_any(ra[0], rb[0], ok0);
     store_tiles(0, ra[0], rb[0], ok0);
-    load_tiles(ra[1], rb[1], ok1);
+    load_any(ra[1], rb[1], ok1);
     __syncthreads();
     // Branch-free body: tiles past the end of K load the tensor base with an all-false mask (zeros in LDS, adds 0), so the
     // number of loads in flight at every wait is the same on every path and hipcc emits exact vmcnt(N) instead of vmcnt(0).
+#ifdef CBX_DIAG
+    const int dg = p.reserved0;
+#define DG(bit) (dg & (bit))
+#else
+#define DG(bit) 0
+#endif
     for (int kt = 0; kt < nk; kt += 2) {
-        load_tiles(ra[0], rb[0], ok0);       // tile kt+2
-        compute(0);                          // tile kt
+        if (!DG(1)) load_any(ra[0], rb[0], ok0);         // tile kt+2
+        if (!DG(4)) compute(0);                          // tile kt
         if constexpr (NS == 1) __syncthreads();  // every wave is done reading the single stage
-        store_tiles(NS == 1 ? 0 : 1, ra[1], rb[1], ok1);   // tile kt+1
+        if (!DG(8)) store_tiles(NS == 1 ? 0 : 1, ra[1], rb[1], ok1);   // tile kt+1
         __syncthreads();
-        load_tiles(ra[1], rb[1], ok1);       // tile kt+3
-        compute(NS == 1 ? 0 : 1);            // tile kt+1 (all zero when nk is odd and this is past the end)
+        if (!DG(1)) load_any(ra[1], rb[1], ok1);         // tile kt+3
+        if (!DG(4)) compute(NS == 1 ? 0 : 1);            // tile kt+1 (all zero when nk is odd and this is past the end)
         if constexpr (NS == 1) __syncthreads();
-        store_tiles(0, ra[0], rb[0], ok0);   // tile kt+2
+        if (!DG(8)) store_tiles(0, ra[0], rb[0], ok0);   // tile kt+2
         __syncthreads();
     }
+#undef DG
 
     if constexpr (F16) {
-        if (oor && range_flag) atomicOr(range_flag, 1);
+        if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -289,10 +361,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
 
 int* g_range_flag = nullptr;
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0>
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * NP * (BM + BN) * SLD * sizeof(__bf16);
-    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16>;
+    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16, LD>;
     static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -331,6 +403,24 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     // measured on the CFM shapes (scripts/bench_gemm.py): 128x64 / 8 waves / 2 workgroups per CU beats 128x128 (1 per CU) by
     // 5-45 % and 64x64 by 0-15 %
     int tile = force ? force : (g128 >= 64 && p.N >= 64 ? 12864 : 64);
+    // loader: 1 / 2 = raw buffer loads (Linear / Conv1d), needs K tiles that never straddle the end of K and 31-bit byte offsets
+    static const int no_fast = getenv("CBX_SPLIT_GENERIC_LOADER") ? atoi(getenv("CBX_SPLIT_GENERIC_LOADER")) : 0;
+    const bool fast = !no_fast && p.up == 1 && p.K % SBK == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
+                      (long)(p.N + 128) * p.ldw * 4 < 0x7fffffffL && (long)p.pad_left * p.lda * 4 < 0x3fffffffL;
+    const int ld = !fast ? 0 : p.taps == 1 ? 1 : 2;
+    if (ld && !force) {  // the default tiles with the fast loader
+        const bool wide = tile == 12864;
+        if (planes == 16) {
+            if (wide) return ld == 1 ? launch_split<128, 64, 4, 2, 2, 2, true, 1>(p, st) : launch_split<128, 64, 4, 2, 2, 2, true, 2>(p, st);
+            return ld == 1 ? launch_split<64, 64, 2, 2, 2, 2, true, 1>(p, st) : launch_split<64, 64, 2, 2, 2, 2, true, 2>(p, st);
+        }
+        if (planes == 2) {
+            if (wide) return ld == 1 ? launch_split<128, 64, 4, 2, 2, 2, false, 1>(p, st) : launch_split<128, 64, 4, 2, 2, 2, false, 2>(p, st);
+            return ld == 1 ? launch_split<64, 64, 2, 2, 2, 2, false, 1>(p, st) : launch_split<64, 64, 2, 2, 2, 2, false, 2>(p, st);
+        }
+        if (wide) return ld == 1 ? launch_split<128, 64, 4, 2, 3, 1, false, 1>(p, st) : launch_split<128, 64, 4, 2, 3, 1, false, 2>(p, st);
+        return ld == 1 ? launch_split<64, 64, 2, 2, 3, 2, false, 1>(p, st) : launch_split<64, 64, 2, 2, 3, 2, false, 2>(p, st);
+    }
     if (planes == 16) {
         if (tile == 12801) return launch_split<128, 128, 2, 4, 2, 1, true>(p, st);
         if (tile == 1286401) return launch_split<128, 64, 4, 2, 2, 1, true>(p, st);

@@ -81,6 +81,9 @@ def _f32(t, name):
 GEMM_PRECISION = 0  # cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued while set: 0 default, 1 exact, 3 / 6 split-bf16, 16 split-fp16
 
 
+GEMM_DIAG = 0  # cbx_gemm_t.reserved0: only read by a -DCBX_DIAG build of gemm_split.hip (scripts/diag_gemm.sh)
+
+
 class gemm_precision:
     """`with ops.gemm_precision(6): ...` -- the engines scope their numerics policy this way (T3 stays exact: sampled
     tokens must match the reference bit for bit; the CFM / vocoder run the fp32-accurate split-bf16 kernels)."""
@@ -141,6 +144,7 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldr, p.r_s1, p.r_s2 = ldr, r_s[0], r_s[1]
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
     p.precision = GEMM_PRECISION
+    p.reserved0 = GEMM_DIAG
     nz = nz1 * nz2
     split = GEMM_PRECISION in (3, 6, 16) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
     kind = "gemm_f32_skinny" if M <= 32 else ("gemm_split" if split else "gemm_f32")  # mirrors the dispatch in gemm_f32.hip

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from chatterbox_amd import ops
 dev = torch.device("cuda:0")
+ops.GEMM_DIAG = int(os.environ.get("CBX_DIAG", "0"))
 M = 16000
 shapes = [("qkv", M, 1536, 256, 1), ("attn_out", M, 256, 512, 1), ("ff1+gelu", M, 1024, 256, 1), ("ff2", M, 256, 1024, 1),
           ("conv3_256", M, 256, 768, 3), ("conv3_320", M, 256, 960, 3), ("conv3_512", M, 256, 1536, 3), ("res1x1", M, 256, 256, 1),

@@ -411,6 +411,9 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     if (ld && !force) {  // the default tiles with the fast loader
         const bool wide = tile == 12864;
         if (planes == 16) {
+            // K <= 256 (8 K tiles: the transformer blocks' q/k/v and ff1 projections): the single-stage form is 3-10 % faster; other wave
+            // shapes (64x32 / 64x64 per wave, 128x128 and 256x64 tiles) all measured slower: profiles/r02_bench_gemm_f16x3_wave_shapes_rejected.log
+            if (wide && ld == 1 && p.K <= 256) return launch_split<128, 64, 4, 2, 2, 1, true, 1>(p, st);
             if (wide) return ld == 1 ? launch_split<128, 64, 4, 2, 2, 2, true, 1>(p, st) : launch_split<128, 64, 4, 2, 2, 2, true, 2>(p, st);
             return ld == 1 ? launch_split<64, 64, 2, 2, 2, 2, true, 1>(p, st) : launch_split<64, 64, 2, 2, 2, 2, true, 2>(p, st);
         }

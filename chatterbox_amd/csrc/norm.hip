@@ -73,13 +73,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Narrow rows (C = 64*NV floats, NV = 4: the 256-channel LayerNorms of the CFM estimator -- 1500 launches per utterance
 // batch): 16 lanes per row, 4 rows per wave, NV float4 per lane all in flight at once (a wave streams 4 KiB instead of 1 KiB
 // per round trip), statistics by 4 xor-shuffles inside the 16-lane group.
-template <int NV>
+template <int NV, int RPT>
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ w, const float* __restrict__ b,
                                                                const float* __restrict__ post_add, long rows, long ldx, long ldy,
                                                                float eps, int rms, int act, float out_scale) {
     constexpr int C = 64 * NV;
-    constexpr int RPT = 2;  // rows per 16-lane group: 2 x NV float4 loads in flight per lane (8 KiB per wave per round trip)
+    // RPT = rows per 16-lane group: RPT x NV float4 loads in flight per lane (RPT x 4 KiB per wave per round trip)
     const int l16 = threadIdx.x & 15;
     const long row0 = (long)blockIdx.x * (16 * RPT) + (threadIdx.x >> 4);
     f32x4 v[RPT][NV];
@@ -158,8 +158,12 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     if (rows <= 0) return 0;
     static const int narrow = getenv("CBX_LN_NARROW") ? atoi(getenv("CBX_LN_NARROW")) : 1;
     if (narrow && C == 256 && rows >= 64) {
-        hipLaunchKernelGGL(layernorm_narrow_kernel<4>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, y, w,
-                           b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
+        if (narrow == 2)
+            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 2>), dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+                               b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
+        else
+            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+                               b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
         return cbx_check_launch("layernorm");
     }
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b,

@@ -26,9 +26,10 @@ for name, m, n, k, taps in shapes:
     b = torch.randn(n, device=dev)
     out = torch.empty(16, m // 16, n + PAD, device=dev)[..., :n]
     r = torch.randn(16, m // 16, n + PAD, device=dev)[..., :n]
+    ACT = getattr(ops, os.environ.get("CBX_ACT", "NONE"))
     def run():
         if taps == 1:
-            ops.conv1d(x[:, : m // 16], w, out, taps=1, cin=cin, bias=b, residual=r)
+            ops.conv1d(x[:, : m // 16], w, out, taps=1, cin=cin, bias=b, residual=None if ACT else r, act=ACT)
         else:
             ops.conv1d(x[:, : m // 16], w, out, taps=taps, cin=cin, bias=b, pad_left=taps - 1)
     line = f"{name:16s} M={m:6d} N={n:5d} K={k:5d} "

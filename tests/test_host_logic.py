@@ -63,6 +63,42 @@ def test_gemm_precision_scope_nests_and_restores():
     assert ops.GEMM_PRECISION == 0
 
 
+def test_range_checked_repeats_at_bf16x6_and_restores(monkeypatch):
+    """engine._range_checked (host logic of the default f16x3 numerics): a tripped range flag repeats the S3Gen work once at precision 6
+    with a warning, the engines' precisions are restored, an untripped flag or check=False runs once."""
+    import types
+    import warnings
+    from chatterbox_amd import engine, ops
+    eng = types.SimpleNamespace(flow=types.SimpleNamespace(precision=16), hift=types.SimpleNamespace(precision=16))
+    seen = []
+
+    def run():
+        seen.append((eng.flow.precision, eng.hift.precision))
+        return len(seen)
+    flags = iter([True])
+    monkeypatch.setattr(ops, "range_flag_tripped", lambda: next(flags, False))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert engine._range_checked(eng, run) == 2
+    assert seen == [(16, 16), (6, 6)] and (eng.flow.precision, eng.hift.precision) == (16, 16)
+    assert any("fp16 range" in str(x.message) for x in w)
+    seen.clear()
+    assert engine._range_checked(eng, run) == 1 and seen == [(16, 16)]          # flag not raised
+    seen.clear()
+    monkeypatch.setattr(ops, "range_flag_tripped", lambda: True)
+    assert engine._range_checked(eng, run, check=False) == 1 and seen == [(16, 16)]  # caller checks later
+    eng.flow.precision = eng.hift.precision = 6                                    # nothing to fall back from
+    seen.clear()
+    assert engine._range_checked(eng, run) == 1 and seen == [(6, 6)]
+    eng.flow.precision, eng.hift.precision = 16, 1                                 # only the f16x3 engine changes mode
+    seen.clear()
+    engine._range_checked(eng, run)
+    assert seen == [(16, 1), (6, 1)] and (eng.flow.precision, eng.hift.precision) == (16, 1)
+    # precision 16 is a legal scope and labelled in bench.py's roofline objects
+    with ops.gemm_precision(16):
+        assert ops.GEMM_PRECISION == 16
+
+
 def test_ops_fail_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
@@ -197,6 +233,8 @@ def test_bench_roofline_assembly_is_pure_and_consistent():
     # exact mode prices the same classes against the fp32 MFMA peak
     r1 = bench.roofline_entries({"gemm_f32": summ["gemm_f32"], "flash_attn_f32": summ["flash_attn_f32"]}, 2.0, 3, 1, 1, 249, None)
     assert r1["flash_attn_f32"]["peak"] == bench.MFMA_F32_PEAK_TFLOPS and "fp32_equivalent_tflops" not in r1["flash_attn_f32"]
+    r16 = bench.roofline_entries(summ, elapsed=2.0, steps=3, timed_steps=1, s3_prec=16, n_decode=249, gemv=None)
+    assert "f16x3" in r16["gemm_split"]["kernel"] and abs(r16["gemm_split"]["achieved"] - 480.0) < 1e-6  # 3 products, like bf16x3
     tr, src = bench.pmc_traffic("gemm_split_kernel")
     assert tr is None or (tr > 1e6 and "profiles/" in src)
 

@@ -19,8 +19,14 @@ namespace {
 
 // K tile: 16 or 32 floats.  LDS row stride BK+4 floats (80 / 144 B): 16-B aligned and conflict-free for the b128 lane groups
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK>
+// LD = 1 (only with !W_KN; up == 1, K % BK == 0, 31-bit byte offsets -- checked by the dispatcher): the loader of gemm_split.hip.  Row offsets
+// are 32-bit VGPRs computed once (per tap for convolutions), the K advance is a scalar offset of raw buffer loads, rows outside the
+// tensor / ragged length / K read zeros from the hardware; tiles are prefetched TWO ahead and the K loop is one basic block (the generic
+// loader predicates every load, which makes hipcc wait for all of them at the join, and prefetches one tile ahead).  Same MFMA order:
+// results are bit-identical to LD = 0.
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK, int LD = 0>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const cbx_gemm_t p) {
+    static_assert(!LD || !W_KN, "the buffer-load loader serves W in [N][K] layout");
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int LDS_LD = BK + 4;
@@ -164,14 +170,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
     const int lr = lane & 31, lh = lane >> 5;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    auto compute = [&](int cur) {
         const float* as = &As[cur][(wm * WM + lr) * LDS_LD + 4 * lh];
         const float* bs = &Bs[cur][(wn * WN + lr) * LDS_LD + 4 * lh];
 #pragma unroll
@@ -189,9 +189,83 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+    };
+
+    if constexpr (LD != 0) {
+        constexpr int OOB = (int)0x80000000;  // byte offset >= num_records: the load returns 0
+        const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, OOB, 0x00020000);
+        int a_vo[A_IT], a_rr[A_IT], a_lin[A_IT], b_vo[B_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            a_rr[i] = a_ok[i] ? a_row[i] : OOB;                 // input row of tap 0 (negative: never valid)
+            a_lin[i] = (a_row[i] * (int)p.lda + a_c4) * 4;
+            a_vo[i] = (a_rr[i] >= 0 && a_rr[i] < lim) ? a_lin[i] : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_vo[i] = b_ok[i] ? ((n0 + (tid / TPR) + RP * i) * (int)p.ldw + a_c4) * 4 : OOB;
+        const int tap_bytes = p.dil * (int)p.lda * 4;
+        const bool conv = p.taps > 1;
+        int f_kt = 0, f_c0 = 0;
+        auto load_fast = [&](f32x4(&fa)[A_IT], f32x4(&fb)[B_IT]) {
+            const int pe = f_kt < nk ? 0 : OOB;  // the unrolled loop touches up to three tiles past the end: zeros
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                fa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[i] | pe, f_c0 * 4, 0));
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                fb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[i] | pe, f_kt * (BK * 4), 0));
+            f_kt += 1;
+            f_c0 += BK;
+            // next tap (convolutions; a Linear has Cin = K and never wraps inside the loop): rows move by dil, validity is re-derived,
+            // branch-free so that the K loop stays one basic block
+            const bool wrap = conv && f_c0 >= p.Cin;
+            f_c0 = wrap ? 0 : f_c0;
+            const int dr = wrap ? p.dil : 0, db = wrap ? tap_bytes : 0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                a_rr[i] += dr;
+                a_lin[i] += db;
+                a_vo[i] = (a_rr[i] >= 0 && a_rr[i] < lim) ? a_lin[i] : OOB;
+            }
+        };
+        auto store_fast = [&](int buf, const f32x4(&fa)[A_IT], const f32x4(&fb)[B_IT]) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                if (!A_PART || (tid / TPR) + RP * i < BM)
+                    *reinterpret_cast<f32x4*>(&As[buf][((tid / TPR) + RP * i) * LDS_LD + a_c4]) = fa[i];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                if (!B_PART || (tid / TPR) + RP * i < BN)
+                    *reinterpret_cast<f32x4*>(&Bs[buf][((tid / TPR) + RP * i) * LDS_LD + a_c4]) = fb[i];
+        };
+        f32x4 fa[2][A_IT], fb[2][B_IT];
+        load_fast(fa[0], fb[0]);
+        store_fast(0, fa[0], fb[0]);
+        load_fast(fa[1], fb[1]);
         __syncthreads();
-        cur ^= 1;
+        for (int kt = 0; kt < nk; kt += 2) {
+            load_fast(fa[0], fb[0]);        // tile kt+2
+            compute(0);                     // tile kt
+            store_fast(1, fa[1], fb[1]);    // tile kt+1
+            __syncthreads();
+            load_fast(fa[1], fb[1]);        // tile kt+3
+            compute(1);                     // tile kt+1 (all zero when nk is odd and this is past the end)
+            store_fast(0, fa[0], fb[0]);    // tile kt+2
+            __syncthreads();
+        }
+    } else {
+        load_tiles(0);
+        store_tiles(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            compute(cur);
+            if (kt + 1 < nk) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -241,11 +315,18 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK = 16>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool W_KN, int BK = 16, int LD = 0>
 int launch(const cbx_gemm_t& p, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WARPS_M, WARPS_N, W_KN, BK>), grid, dim3(WARPS_M * WARPS_N * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WARPS_M, WARPS_N, W_KN, BK, LD>), grid, dim3(WARPS_M * WARPS_N * 64), 0, st, p);
     return cbx_check_launch("gemm_f32");
+}
+
+// can the buffer-load loader serve this call?  (K tiles that never straddle the end of K or a conv tap, 31-bit byte offsets)
+bool fast_loader_ok(const cbx_gemm_t& p, int bk) {
+    static const int off = getenv("CBX_GEMM_GENERIC_LOADER") ? atoi(getenv("CBX_GEMM_GENERIC_LOADER")) : 0;
+    return !off && !p.w_kn && p.up == 1 && p.K % bk == 0 && p.Cin % bk == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
+           (long)(p.N + 256) * p.ldw * 4 < 0x7fffffffL && (long)p.pad_left * p.lda * 4 < 0x3fffffffL;
 }
 
 }  // namespace
@@ -278,6 +359,7 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     }
     if (p.swiglu) {
         if (p.M <= 32) return launch<32, 256, 1, 4, false>(p, st);
+        if (fast_loader_ok(p, 16)) return launch<128, 128, 2, 2, false, 16, 1>(p, st);
         return launch<128, 128, 2, 2, false>(p, st);
     }
     if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
@@ -308,6 +390,7 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
         if (force == 6464) return launch<64, 64, 2, 2, false>(p, st);
         // BK = 32 halves the barriers and loader work per MFMA; a K tile must stay inside one conv tap
         if (force == 32 && (p.taps == 1 || p.Cin % 32 == 0)) return launch<128, 64, 4, 2, false, 32>(p, st);
+        if (!force && fast_loader_ok(p, 16)) return launch<128, 64, 4, 2, false, 16, 1>(p, st);
         return launch<128, 64, 4, 2, false>(p, st);  // 8 waves x (32x32): 81 TF/s on the bench mix vs 77 for 64x64 (4 waves)
     }
     return launch<128, 128, 2, 2, false>(p, st);

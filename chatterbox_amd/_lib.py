@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 5  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 6  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -33,7 +33,7 @@ class GemmParams(ctypes.Structure):
         ("ldc", c_long), ("c_s1", c_long), ("c_s2", c_long),
         ("ldr", c_long), ("r_s1", c_long), ("r_s2", c_long),
         ("ldc2", c_long), ("c2_s1", c_long), ("c2_s2", c_long),
-        ("precision", c_int), ("reserved0", c_int),
+        ("precision", c_int), ("reserved0", c_int), ("ln_stats", c_f), ("ln_w", c_f), ("ln_b", c_f),
     ]
 
 
@@ -86,6 +86,7 @@ _SIGS = {
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
     "cbx_set_split_tile": ([c_int], c_int),
     "cbx_set_range_flag": ([c_f], c_int),
+    "cbx_row_stats_f32": ([c_f, c_f, c_long, c_int, c_long, c_float, c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),
     "cbx_axpby_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_float, c_f], c_int),

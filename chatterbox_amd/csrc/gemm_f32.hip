@@ -353,6 +353,8 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
                 "gemm: W must be 16-byte aligned (ldw=%ld)", p.ldw);
     CBX_REQUIRE((long)p.nz1 * p.nz2 <= 65535, "gemm: too many batches");
     CBX_REQUIRE(!p.swiglu || (p.N % 64 == 0 && !p.bias && !p.R && !p.C2 && !p.w_kn), "gemm: bad swiglu config");
+    CBX_REQUIRE(!p.ln_stats || (!p.w_kn && !p.swiglu && p.M > 32 && (p.precision ? p.precision : 0) == 16),
+                "gemm: ln_stats (LayerNorm folded into A) is served by the precision-16 split kernel only, M > 32");
     if (p.w_kn) {
         if (p.N <= 64) return launch<128, 64, 2, 2, true>(p, st);
         return launch<128, 128, 2, 2, true>(p, st);
@@ -372,6 +374,7 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
         if (prec != 1) {
             int rc = cbx_gemm_split_dispatch(p, prec == 16 ? 16 : prec == 3 ? 2 : 3, st);
             if (rc != -1) return rc;
+            CBX_REQUIRE(!p.ln_stats, "gemm: ln_stats on a shape the split kernel does not serve");
         }
     }
     if (p.N <= 64) return launch<128, 64, 2, 2, false>(p, st);

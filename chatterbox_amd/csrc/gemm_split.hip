@@ -75,8 +75,12 @@ __device__ __forceinline__ void split_store(const f32x4 v, __bf16* dst, int plan
 // (per tap for convolutions), the K advance is a scalar offset, and rows outside the tensor / past the ragged length / past K get an
 // offset beyond num_records, for which the hardware returns zeros: no address arithmetic, no mask and no select in the K loop
 // (the generic loader spends ~180 VALU instructions per K tile and wave, of which ~45 are the plane conversion itself).
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0>
+// LN (with LD = 1): LayerNorm folded into the A operand -- (a - mean[m]) * rstd[m] * ln_w[k] + ln_b[k] (the expression of norm.hip) is applied
+// to the fp32 tile in registers just before the plane split; mean / rstd come from cbx_row_stats_f32, ln_w / ln_b tiles ride along with
+// the operand tiles (buffer loads, zeros past K).  Rows past M carry garbage that only reaches output rows that are never stored.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0, bool LN = false>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(const cbx_gemm_t p, int* range_flag) {
+    static_assert(!LN || LD == 1, "the folded LayerNorm rides on the Linear buffer-load loader");
     static_assert(!F16 || NP == 2, "the fp16 form has two planes");
     constexpr int BK = SBK;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -192,9 +196,25 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) b_vo[i] = b_ok[i] ? ((n0 + l_row + RP * i) * (int)p.ldw + a_c4) * 4 : OOB;
     }
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t lw_rs, lb_rs;
+    [[maybe_unused]] float ln_mean[A_IT], ln_rstd[A_IT];
+    if constexpr (LN) {
+        lw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_w), 0, OOB, 0x00020000);
+        lb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_b), 0, OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + l_row + RP * i;
+            ln_mean[i] = a_ok[i] ? p.ln_stats[2 * (long)m] : 0.f;
+            ln_rstd[i] = a_ok[i] ? p.ln_stats[2 * (long)m + 1] : 0.f;
+        }
+    }
     const int tap_bytes = p.dil * (int)p.lda * 4;
-    auto load_fast = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT]) {
+    auto load_fast = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT], f32x4& lg, f32x4& lb) {
         const int pe = ld_kt < nk ? 0 : OOB;  // the unrolled loop touches up to three tiles past the end: zeros
+        if constexpr (LN) {
+            lg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lw_rs, (a_c4 * 4) | pe, ld_kt * (BK * 4), 0));
+            lb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lb_rs, (a_c4 * 4) | pe, ld_kt * (BK * 4), 0));
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[i] | pe, ld_c0 * 4, 0));
@@ -215,17 +235,23 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
             }
         }
     };
-    auto load_any = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT], unsigned& okmask) {
-        if constexpr (LD != 0) load_fast(ra, rb);
+    auto load_any = [&](f32x4(&ra)[A_IT], f32x4(&rb)[B_IT], unsigned& okmask, f32x4& lg, f32x4& lb) {
+        if constexpr (LD != 0) load_fast(ra, rb, lg, lb);
         else load_tiles(ra, rb, okmask);
     };
 
-    auto store_tiles = [&](int buf, const f32x4(&ra)[A_IT], const f32x4(&rb)[B_IT], unsigned okmask) {
+    auto store_tiles = [&](int buf, const f32x4(&ra)[A_IT], const f32x4(&rb)[B_IT], unsigned okmask, const f32x4 lg, const f32x4 lb) {
         __bf16* st = smem + buf * STAGE;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            split_store<NP, F16>(LD || ((okmask >> i) & 1u) ? ra[i] : zero, st + (l_row + RP * i) * SLD + a_c4, PLANE, amax, raw);
+        for (int i = 0; i < A_IT; ++i) {
+            f32x4 a = LD || ((okmask >> i) & 1u) ? ra[i] : zero;
+            if constexpr (LN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (a[e] - ln_mean[i]) * ln_rstd[i] * lg[e] + lb[e];
+            }
+            split_store<NP, F16>(a, st + (l_row + RP * i) * SLD + a_c4, PLANE, amax, raw);
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             split_store<NP, F16>(LD || ((okmask >> (16 + i)) & 1u) ? rb[i] : zero, st + (BM + l_row + RP * i) * SLD + a_c4, PLANE, amax, raw);
@@ -284,11 +310,11 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     };
 
     // ---- main loop: registers hold tiles kt+1 and kt+2 in flight while tile kt is consumed from LDS
-    f32x4 ra[2][A_IT], rb[2][B_IT];
+    f32x4 ra[2][A_IT], rb[2][B_IT], lg[2], lbt[2];
     unsigned ok0 = 0, ok1 = 0;
-    load_any(ra[0], rb[0], ok0);
-    store_tiles(0, ra[0], rb[0], ok0);
-    load_any(ra[1], rb[1], ok1);
+    load_any(ra[0], rb[0], ok0, lg[0], lbt[0]);
+    store_tiles(0, ra[0], rb[0], ok0, lg[0], lbt[0]);
+    load_any(ra[1], rb[1], ok1, lg[1], lbt[1]);
     __syncthreads();
     // Branch-free body: tiles past the end of K load the tensor base with an all-false mask (zeros in LDS, adds 0), so the
     // number of loads in flight at every wait is the same on every path and hipcc emits exact vmcnt(N) instead of vmcnt(0).
@@ -299,15 +325,15 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
 #define DG(bit) 0
 #endif
     for (int kt = 0; kt < nk; kt += 2) {
-        if (!DG(1)) load_any(ra[0], rb[0], ok0);         // tile kt+2
+        if (!DG(1)) load_any(ra[0], rb[0], ok0, lg[0], lbt[0]);  // tile kt+2
         if (!DG(4)) compute(0);                          // tile kt
         if constexpr (NS == 1) __syncthreads();  // every wave is done reading the single stage
-        if (!DG(8)) store_tiles(NS == 1 ? 0 : 1, ra[1], rb[1], ok1);   // tile kt+1
+        if (!DG(8)) store_tiles(NS == 1 ? 0 : 1, ra[1], rb[1], ok1, lg[1], lbt[1]);   // tile kt+1
         __syncthreads();
-        if (!DG(1)) load_any(ra[1], rb[1], ok1);         // tile kt+3
+        if (!DG(1)) load_any(ra[1], rb[1], ok1, lg[1], lbt[1]);  // tile kt+3
         if (!DG(4)) compute(NS == 1 ? 0 : 1);            // tile kt+1 (all zero when nk is odd and this is past the end)
         if constexpr (NS == 1) __syncthreads();
-        if (!DG(8)) store_tiles(0, ra[0], rb[0], ok0);   // tile kt+2
+        if (!DG(8)) store_tiles(0, ra[0], rb[0], ok0, lg[0], lbt[0]);   // tile kt+2
         __syncthreads();
     }
 #undef DG
@@ -361,10 +387,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
 
 int* g_range_flag = nullptr;
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0, bool LN = false>
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * NP * (BM + BN) * SLD * sizeof(__bf16);
-    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16, LD>;
+    auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16, LD, LN>;
     static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -408,6 +434,13 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     const bool fast = !no_fast && p.up == 1 && p.K % SBK == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
                       (long)(p.N + 128) * p.ldw * 4 < 0x7fffffffL && (long)p.pad_left * p.lda * 4 < 0x3fffffffL;
     const int ld = !fast ? 0 : p.taps == 1 ? 1 : 2;
+    if (p.ln_stats) {  // LayerNorm folded into the A operand: f16x3 Linear on the buffer-load loader only -- anything else is a caller error
+        if (planes != 16 || ld != 1 || force || p.nz1 * p.nz2 != 1 || p.lens || !p.ln_w || !p.ln_b)
+            return cbx_set_error(CBX_EINVAL, "gemm: ln_stats needs precision 16, taps == 1, up == 1, K %% 32 == 0, one batch, no lens, ln_w and ln_b");
+        if (tile == 12864 && p.K <= 256) return launch_split<128, 64, 4, 2, 2, 1, true, 1, true>(p, st);
+        if (tile == 12864) return launch_split<128, 64, 4, 2, 2, 2, true, 1, true>(p, st);
+        return launch_split<64, 64, 2, 2, 2, 2, true, 1, true>(p, st);
+    }
     if (ld && !force) {  // the default tiles with the fast loader
         const bool wide = tile == 12864;
         if (planes == 16) {

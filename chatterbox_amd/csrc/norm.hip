@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Narrow rows (C = 64*NV floats, NV = 4: the 256-channel LayerNorms of the CFM estimator -- 1500 launches per utterance
 // batch): 16 lanes per row, 4 rows per wave, NV float4 per lane all in flight at once (a wave streams 4 KiB instead of 1 KiB
 // per round trip), statistics by 4 xor-shuffles inside the 16-lane group.
-template <int NV, int RPT>
+// STATS: write {mean, rstd} per row to y (2 floats per row) instead of the normalised row (cbx_row_stats_f32): same loads, same reductions.
+template <int NV, int RPT, bool STATS = false>
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ w, const float* __restrict__ b,
                                                                const float* __restrict__ post_add, long rows, long ldx, long ldy,
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
     f32x4 wv[NV], bv[NV], pv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+        if constexpr (STATS) continue;
         const int c = (i * 16 + l16) * 4;
         wv[i] = *reinterpret_cast<const f32x4*>(w + c);
         bv[i] = b ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -132,6 +134,13 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
             rstd = rsqrtf(q / C + eps);
         }
         if (row >= rows) continue;
+        if constexpr (STATS) {
+            if (l16 == 0) {
+                y[2 * row] = mean;
+                y[2 * row + 1] = rstd;
+            }
+            continue;
+        }
         float* yr = y + row * ldy;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -169,4 +178,12 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b,
                        post_add, rows, C, ldx, ldy, eps, rms, act, out_scale);
     return cbx_check_launch("layernorm");
+}
+
+extern "C" int cbx_row_stats_f32(const float* x, float* stats, long rows, int C, long ldx, float eps, void* stream) {
+    CBX_REQUIRE(x && stats && C == 256 && ldx % 4 == 0, "row_stats: C must be 256 (got %d), ldx %% 4 == 0", C);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1, true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, stats,
+                       nullptr, nullptr, nullptr, rows, ldx, 0L, eps, 0, 0, 1.0f);
+    return cbx_check_launch("row_stats");
 }

@@ -4,6 +4,7 @@ torch is used only as the allocator / stream provider; every function below laun
 from libcbx_hip.so and raises if the library is unavailable (no eager fallback).
 """
 import ctypes
+import os
 
 import torch
 
@@ -100,6 +101,7 @@ class gemm_precision:
         GEMM_PRECISION = self._prev
 
 
+LN_FUSION = os.environ.get("CBX_LN_FUSION", "1") != "0"  # CFM transformer blocks: LayerNorm folded into the consuming Linear
 _RANGE_FLAG = None
 
 
@@ -126,7 +128,7 @@ def range_flag_tripped():
 def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, ldc2=0, act1=NONE, act2=NONE,
          act1_param=None, act2_param=None, act1_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, lens=None, Cin=0, taps=1,
          dil=1, stride=1, pad_left=0, up=1, Tin=0, nz1=1, nz2=1, a_s=(0, 0), w_s=(0, 0), c_s=(0, 0), r_s=(0, 0),
-         c2_s=(0, 0), w_kn=False, swiglu=False):
+         c2_s=(0, 0), w_kn=False, swiglu=False, ln=None):
     """Raw access to cbx_gemm_f32 (see include/cbx.h).  A/W/C... are tensors (their data_ptr() is the base)."""
     p = GemmParams()
     p.A, p.W, p.C = _p(_f32(A, "A")), _p(_f32(W, "W")), _p(_f32(C, "C"))
@@ -145,6 +147,8 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
     p.precision = GEMM_PRECISION
     p.reserved0 = GEMM_DIAG
+    if ln is not None:  # (stats (M, 2), ln_w (K,), ln_b (K,)): LayerNorm folded into the A operand (ln_fusable())
+        p.ln_stats, p.ln_w, p.ln_b = _p(_f32(ln[0], "ln stats")), _p(_f32(ln[1], "ln_w")), _p(_f32(ln[2], "ln_b"))
     nz = nz1 * nz2
     split = GEMM_PRECISION in (3, 6, 16) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
     kind = "gemm_f32_skinny" if M <= 32 else ("gemm_split" if split else "gemm_f32")  # mirrors the dispatch in gemm_f32.hip
@@ -153,16 +157,31 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     return C
 
 
+def ln_fusable(M, K):
+    """Can `linear(..., ln=...)` fold a LayerNorm over K into its A operand here?  (the f16x3 split kernel on its Linear loader, C = 256
+    statistics kernel: the CFM transformer blocks)"""
+    return GEMM_PRECISION == 16 and K == 256 and M > 32 and LN_FUSION
+
+
+def row_stats(x, stats, eps=1e-5):
+    """stats[r] = (mean, rstd) of row r of x (rows, 256), as layernorm() computes them."""
+    rows, C = x.shape
+    assert x.stride(1) == 1 and stats.is_contiguous() and stats.shape == (rows, 2)
+    check(lib.cbx_row_stats_f32(_p(_f32(x, "x")), _p(_f32(stats, "stats")), rows, C, x.stride(0), eps, _stream()), "cbx_row_stats_f32")
+    return stats
+
+
 def linear(x, w, out, bias=None, act=NONE, residual=None, out2=None, act2=NONE, act_param=None, act2_param=None,
-           act_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, swiglu=False):
-    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T).  x/out/residual are 2-D views with unit inner stride."""
+           act_slope=0.0, act2_slope=0.0, alpha=1.0, beta=0.0, swiglu=False, ln=None):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T).  x/out/residual are 2-D views with unit inner stride.
+    ln = (stats, ln_w, ln_b): x is LayerNorm'ed on the way in (row_stats() + ln_fusable())."""
     M, K = x.shape
     N = w.shape[0]
     assert x.stride(1) == 1 and out.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
     return gemm(x, w, out, M=M, N=N, K=K, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0), bias=bias, R=residual,
                 ldr=0 if residual is None else residual.stride(0), C2=out2, ldc2=0 if out2 is None else out2.stride(0),
                 act1=act, act2=act2, act1_param=act_param, act2_param=act2_param, act1_slope=act_slope,
-                act2_slope=act2_slope, alpha=alpha, beta=beta, swiglu=swiglu)
+                act2_slope=act2_slope, alpha=alpha, beta=beta, swiglu=swiglu, ln=ln)
 
 
 def conv1d(x, w, out, *, taps, cin, bias=None, dil=1, stride=1, pad_left=0, up=1, lens=None, act=NONE, residual=None,

@@ -214,13 +214,20 @@ class FlowEngine:
         """BasicTransformerBlock (matcha/transformer.py:243-316) with diffusers Attention/GELU semantics."""
         M = rows * T
         x2, h, qkv, att, ff = x.view(M, 256), ws["h"], ws["qkv"], ws["att"], ws["ff"]
-        ops.layernorm(x2, tw["n1"][0], tw["n1"][1], h, 1e-5)
-        ops.linear(h, tw["wqkv"], qkv)
+        fuse = ops.ln_fusable(M, 256)  # norm1 / norm3 folded into the q/k/v and ff1 projections: a statistics pass instead of a LayerNorm pass
+        if fuse:
+            ops.linear(x2, tw["wqkv"], qkv, ln=(ops.row_stats(x2, ws["stats"]), tw["n1"][0], tw["n1"][1]))
+        else:
+            ops.layernorm(x2, tw["n1"][0], tw["n1"][1], h, 1e-5)
+            ops.linear(h, tw["wqkv"], qkv)
         q5 = qkv.view(rows, T, 3, 8, 64)
         ops.flash_attn(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], att.view(rows, T, 8, 64), 0.125, key_lens=lens)
         ops.linear(att, tw["wo"], x2, bias=tw["bo"], residual=x2)
-        ops.layernorm(x2, tw["n3"][0], tw["n3"][1], h, 1e-5)
-        ops.linear(h, tw["w1"], ff, bias=tw["b1"], act=ops.GELU_ERF)
+        if fuse:
+            ops.linear(x2, tw["w1"], ff, bias=tw["b1"], act=ops.GELU_ERF, ln=(ops.row_stats(x2, ws["stats"]), tw["n3"][0], tw["n3"][1]))
+        else:
+            ops.layernorm(x2, tw["n3"][0], tw["n3"][1], h, 1e-5)
+            ops.linear(h, tw["w1"], ff, bias=tw["b1"], act=ops.GELU_ERF)
         ops.linear(ff, tw["w2"], x2, bias=tw["b2"], residual=x2)
 
     def _estimator(self, xin, rows, T, lens, tbias, ws):
@@ -290,7 +297,8 @@ class FlowEngine:
         f = lambda *s: torch.empty(*s, device=dev)
         ws = dict(ra=f(rows, T, 256), rb=f(rows, T, 256), x=f(rows, T, 256), x2=f(rows, T, 256), y=f(rows, T, 256),
                   cat=f(rows, T, 512),
-                  h=f(rows * T, 256), qkv=f(rows * T, 1536), att=f(rows * T, 512), ff=f(rows * T, 1024), v=f(rows, T, 80))
+                  h=f(rows * T, 256), qkv=f(rows * T, 1536), att=f(rows * T, 512), ff=f(rows * T, 1024), v=f(rows, T, 80),
+                  stats=f(rows * T, 2))
         xin = torch.zeros(rows, T, 320, device=dev)
         xin[:B, :, 0:80] = z
         xin[:B, :, 80:160] = mu

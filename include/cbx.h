@@ -15,8 +15,8 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 5  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
-                              5: precision 16 (f16x3) + cbx_set_range_flag */
+#define CBX_ABI_VERSION 6  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+                              5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32) */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -65,12 +65,21 @@ typedef struct cbx_gemm_t {
                                  bf16x3; operands must satisfy |a| <= 65504, see cbx_set_range_flag).  Shapes the split kernel does
                                  not serve (w_kn, swiglu, M <= 32, conv Cin % 32 != 0) run exact. */
     int reserved0;
+    /* ABI v6: LayerNorm folded into the A operand of a Linear (precision 16, taps == 1, nz == 1, no lens):
+     * A'[m][k] = (A[m][k] - mean[m]) * rstd[m] * ln_w[k] + ln_b[k] is applied on the way to the matrix cores, so the standalone
+     * F.layer_norm pass (one read + one write of the activation) becomes a statistics pass (cbx_row_stats_f32: one read). */
+    const float* ln_stats;    /* [M][2] = {mean, rstd} per row, or NULL */
+    const float* ln_w;        /* [K] */
+    const float* ln_b;        /* [K] */
 } cbx_gemm_t;
 int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
 /* Device word that every precision-16 launch (GEMM and flash attention) ORs a 1 into when it meets an operand outside the fp16 range
  * (its result is then not meaningful and the caller repeats the computation at precision 6, which has the fp32 exponent range).
  * NULL (the default) = not reported.  Process-global; the word must stay allocated while such launches are in flight. */
 int cbx_set_range_flag(int* dev_flag);
+/* stats[r] = {mean, rstd = 1/sqrt(var + eps)} of row r of x (C = 256: the CFM transformer blocks), computed exactly as cbx_layernorm_f32
+ * computes them; feeds cbx_gemm_t.ln_stats.  Replaces the statistics half of F.layer_norm (matcha/transformer.py:243-316 norm1 / norm3). */
+int cbx_row_stats_f32(const float* x, float* stats, long rows, int C, long ldx, float eps, void* stream);
 
 /* ---- skinny-M weight-streaming GEMM for decode (M = 2*B rows <= 64), HBM-roofline kernel ----
  * out[ks][m][n] = sum_{k in slice ks} x[m][k] * W[n][k]  (+ bias on slice 0);  ksplit > 1 leaves partial sums that

@@ -238,6 +238,37 @@ def test_split_flash_attn(dev, Tq, Tk, causal, prec):
     _close(out, ref.transpose(1, 2), {6: 2e-5, 16: 2e-5, 3: 1e-4}[prec], f"split flash_attn p{prec}")
 
 
+def test_layernorm_folded_into_linear(dev):
+    """cbx_row_stats_f32 + cbx_gemm_t.ln_*: LayerNorm applied to the A operand inside the f16x3 Linear == layernorm() followed by
+    linear() (same statistics kernel code, same normalisation expression), and within the split tolerance of torch; unsupported
+    configurations are refused loudly, never silently un-normalised."""
+    from chatterbox_amd import ops
+    from chatterbox_amd._lib import CbxError
+    K = 256
+    for (M, N) in [(16000, 1536), (1000, 1024), (333, 80)]:
+        x, w, b = _r((M, K + 4), 1, 3.0) + 1.5, _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3)
+        g, be = 1.0 + 0.3 * _r((K,), 4), _r((K,), 5)
+        xd, wd, gd, bd = x.to(dev)[:, :K], w.to(dev), g.to(dev), be.to(dev)
+        stats = ops.row_stats(xd, torch.empty(M, 2, device=dev))
+        mu, var = x[:, :K].mean(1), x[:, :K].var(1, unbiased=False)
+        _close(stats[:, 0], mu, 2e-6, "row mean")
+        _close(stats[:, 1], (var + 1e-5).rsqrt(), 2e-6, "row rstd")
+        fused, plain, h = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
+        with ops.gemm_precision(16):
+            assert ops.ln_fusable(M, K)
+            ops.linear(xd, wd, fused, bias=b.to(dev), act=ops.GELU_ERF, ln=(stats, gd, bd))
+            ops.layernorm(xd, gd, bd, h, 1e-5)
+            ops.linear(h, wd, plain, bias=b.to(dev), act=ops.GELU_ERF)
+        _close(fused, plain.cpu(), 2e-6, f"folded LN == LN + linear {M}x{N}")
+        _close(fused, F.gelu(F.linear(F.layer_norm(x[:, :K], (K,), g, be, 1e-5), w, b)), _SPLIT_TOL[16], "folded LN vs torch")
+    with ops.gemm_precision(6):  # only the f16x3 kernel carries the fold: any other mode must refuse, not ignore it
+        assert not ops.ln_fusable(1000, K)
+        with pytest.raises(CbxError):
+            ops.linear(xd, wd, fused, ln=(stats, gd, bd))
+    with ops.gemm_precision(16), pytest.raises(CbxError):
+        ops.linear(xd[:20], wd, fused[:20], ln=(stats, gd, bd))  # M <= 32: the skinny exact kernel
+
+
 def test_f16x3_accuracy_and_range_flag(dev):
     """precision 16 against an fp64 product: as close as the exact fp32 MFMA kernel over 8 decades of operand scale; operands beyond
     the fp16 range raise the device flag (and only they do)."""

@@ -1,0 +1,69 @@
+"""CPU model of the split-operand arithmetics of DESIGN.md section 1 (no GPU): the figures quoted there for bf16x3 / bf16x6 / f16x3 are
+properties of the plane decompositions themselves, so they are pinned here with torch on the host; the device kernels are checked against
+the same bounds in tests/test_ops_gpu.py (test_f16x3_accuracy_and_range_flag)."""
+import torch
+
+SCALE = 2048.0  # CBX_F16_LO_SCALE
+
+
+def f16_planes(x):
+    h = x.half()
+    l = ((x - h.float()) * SCALE).half()
+    return h.float(), l.float()
+
+
+def bf16_planes(x, n):
+    out, r = [], x.clone()
+    for _ in range(n):
+        q = r.bfloat16().float()
+        out.append(q)
+        r = r - q
+    return out
+
+
+def mm(a, b):
+    return a.double() @ b.double().t()
+
+
+def products(A, B):
+    ref = mm(A, B)
+    ah, al = f16_planes(A)
+    bh, bl = f16_planes(B)
+    f16x3 = mm(ah, bh) + (mm(ah, bl) + mm(al, bh)) / SCALE
+    a, b = bf16_planes(A, 3), bf16_planes(B, 3)
+    bf16x3 = mm(a[0], b[0]) + mm(a[0], b[1]) + mm(a[1], b[0])
+    bf16x6 = bf16x3 + mm(a[0], b[2]) + mm(a[2], b[0]) + mm(a[1], b[1])
+    fp32 = (A @ B.t()).double()
+    n = ref.abs().mean()
+    return {k: float((v - ref).abs().mean() / n) for k, v in dict(f16x3=f16x3, bf16x3=bf16x3, bf16x6=bf16x6, fp32=fp32).items()}
+
+
+def test_plane_pair_represents_fp32_to_22_bits():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1 << 16, generator=g) * torch.logspace(-3, 4, 1 << 16)
+    x = x[(x.abs() >= 1e-3) & (x.abs() <= 6.0e4)]  # first plane normal, inside the fp16 range
+    h, l = f16_planes(x)
+    rel = ((h.double() + l.double() / SCALE) - x.double()).abs() / x.double().abs()
+    assert rel.max() <= 2.0 ** -22  # half an ulp of h (2^-11) times half an ulp of l (2^-11)
+    assert torch.isfinite(l).all() and (l.abs() <= 1.001 * h.abs()).all()  # the scaled second plane is as large as the first: never sub-normal
+    small = torch.tensor([6.8e-7, -3.0e-6])  # sub-normal first plane: absolute, not relative, precision (2^-36 after the scaling)
+    hs, ls = f16_planes(small)
+    assert ((hs.double() + ls.double() / SCALE) - small.double()).abs().max() <= 2.0 ** -35
+
+
+def test_error_ladder_of_the_three_split_modes():
+    g = torch.Generator().manual_seed(1)
+    for sa, sb in [(1.0, 0.03), (100.0, 0.03), (1e-3, 0.03), (3000.0, 1.0)]:
+        e = products(torch.randn(256, 512, generator=g) * sa, torch.randn(192, 512, generator=g) * sb)
+        assert e["f16x3"] < 1.5e-7 and e["f16x3"] < e["fp32"], e          # below the fp32 accumulation error of an exact kernel
+        assert e["bf16x6"] < 2e-8, e                                         # all 24 significand bits kept
+        assert 1e-6 < e["bf16x3"] < 1e-5 and e["f16x3"] < 0.05 * e["bf16x3"], e  # the opt-in fast mode is ~60x less accurate
+
+
+def test_f16x3_degrades_gracefully_for_tiny_tensors_and_needs_the_range_check():
+    g = torch.Generator().manual_seed(2)
+    e = products(torch.randn(128, 256, generator=g) * 1e-5, torch.randn(64, 256, generator=g) * 1e-3)
+    assert e["f16x3"] < 3e-6  # sub-normal planes: towards bf16x3 accuracy, never garbage
+    big = torch.tensor([7.0e4, -1.0e5, 65504.0])
+    h, _ = f16_planes(big)
+    assert torch.isinf(h[:2]).all() and torch.isfinite(h[2])  # > 65504 overflows the first plane: what the device flag reports

@@ -109,6 +109,20 @@ def _make_analyzer(s3gen_sd, ve_sd, device):
     return PromptAnalyzer(s3gen_sd, ve_sd, device)
 
 
+def _norm_loudness(wav, sr, target_lufs=-27.0):
+    """Gain a waveform to `target_lufs` integrated loudness (reference ChatterboxTurboTTS.norm_loudness, tts_turbo.py:223-239): needs the
+    third-party `pyloudnorm`; on any error the reference prints a warning and carries on with the input, and so does this."""
+    try:
+        import numpy as np
+        import pyloudnorm as ln
+        gain = 10.0 ** ((target_lufs - ln.Meter(sr).integrated_loudness(wav)) / 20.0)
+        if np.isfinite(gain) and gain > 0.0:
+            wav = wav * gain
+    except Exception as e:
+        print(f"Warning: Error in norm_loudness, skipping: {e}")
+    return wav
+
+
 def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_seconds=None, norm_loudness=False):
     """The common body of prepare_conditionals (tts.py:182-206, mtl_tts.py:253-277, tts_turbo.py:241-270).  `wav`: a file path or a
     (waveform, sample_rate) pair."""
@@ -123,15 +137,7 @@ def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_s
     if min_seconds is not None:
         assert len(w24) / S3GEN_SR > min_seconds, "Audio prompt must be longer than 5 seconds!"
     if norm_loudness:
-        try:
-            import pyloudnorm as ln
-            import numpy as np
-            meter = ln.Meter(S3GEN_SR)
-            gain = 10.0 ** ((-27.0 - meter.integrated_loudness(w24)) / 20.0)
-            if np.isfinite(gain) and gain > 0.0:
-                w24 = w24 * gain
-        except Exception as e:  # the reference prints a warning and carries on (tts_turbo.py:236-237)
-            print(f"Warning: Error in norm_loudness, skipping: {e}")
+        w24 = _norm_loudness(w24, S3GEN_SR)
     w16 = fe.resample(w24, S3GEN_SR, S3_SR)
     gen = analyzer.embed_ref(w24[: analyzer.DEC_COND_LEN], S3GEN_SR)
     spk, ptoks = analyzer.t3_prompt(w16, prompt_len)
@@ -310,6 +316,9 @@ class ChatterboxTurboTTS:
         c = synth.t3_cond(prompt_len=375)
         return cls(eng, None, device, Conditionals(T3Cond(speaker_emb=c["speaker_emb"], cond_prompt_speech_tokens=c["cond_prompt_speech_tokens"],
                                                           emotion_adv=None), synth.s3gen_ref()), "Nano" if nano else "Turbo")
+
+    def norm_loudness(self, wav, sr, target_lufs=-27):
+        return _norm_loudness(wav, sr, target_lufs)
 
     def prepare_conditionals(self, wav_fpath, exaggeration=0.0, norm_loudness=True):
         """reference tts_turbo.py:241-270 (prompt > 5 s, optional loudness normalisation to -27 LUFS, 375 prompt tokens)."""

@@ -201,6 +201,20 @@ def test_conditionals_roundtrip_and_api_surface(tmp_path):
     assert compat.ChatterboxMultilingualTTS is ChatterboxMultilingualTTS
 
 
+def test_turbo_norm_loudness_is_exposed_and_never_raises(capsys):
+    """reference ChatterboxTurboTTS.norm_loudness (tts_turbo.py:223-239): a gain towards -27 LUFS when pyloudnorm is there, otherwise
+    the input comes back with the reference's warning -- never an exception."""
+    import numpy as np
+    from chatterbox_amd import api
+    wav = (0.1 * np.sin(np.arange(24000 * 2) * 0.05)).astype(np.float32)
+    out = api.ChatterboxTurboTTS.norm_loudness(None, wav, 24000)
+    try:
+        import pyloudnorm  # noqa: F401
+        assert out.shape == wav.shape and np.isfinite(out).all()
+    except ImportError:
+        assert out is wav and "norm_loudness" in capsys.readouterr().out
+
+
 def test_shard_range():
     from chatterbox_amd.dist import shard_range
     for n in (0, 1, 7, 256, 257):

@@ -126,10 +126,12 @@ int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld
 /* the same image with the weights rounded (RNE) to bf16: [tile][K/32][lanes][8 bf16] (cbx_gemv_t.w_bf16); dst holds half the bytes */
 int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
-/* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass */
+/* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
+ * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
                         int rows, int C, long ldx, long ldh, float eps, void* stream);
-/* same with LayerNorm (rms = 0, bias b) for the GPT-2 backbone of Turbo/Nano (HF GPT2Block ln_1 / ln_2 / ln_f) */
+/* same with LayerNorm (rms = 0, bias b) for the GPT-2 backbone of Turbo/Nano (HF GPT2Block ln_1 / ln_2 / ln_f, driven by
+ * T3.inference_turbo, t3.py:392-468) */
 int cbx_add_norm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, const float* b,
                      float* h, int rows, int C, long ldx, long ldh, float eps, int rms, void* stream);
 
@@ -183,17 +185,21 @@ int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int
                            float scale, void* stream);
 
 /* ---- elementwise / glue ---- */
-/* y[r][c] = act(x[r][c]) (per-column param for snake), 2-D strided. */
+/* y[r][c] = act(x[r][c]) (per-column param for snake), 2-D strided: the activations that cannot ride a GEMM / LayerNorm epilogue
+ * (Mish of the time MLP, matcha/decoder.py:105-117; Snake at a ResBlock entry, hifigan.py:57-66). */
 int cbx_act_f32(const float* x, float* y, const float* param, long rows, int C, long ldx, long ldy, int act,
                 float slope, void* stream);
-/* generic 2-D strided copy / scale-add: y = a*x + b*y */
+/* generic 2-D strided copy / scale-add: y = a*x + b*y (skip-connection concat of the CFM up block, decoder.py:307-313; conformer
+ * macaron residuals, transformer/encoder_layer.py:168-236) */
 int cbx_axpby_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, float a, float b, void* stream);
-/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2[r]][:]]   (nn.Embedding gathers; negative ids give zeros).
+/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2[r]][:]]   (nn.Embedding gathers: speech_emb + LearnedPositionEmbeddings, t3.py:108-122,
+ * 366-372; flow.input_embedding, flow.py:150-157; negative ids give zeros).
  * flags bit 1 (value 2): out is the packed operand image of a decode GEMV (cbx_gemv_t.x_packed, K = C % 32 == 0; ld_out ignored;
  * rows of the last 16-row tile that are not written keep their previous contents). */
 int cbx_embed_f32(const long long* ids, const float* table, const float* table2, const int* ids2, float* out,
                   long rows, int C, long ld_out, float scale, int flags, void* stream);
-/* RoPE (HF apply_rotary_pos_emb, rotate_half form) on q,k rows of a fused qkv buffer + KV-cache append.
+/* RoPE (HF apply_rotary_pos_emb, rotate_half form, as called by LlamaAttention in T3's prefill, t3.py:326-333) on q,k rows of a fused
+ * qkv buffer + KV-cache append.
  * positions[r] gives the absolute position of row r; cos/sin tables are [max_pos][64] (cat(freqs,freqs)). */
 int cbx_rope_kv_f32(float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc, float* vc,
                     const int* cache_rows, long n_rows, int n_heads, long ld_qkv, long cache_row_stride,
@@ -294,6 +300,7 @@ int cbx_cplx_power_f32(const float* spec, float* out, long rows, int F, long ld_
 #define CBX_UN_AFFINE 4        /* a x + b */
 int cbx_unary_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, int op, float a, float b, const float* dev_scalar,
                   void* stream);
+/* out[0] = max over a 2-D strided block (log_spec.max() of s3tokenizer.py:164, kept on the device as CBX_UN_FLOOR_AFFINE's dev_scalar) */
 int cbx_reduce_max_f32(const float* x, float* out, long rows, int C, long ldx, void* stream);
 /* CAMLayer context (xvector.py:204-231): ctx[s][c] = mean_t x + mean over segment s (avg_pool1d ceil_mode), s = t / seg_len */
 int cbx_seg_context_f32(const float* x, float* ctx, int T, int C, int seg_len, long ldx, long ldc, void* stream);

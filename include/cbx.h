@@ -186,14 +186,14 @@ int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int
 
 /* ---- elementwise / glue ---- */
 /* y[r][c] = act(x[r][c]) (per-column param for snake), 2-D strided: the activations that cannot ride a GEMM / LayerNorm epilogue
- * (Mish of the time MLP, matcha/decoder.py:105-117; Snake at a ResBlock entry, hifigan.py:57-66). */
+ * (Mish of the ResNet time MLPs, matcha/decoder.py:49,58; Snake at a ResBlock entry, hifigan.py:34-60,146-150). */
 int cbx_act_f32(const float* x, float* y, const float* param, long rows, int C, long ldx, long ldy, int act,
                 float slope, void* stream);
-/* generic 2-D strided copy / scale-add: y = a*x + b*y (skip-connection concat of the CFM up block, decoder.py:307-313; conformer
- * macaron residuals, transformer/encoder_layer.py:168-236) */
+/* generic 2-D strided copy / scale-add: y = a*x + b*y (skip-connection concat of the CFM up block, decoder.py:294,316-317; conformer
+ * macaron residuals, transformer/encoder_layer.py:193-229) */
 int cbx_axpby_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, float a, float b, void* stream);
-/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2[r]][:]]   (nn.Embedding gathers: speech_emb + LearnedPositionEmbeddings, t3.py:108-122,
- * 366-372; flow.input_embedding, flow.py:150-157; negative ids give zeros).
+/* out[r][:] = table[ids[r]][:] * scale [+ table2[ids2[r]][:]]   (nn.Embedding gathers: speech_emb + LearnedPositionEmbeddings, t3.py:116-119,
+ * 370-371; flow.input_embedding, flow.py:106,166; negative ids give zeros).
  * flags bit 1 (value 2): out is the packed operand image of a decode GEMV (cbx_gemv_t.x_packed, K = C % 32 == 0; ld_out ignored;
  * rows of the last 16-row tile that are not written keep their previous contents). */
 int cbx_embed_f32(const long long* ids, const float* table, const float* table2, const int* ids2, float* out,
@@ -295,12 +295,12 @@ int cbx_affine_act_f32(const float* x, float* y, const float* scale, const float
  * sqrt(|.|^2 + eps) (mode 1: s3gen/utils/mel.py:77) */
 int cbx_cplx_power_f32(const float* spec, float* out, long rows, int F, long ld_spec, long ld_out, int mode, float eps, void* stream);
 #define CBX_UN_LOG_CLAMP 1     /* log(max(x, a))                 utils/mel.py:18-19 */
-#define CBX_UN_LOG10_CLAMP 2   /* log10(max(x, a))               s3tokenizer.py:163 */
-#define CBX_UN_FLOOR_AFFINE 3  /* (max(x, *dev_scalar - a) + b) / b   s3tokenizer.py:164-165 */
+#define CBX_UN_LOG10_CLAMP 2   /* log10(max(x, a))               s3tokenizer.py:165 */
+#define CBX_UN_FLOOR_AFFINE 3  /* (max(x, *dev_scalar - a) + b) / b   s3tokenizer.py:166-167 */
 #define CBX_UN_AFFINE 4        /* a x + b */
 int cbx_unary_f32(const float* x, float* y, long rows, int C, long ldx, long ldy, int op, float a, float b, const float* dev_scalar,
                   void* stream);
-/* out[0] = max over a 2-D strided block (log_spec.max() of s3tokenizer.py:164, kept on the device as CBX_UN_FLOOR_AFFINE's dev_scalar) */
+/* out[0] = max over a 2-D strided block (log_spec.max() of s3tokenizer.py:166, kept on the device as CBX_UN_FLOOR_AFFINE's dev_scalar) */
 int cbx_reduce_max_f32(const float* x, float* out, long rows, int C, long ldx, void* stream);
 /* CAMLayer context (xvector.py:204-231): ctx[s][c] = mean_t x + mean over segment s (avg_pool1d ceil_mode), s = t / seg_len */
 int cbx_seg_context_f32(const float* x, float* ctx, int T, int C, int seg_len, long ldx, long ldc, void* stream);

@@ -291,8 +291,8 @@ int cbx_lstm_cell_f32(const float* pre, const float* hh, float* c, float* h, int
 /* y = act(x * scale[c] + shift[c]): eval BatchNorm + ReLU that PRECEDES a conv in CAMPPlus (xvector.py:136-151,262-266) */
 int cbx_affine_act_f32(const float* x, float* y, const float* scale, const float* shift, long rows, int C, long ldx, long ldy,
                        int act, void* stream);
-/* spec row [re(0..F-1) | im(0..F-1)] -> |.|^2 (mode 0: s3tokenizer.py:161, voice_encoder/melspec.py:40-44) or
- * sqrt(|.|^2 + eps) (mode 1: s3gen/utils/mel.py:77) */
+/* spec row [re(0..F-1) | im(0..F-1)] -> |.|^2 (mode 0: s3tokenizer.py:161, voice_encoder/melspec.py:35-39) or
+ * sqrt(|.|^2 + eps) (mode 1: s3gen/utils/mel.py:80) */
 int cbx_cplx_power_f32(const float* spec, float* out, long rows, int F, long ld_spec, long ld_out, int mode, float eps, void* stream);
 #define CBX_UN_LOG_CLAMP 1     /* log(max(x, a))                 utils/mel.py:18-19 */
 #define CBX_UN_LOG10_CLAMP 2   /* log10(max(x, a))               s3tokenizer.py:165 */

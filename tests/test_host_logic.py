@@ -215,6 +215,42 @@ def test_turbo_norm_loudness_is_exposed_and_never_raises(capsys):
         assert out is wav and "norm_loudness" in capsys.readouterr().out
 
 
+def test_reference_citations_point_into_existing_files():
+    """Every `path.py:line[-line]` citation of the reference in the header, the docs and the package must name a file of /root/reference and
+    lines inside it (skipped where the reference tree is absent, e.g. on the GPU box)."""
+    import glob
+    import re
+    if not os.path.isdir("/root/reference/src/chatterbox"):
+        pytest.skip("reference tree not present")
+    ref = {}
+    for root, _, files in os.walk("/root/reference"):
+        for f in files:
+            if f.endswith(".py"):
+                ref.setdefault(f, []).append(os.path.join(root, f))
+    own = {os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "chatterbox_amd", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "*.py")) +
+           glob.glob(os.path.join(ROOT, "oracle", "*.py"))} | {"bench.py"}
+    pat = re.compile(r"([A-Za-z0-9_/]+\.py):(\d+)(?:-(\d+))?")
+    files = ["include/cbx.h", "DESIGN.md", "INTEGRATION.md"] + [os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, "chatterbox_amd", "*.py")) +
+                                                                 glob.glob(os.path.join(ROOT, "chatterbox_amd", "csrc", "*.hip"))]
+    bad, n = [], 0
+    for fn in files:
+        for i, line in enumerate(open(os.path.join(ROOT, fn)), 1):
+            for m in pat.finditer(line):
+                path, hi = m.group(1), int(m.group(3) or m.group(2))
+                base = os.path.basename(path)
+                if base not in ref:
+                    if base not in own:
+                        bad.append((fn, i, m.group(0), "no such reference file"))
+                    continue
+                cands = [q for q in ref[base] if q.endswith(path)] or ([] if base in own else ref[base])
+                if not cands:
+                    continue  # e.g. a citation of this repo's own t3.py / api.py
+                n += 1
+                if not any(hi <= sum(1 for _ in open(c)) for c in cands):
+                    bad.append((fn, i, m.group(0), "past the end of the file"))
+    assert n > 100 and not bad, bad[:10]
+
+
 def test_shard_range():
     from chatterbox_amd.dist import shard_range
     for n in (0, 1, 7, 256, 257):

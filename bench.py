@@ -2,7 +2,8 @@
 """bench.py -- headline metric of BASELINE.json: audio-seconds per wall-second (xRT) + p50 first-audio latency of
 generate() = T3 -> S3Gen (10-step CFM, CFG) -> HiFT, Multilingual-V3 500M architecture, batch 8 per GPU.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU over RCCL -- either the caller launched the ranks with
+                                                          torch.distributed.run, or this script re-runs itself under it)
 
 A "step" is one pass of the whole hot path over one batch of synthetic utterances: 64 text tokens,
 250 speech tokens (10 s of audio, EOS banned so the length is fixed), 150-token T3 voice prompt, 250-token / 500-frame
@@ -64,7 +65,68 @@ def parse():
                     help="after the timed region also run configs[3]: 256 utterances strong-sharded over the ranks (32 per GPU at 8 GPUs); "
                          "default on when WORLD_SIZE == 8")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-CPU parity block (needs the CPU baseline utterance)")
+    ap.add_argument("--selftest-rendezvous", action="store_true",
+                    help="launcher / collective self-test WITHOUT kernels (gloo, host tensors): the N ranks rendezvous, C1 (broadcast of the "
+                         "Conditionals) and C2 (gather of waveforms) fire on synthetic payloads of the benched shapes, rank 0 prints the JSON "
+                         "line with value = null.  Used by tests/test_bench_launcher.py on the CPU; it measures nothing")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: re-run this very command line under
+    `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  When the
+    driver (or a user) already launched the ranks, WORLD_SIZE is set and this is a no-op."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_rendezvous(args, rank, world):
+    """No kernels, no GPU: exercises exactly the multi-rank plumbing of main() -- init, C1, per-rank work list, barrier-bracketed
+    timed region with max-over-ranks, C2 inside it, one JSON line from rank 0 -- on host tensors over gloo."""
+    import torch.distributed as dist
+    from chatterbox_amd import dist as cdist, synth
+    t3c, gen = (synth.t3_cond(), synth.s3gen_ref()) if rank == 0 else (None, None)
+    t3c, gen = cdist.broadcast_conditionals(t3c, gen, src=0)                                     # C1
+    c1_ok = bool(torch.equal(t3c["cond_prompt_speech_tokens"], synth.t3_cond()["cond_prompt_speech_tokens"]))
+    B, N = args.batch, args.tokens
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    got = 0
+    for _ in range(args.steps):
+        wavs = [torch.full(((N - 1) * 960,), float(rank * B + b)) for b in range(B)]
+        allw = cdist.gather_waveforms(wavs, dst=0)                                                # C2
+        if rank == 0:
+            assert len(allw) == B * world and all(float(w[0]) == i for i, w in enumerate(allw)), "C2: wrong order / count"
+            got += len(allw)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "audio-sec/wall-sec (xRT) + p50 first-audio latency, Multilingual-V3 500M", "value": None,
+                          "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(el[0]) / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none",
+                          "selftest": {"what": "rendezvous + C1 + C2 only (gloo, host tensors): NO kernels ran, nothing is measured",
+                                       "c1_ok": c1_ok, "c2_waveforms_gathered": got, "ranks": world},
+                          "config": {"workload": "selftest", "global_batch": B * world, "parallelism": f"dp{world}"}}), flush=True)
 
 
 def cpu_baseline(t3_sd, s3_sd, args, n_layers):
@@ -311,13 +373,28 @@ def log(msg):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run `python bench.py "
+                 f"--gpus {args.gpus}` without a torch.distributed environment and it spawns the ranks itself)")
     import torch.distributed as dist
+    if args.selftest_rendezvous:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        selftest_rendezvous(args, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

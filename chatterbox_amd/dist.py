@@ -4,7 +4,7 @@
 The reference has no distributed path; utterances are independent, so the path shards with NO
 collective inside it.  Only two exchanges exist, both outside the kernels' critical path:
   C1  broadcast of the packed voice `Conditionals` (~170 KB) from the rank that analysed the prompt,
-  C2  gather of the finished waveforms (padded to the longest + int32 lengths) to rank 0.
+  C2  gather of the finished waveforms (padded to the longest + int32 lengths) to rank 0 (`dist.gather`: only rank 0 receives).
 Over 7 xGMI links x ~153 GB/s a 31 MB/GPU gather costs < 1 ms, so scaling is decided by load balance: shards are
 contiguous blocks of the utterance list (length-sorted lists balance best).
 """
@@ -60,7 +60,9 @@ def broadcast_conditionals(t3_cond, gen_ref, src=0, device=None):
 
 def gather_waveforms(wavs, dst=0):
     """C2: `wavs` is this rank's list of 1-D float tensors.  Returns, on rank `dst`, the list over all ranks in rank
-    order (CPU tensors); None elsewhere.  One all_gather of a padded (n_local_max, L_max) block + lengths."""
+    order (CPU tensors); None elsewhere.  A real gather-to-`dst`: every rank all-gathers two int64 (its utterance count and
+    longest waveform) so that all agree on the padded block shape, then ONE `dist.gather` of the padded (n_max, L_max) fp32 block
+    and one of the int32 lengths -- only `dst` receives the 31 MB / rank, the other ranks send and are done."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [w.detach().cpu() for w in wavs]
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -77,10 +79,10 @@ def gather_waveforms(wavs, dst=0):
     for i, w in enumerate(wavs):
         block[i, : w.numel()] = w.to(dev)
         lens[i] = w.numel()
-    blocks = [torch.empty_like(block) for _ in range(world)]
-    all_lens = [torch.empty_like(lens) for _ in range(world)]
-    dist.all_gather(blocks, block)
-    dist.all_gather(all_lens, lens)
+    blocks = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+    all_lens = [torch.empty_like(lens) for _ in range(world)] if rank == dst else None
+    dist.gather(block, blocks, dst=dst)
+    dist.gather(lens, all_lens, dst=dst)
     if rank != dst:
         return None
     out = []

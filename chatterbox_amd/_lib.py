@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 6  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 7  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -34,6 +34,17 @@ class GemmParams(ctypes.Structure):
         ("ldr", c_long), ("r_s1", c_long), ("r_s2", c_long),
         ("ldc2", c_long), ("c2_s1", c_long), ("c2_s2", c_long),
         ("precision", c_int), ("reserved0", c_int), ("ln_stats", c_f), ("ln_w", c_f), ("ln_b", c_f),
+    ]
+
+
+class GemmPlParams(ctypes.Structure):
+    _fields_ = [
+        ("A", c_f), ("W", c_f), ("C", c_f), ("P", c_f), ("bias", c_f), ("R", c_f), ("act_param", c_f), ("lens", c_f),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("Cin", c_int), ("taps", c_int), ("dil", c_int), ("stride", c_int), ("pad_left", c_int), ("Tin", c_int), ("nz1", c_int),
+        ("act", c_int), ("act_slope", c_float), ("alpha", c_float),
+        ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long),
+        ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long),
     ]
 
 
@@ -86,6 +97,12 @@ _SIGS = {
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
     "cbx_set_split_tile": ([c_int], c_int),
     "cbx_set_range_flag": ([c_f], c_int),
+    "cbx_gemm_ln_fusable": ([c_long, c_int, c_long], c_int),
+    "cbx_gemm_planes": ([ctypes.POINTER(GemmPlParams), c_f], c_int),
+    "cbx_set_planes_tile": ([c_int], c_int),
+    "cbx_split_planes_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_f], c_int),
+    "cbx_layernorm_planes_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_float, c_int, c_float, c_f], c_int),
+    "cbx_flash_attn_split_po": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 9 + [c_float, c_int, c_f], c_int),
     "cbx_row_stats_f32": ([c_f, c_f, c_long, c_int, c_long, c_float, c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),

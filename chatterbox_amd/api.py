@@ -123,7 +123,7 @@ def _norm_loudness(wav, sr, target_lufs=-27.0):
     return wav
 
 
-def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_seconds=None, norm_loudness=False):
+def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_seconds=None, norm_loudness=False, enc_cond_len=None):
     """The common body of prepare_conditionals (tts.py:182-206, mtl_tts.py:253-277, tts_turbo.py:241-270).  `wav`: a file path or a
     (waveform, sample_rate) pair."""
     from . import frontend as fe
@@ -140,7 +140,7 @@ def _prepare_conditionals(analyzer, wav, exaggeration, prompt_len, device, min_s
         w24 = _norm_loudness(w24, S3GEN_SR)
     w16 = fe.resample(w24, S3GEN_SR, S3_SR)
     gen = analyzer.embed_ref(w24[: analyzer.DEC_COND_LEN], S3GEN_SR)
-    spk, ptoks = analyzer.t3_prompt(w16, prompt_len)
+    spk, ptoks = analyzer.t3_prompt(w16, prompt_len, enc_cond_len=enc_cond_len)
     t3 = T3Cond(speaker_emb=spk, cond_prompt_speech_tokens=ptoks, emotion_adv=exaggeration * torch.ones(1, 1, 1)).to(device=device)
     return Conditionals(t3, {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in gen.items()})
 
@@ -278,6 +278,7 @@ class ChatterboxMultilingualTTS(_Base):
 class ChatterboxTurboTTS:
     """Reference tts_turbo.py:111-320: GPT2-medium (Turbo) or GPT2-small (Nano) T3, meanflow S3Gen, GPT-2 BPE tokenizer."""
     sr = S3GEN_SR
+    ENC_COND_LEN, DEC_COND_LEN = 15 * S3_SR, 10 * S3GEN_SR  # tts_turbo.py:112-113: the T3 prompt covers up to 15 s (375 tokens)
 
     def __init__(self, engine, tokenizer, device, conds=None, model_label="Turbo", analyzer=None):
         self.engine, self.tokenizer, self.device, self.conds, self.model_label = engine, tokenizer, device, conds, model_label
@@ -323,7 +324,7 @@ class ChatterboxTurboTTS:
     def prepare_conditionals(self, wav_fpath, exaggeration=0.0, norm_loudness=True):
         """reference tts_turbo.py:241-270 (prompt > 5 s, optional loudness normalisation to -27 LUFS, 375 prompt tokens)."""
         self.conds = _prepare_conditionals(self.analyzer, wav_fpath, exaggeration, 375, self.device, min_seconds=5.0,
-                                           norm_loudness=norm_loudness)
+                                           norm_loudness=norm_loudness, enc_cond_len=self.ENC_COND_LEN)
 
     def _generate(self, text_tokens, **samp):
         wavs, _ = self.engine.synthesize([text_tokens.view(-1).long().cpu()], self.conds.t3.as_dict(), self.conds.gen, **samp)

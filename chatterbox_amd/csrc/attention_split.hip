@@ -30,6 +30,8 @@ struct FlashSplitArgs {
     long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
     float scale;
     int causal;
+    int o_planes;  // o is a PLANE-format tensor (two fp16 planes, gemm_planes.hip): o_sb / o_st in halves, l plane o_lo halves after h
+    long o_lo;
 };
 
 template <int NP, bool F16>
@@ -302,7 +304,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
     // ---- finalise: both half-waves hold partial sums of the same query
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qi < a.Tq) {
+    if (qi < a.Tq && a.o_planes) {  // attention output feeds the to_out projection only: written as the two fp16 planes that GEMM consumes
+        _Float16* op = reinterpret_cast<_Float16*>(a.o) + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t = {ot[d][g * 4 + 0] * inv, ot[d][g * 4 + 1] * inv, ot[d][g * 4 + 2] * inv, ot[d][g * 4 + 3] * inv};
+                const f16x4 h = __builtin_convertvector(t, f16x4);
+                const f32x4 t2 = t * CBX_F16_LO_SCALE;
+                f32x4 dl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dl[e] = __builtin_fmaf((float)h[e], -CBX_F16_LO_SCALE, t2[e]);
+                *reinterpret_cast<f16x4*>(op + d * 32 + 8 * g + 4 * lh) = h;
+                *reinterpret_cast<f16x4*>(op + a.o_lo + d * 32 + 8 * g + 4 * lh) = __builtin_convertvector(dl, f16x4);
+            }
+    } else if (qi < a.Tq) {
         float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -316,18 +333,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
 
 }  // namespace
 
-extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
-                                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
-                                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,
-                                        void* stream) {
+static int flash_split_launch(const float* q, const float* k, const float* v, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
+                              int Tk, long q_sb, long q_st, long k_sb, long k_st, long v_sb, long v_st, long o_sb, long o_st, float scale,
+                              int causal, int precision, int o_planes, long o_lo, void* stream) {
     CBX_REQUIRE(q && k && v && o, "flash_attn_split: null operand");
     CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn_split: bad shape");
     CBX_REQUIRE(precision == 3 || precision == 6 || precision == 16, "flash_attn_split: precision must be 3, 6 or 16 (got %d)", precision);
-    CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb) % 4 == 0, "flash_attn_split: strides must be multiples of 4");
-    CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn_split: 16-byte alignment");
+    CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb | o_lo) % 4 == 0, "flash_attn_split: strides must be multiples of 4");
+    CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)o & (o_planes ? 7 : 15)) == 0, "flash_attn_split: alignment");
     CBX_REQUIRE((long)(Tk + 64) * k_st * 4 < 0x7fffffffL && (long)(Tk + 64) * v_st * 4 < 0x7fffffffL && k_st > 0 && v_st > 0,
                 "flash_attn_split: one (batch, head) slice of K / V must span less than 2 GiB");
-    FlashSplitArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
+    CBX_REQUIRE(!o_planes || precision == 16, "flash_attn_split: plane-format output is an f16x3 (precision 16) feature");
+    FlashSplitArgs a{q, k, v, reinterpret_cast<float*>(o), key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal, o_planes, o_lo};
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     int* flag = cbx_range_flag();
     if (precision == 16) {
@@ -338,4 +355,19 @@ extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const fl
         hipLaunchKernelGGL((flash_attn_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a, flag);
     }
     return cbx_check_launch("flash_attn_split");
+}
+
+extern "C" int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
+                                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,
+                                        void* stream) {
+    return flash_split_launch(q, k, v, o, key_lens, nz1, n_heads, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal,
+                              precision, 0, 0, stream);
+}
+
+extern "C" int cbx_flash_attn_split_po(const float* q, const float* k, const float* v, void* o_planes, const int* key_lens,
+                                       int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                                       long v_sb, long v_st, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream) {
+    return flash_split_launch(q, k, v, o_planes, key_lens, nz1, n_heads, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale,
+                              causal, 16, 1, o_lo, stream);
 }

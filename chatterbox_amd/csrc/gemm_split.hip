@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_split_kernel(cons
     }
 }
 
-int* g_range_flag = nullptr;
+int* g_range_flags[64] = {nullptr};  // one word per device ordinal (cbx_set_range_flag)
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16 = false, int LD = 0, bool LN = false>
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
@@ -398,7 +398,7 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
         configured = true;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
-    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, g_range_flag);
+    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());
     return cbx_check_launch("gemm_split");
 }
 
@@ -411,12 +411,32 @@ extern "C" int cbx_set_split_tile(int t) {
     return 0;
 }
 
-// Device word that the fp16 forms (precision 16, here and in attention_split.hip) OR a 1 into when an operand exceeds the fp16 range.
-// NULL (default) = not reported.  Process-global like the current device; the word has to outlive the launches.
-int* cbx_range_flag() { return g_range_flag; }
+// Device word that the fp16 forms (precision 16: here, gemm_planes.hip, attention_split.hip, norm.hip) OR a 1 into when an operand exceeds
+// the fp16 range.  NULL (default) = not reported.  ONE WORD PER DEVICE: cbx_set_range_flag registers the word for the calling thread's
+// current device, a launch reports into the word of the device it is launched on (an engine per GPU may share one process).
+int* cbx_range_flag() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    return g_range_flags[d];
+}
 extern "C" int cbx_set_range_flag(int* dev_flag) {
-    g_range_flag = dev_flag;
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess || d < 0 || d >= 64) return cbx_set_error(CBX_EINVAL, "set_range_flag: no current device");
+    g_range_flags[d] = dev_flag;
     return 0;
+}
+
+// Would a Linear (M, N?, K) with row stride lda fold a LayerNorm into its A operand (cbx_gemm_t.ln_stats)?  Mirrors the conditions of the
+// dispatcher below that do not depend on the caller's other operands: no forced tile, the buffer-load loader usable (31-bit offsets,
+// no CBX_SPLIT_GENERIC_LOADER), K % 32 == 0.  The caller additionally needs precision 16, taps == 1, one batch, no lens.
+static int split_generic_loader_forced() {
+    static const int no_fast = getenv("CBX_SPLIT_GENERIC_LOADER") ? atoi(getenv("CBX_SPLIT_GENERIC_LOADER")) : 0;
+    return no_fast;
+}
+extern "C" int cbx_gemm_ln_fusable(long M, int K, long lda) {
+    if (g_split_tile || split_generic_loader_forced()) return 0;
+    return M > 32 && K > 0 && K % SBK == 0 && (M + 1) * lda * 4 < 0x7fffffffL;
 }
 
 // Called by cbx_gemm_f32 after argument validation.  planes = 2 (bf16x3), 3 (bf16x6) or 16 (f16x3).  Returns -1 when the shape is not
@@ -430,7 +450,7 @@ int cbx_gemm_split_dispatch(const cbx_gemm_t& p, int planes, hipStream_t st) {
     // 5-45 % and 64x64 by 0-15 %
     int tile = force ? force : (g128 >= 64 && p.N >= 64 ? 12864 : 64);
     // loader: 1 / 2 = raw buffer loads (Linear / Conv1d), needs K tiles that never straddle the end of K and 31-bit byte offsets
-    static const int no_fast = getenv("CBX_SPLIT_GENERIC_LOADER") ? atoi(getenv("CBX_SPLIT_GENERIC_LOADER")) : 0;
+    const int no_fast = split_generic_loader_forced();
     const bool fast = !no_fast && p.up == 1 && p.K % SBK == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
                       (long)(p.N + 128) * p.ldw * 4 < 0x7fffffffL && (long)p.pad_left * p.lda * 4 < 0x3fffffffL;
     const int ld = !fast ? 0 : p.taps == 1 ? 1 : 2;

@@ -74,11 +74,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // batch): 16 lanes per row, 4 rows per wave, NV float4 per lane all in flight at once (a wave streams 4 KiB instead of 1 KiB
 // per round trip), statistics by 4 xor-shuffles inside the 16-lane group.
 // STATS: write {mean, rstd} per row to y (2 floats per row) instead of the normalised row (cbx_row_stats_f32): same loads, same reductions.
-template <int NV, int RPT, bool STATS = false>
+// PL: the normalised row is written in PLANE format (two fp16 planes h, l = 2048 (y - h), see gemm_planes.hip) for a consuming
+// cbx_gemm_planes: y is the fp16 base, ldy the row stride in halves, p_lo the offset of the l plane; same bytes as the fp32 row.
+template <int NV, int RPT, bool STATS = false, bool PL = false>
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ w, const float* __restrict__ b,
                                                                const float* __restrict__ post_add, long rows, long ldx, long ldy,
-                                                               float eps, int rms, int act, float out_scale) {
+                                                               float eps, int rms, int act, float out_scale, long p_lo = 0,
+                                                               int* range_flag = nullptr) {
     constexpr int C = 64 * NV;
     // RPT = rows per 16-lane group: RPT x NV float4 loads in flight per lane (RPT x 4 KiB per wave per round trip)
     const int l16 = threadIdx.x & 15;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
             continue;
         }
         float* yr = y + row * ldy;
+        [[maybe_unused]] float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 16 + l16) * 4;
@@ -152,7 +156,23 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
                 t = cbx_act(t, act, 0.f, 0.f);
                 o[e] = t * out_scale + pv[i][e];
             }
-            *reinterpret_cast<f32x4*>(yr + c) = o;
+            if constexpr (PL) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                _Float16* pr = reinterpret_cast<_Float16*>(y) + row * ldy + c;
+                const f16x4 h = __builtin_convertvector(o, f16x4);
+                const f32x4 t2 = o * CBX_F16_LO_SCALE;
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf((float)h[e], -CBX_F16_LO_SCALE, t2[e]);
+                *reinterpret_cast<f16x4*>(pr) = h;
+                *reinterpret_cast<f16x4*>(pr + p_lo) = __builtin_convertvector(d, f16x4);
+                cbx_amax4(amax, o);
+            } else {
+                *reinterpret_cast<f32x4*>(yr + c) = o;
+            }
+        }
+        if constexpr (PL) {
+            if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
         }
     }
 }
@@ -178,6 +198,16 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b,
                        post_add, rows, C, ldx, ldy, eps, rms, act, out_scale);
     return cbx_check_launch("layernorm");
+}
+
+extern "C" int cbx_layernorm_planes_f32(const float* x, void* planes, const float* w, const float* b, const float* post_add, long rows,
+                                        int C, long ldx, long ldp, long p_lo, float eps, int act, float out_scale, void* stream) {
+    CBX_REQUIRE(x && planes && w, "layernorm_planes: null operand");
+    CBX_REQUIRE(C == 256 && ldx % 4 == 0 && ldp % 4 == 0 && p_lo % 4 == 0, "layernorm_planes: C must be 256 (got %d); strides multiples of 4", C);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1, false, true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<float*>(planes), w, b, post_add, rows, ldx, ldp, eps, 0, act, out_scale, p_lo, cbx_range_flag());
+    return cbx_check_launch("layernorm_planes");
 }
 
 extern "C" int cbx_row_stats_f32(const float* x, float* stats, long rows, int C, long ldx, float eps, void* stream) {

@@ -65,7 +65,8 @@ class ChatterboxEngine:
         from . import formats
         fp = formats.fingerprint(t3_sd) + f"-L{n_layers}"
         path = os.path.join(cache, f"t3_{fp}.cbxpack")
-        kind = "t3-llama-" + os.environ.get("CBX_T3_DECODE", "v2") + "-" + (self.t3_weights or os.environ.get("CBX_T3_WEIGHTS", "fp32"))
+        kind = formats.packed_kind("t3-llama-" + os.environ.get("CBX_T3_DECODE", "v2") + "-" + (self.t3_weights or os.environ.get("CBX_T3_WEIGHTS", "fp32"))
+                                   + f"-ht{int(bool(T3Engine._TUNE.get('half_tiles')))}")  # the half-tile images are part of the packed set
         t = formats.load_packed(path, fp, kind)
         if t is not None:
             return T3Engine.from_packed(t, self.dev)

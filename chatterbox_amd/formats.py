@@ -66,7 +66,8 @@ def write_safetensors(tensors, path, metadata=None):
         f.write(struct.pack("<Q", len(hj)))
         f.write(hj)
         for t in blobs:
-            if t.numel():
+            if t.numel():  # reshape(-1) first: a 0-d tensor (num_batches_tracked, a scalar emotion_adv) cannot be viewed as bytes
+                t = t.reshape(-1)
                 f.write(t.view(torch.uint8).numpy().tobytes() if t.dtype != torch.bool else t.to(torch.uint8).numpy().tobytes())
     os.replace(tmp, path)
 
@@ -110,15 +111,28 @@ def fingerprint(sd):
         h.update(str(tuple(v.shape)).encode())
         h.update(str(v.dtype).encode())
         flat = v.detach().reshape(-1)
-        if flat.numel():
-            step = max(1, flat.numel() // 64)
-            h.update(flat[::step][:64].to(torch.float64).cpu().numpy().tobytes())
+        n = flat.numel()
+        if n:  # the first and last 4 KiB in full + 1024 strided samples: an edit that misses all of them has to be adversarial
+            step = max(1, n // 1024)
+            for piece in (flat[:1024], flat[max(0, n - 1024):], flat[::step][:1024]):
+                h.update(piece.to(torch.float64).cpu().numpy().tobytes())
     return h.hexdigest()[:32]
+
+
+PACKED_LAYOUT_VERSION = 2  # bump whenever an engine changes what export_packed() holds or how an image is laid out
+
+
+def packed_kind(base):
+    """`kind` of a packed image: the engine flavour + everything the packed layout depends on besides the checkpoint -- the C ABI version
+    (lane orders are part of it) and this module's layout version -- so that a library / layout change never maps a stale image."""
+    from ._lib import ABI_VERSION
+    return f"{base}-abi{ABI_VERSION}-pl{PACKED_LAYOUT_VERSION}"
 
 
 def save_packed(tensors, path, source_fingerprint, kind):
     """tensors: flat {name: device tensor} as exported by an engine (`export_packed()`)."""
-    write_safetensors(tensors, path, metadata={"format": "chatterbox-packed", "version": 1, "kind": kind, "source": source_fingerprint})
+    write_safetensors(tensors, path, metadata={"format": "chatterbox-packed", "version": PACKED_LAYOUT_VERSION, "kind": kind,
+                                               "source": source_fingerprint})
 
 
 def load_packed(path, source_fingerprint, kind):
@@ -126,6 +140,7 @@ def load_packed(path, source_fingerprint, kind):
     if not os.path.exists(path):
         return None
     t, meta = read_safetensors(path, with_metadata=True)
-    if meta.get("format") != "chatterbox-packed" or meta.get("kind") != kind or meta.get("source") != source_fingerprint:
+    if (meta.get("format") != "chatterbox-packed" or meta.get("kind") != kind or meta.get("source") != source_fingerprint
+            or str(meta.get("version")) != str(PACKED_LAYOUT_VERSION)):
         return None
     return t

@@ -442,7 +442,8 @@ class VoiceEncoderEngine:
 
     def _l2norm(self, x, out):
         C = x.shape[1]
-        return ops.layernorm(x, torch.ones(C, device=self.dev), None, out, 0.0, rms=True, scale=1.0 / math.sqrt(C))
+        # F.normalize: x / max(||x||, 1e-12).  eps = 1e-24 / C under the root: identical for any representable non-zero row, 0 (not NaN) for a zero row
+        return ops.layernorm(x, torch.ones(C, device=self.dev), None, out, 1e-24 / C, rms=True, scale=1.0 / math.sqrt(C))
 
     @ops.on_device
     @torch.inference_mode()
@@ -566,11 +567,13 @@ class PromptAnalyzer:
             tlen = torch.tensor([tok.shape[1]])
         return dict(prompt_token=tok, prompt_token_len=tlen, prompt_feat=feat, prompt_feat_len=None, embedding=xvec)
 
-    def t3_prompt(self, ref_16k_wav, plen):
-        """(speaker_emb (1, 256), cond_prompt_speech_tokens (1, <= plen)) of T3Cond."""
+    def t3_prompt(self, ref_16k_wav, plen, enc_cond_len=None):
+        """(speaker_emb (1, 256), cond_prompt_speech_tokens (1, <= plen)) of T3Cond.  enc_cond_len: samples of the 16 kHz prompt that
+        are tokenised -- 6 s for English / Multilingual (tts.py:107,194), 15 s for Turbo / Nano (tts_turbo.py:112,258: 375 tokens)."""
         assert self.ve is not None, "no voice-encoder weights (ve.safetensors) loaded"
         tokens = None
         if plen:
-            tokens, _ = self.tokenizer(torch.from_numpy(np.asarray(ref_16k_wav[: self.ENC_COND_LEN], dtype=np.float32)), max_len=plen)
+            cut = self.ENC_COND_LEN if enc_cond_len is None else int(enc_cond_len)
+            tokens, _ = self.tokenizer(torch.from_numpy(np.asarray(ref_16k_wav[:cut], dtype=np.float32)), max_len=plen)
         ve = self.ve.embeds_from_wavs([ref_16k_wav], sample_rate=S3_SR).mean(0, keepdim=True)
         return ve, tokens

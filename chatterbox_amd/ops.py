@@ -102,26 +102,34 @@ class gemm_precision:
 
 
 LN_FUSION = os.environ.get("CBX_LN_FUSION", "1") != "0"  # CFM transformer blocks: LayerNorm folded into the consuming Linear
-_RANGE_FLAG = None
+_RANGE_FLAGS = {}  # device index -> int32 device word (one per GPU: an engine per GPU may live in one process, see on_device())
 
 
-def enable_range_flag(device):
-    """Allocate (once) the device word the f16x3 kernels (precision 16) raise when an operand exceeds the fp16 range, and register it
-    with the library (cbx_set_range_flag).  One process drives one GPU, so one word per process."""
-    global _RANGE_FLAG
-    if _RANGE_FLAG is None or _RANGE_FLAG.device != torch.device(device):
-        _RANGE_FLAG = torch.zeros(1, dtype=torch.int32, device=device)
-        check(lib.cbx_set_range_flag(_p(_RANGE_FLAG)), "cbx_set_range_flag")
-    return _RANGE_FLAG
+def _dev_index(device=None):
+    d = torch.device("cuda" if device is None else device)
+    return torch.cuda.current_device() if d.index is None else d.index
 
 
-def range_flag_tripped():
-    """True when a precision-16 launch since the last call saw an operand outside the fp16 range (synchronises; clears the flag)."""
-    if _RANGE_FLAG is None:
+def enable_range_flag(device=None):
+    """Allocate (once per GPU) the device word the f16x3 kernels (precision 16) raise when an operand exceeds the fp16 range.  The library
+    keeps one pointer per device ordinal (cbx_set_range_flag registers it for the CURRENT device; a launch looks its own device's word up),
+    so engines on different GPUs of one process never OR into a foreign-device pointer."""
+    idx = _dev_index(device)
+    if idx not in _RANGE_FLAGS:
+        with torch.cuda.device(idx):
+            _RANGE_FLAGS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+            check(lib.cbx_set_range_flag(_p(_RANGE_FLAGS[idx])), "cbx_set_range_flag")
+    return _RANGE_FLAGS[idx]
+
+
+def range_flag_tripped(device=None):
+    """True when a precision-16 launch on this GPU since the last call saw an operand outside the fp16 range (synchronises; clears the flag)."""
+    flag = _RANGE_FLAGS.get(_dev_index(device))
+    if flag is None:
         return False
-    hit = bool(_RANGE_FLAG.item())
+    hit = bool(flag.item())
     if hit:
-        _RANGE_FLAG.zero_()
+        flag.zero_()
     return hit
 
 
@@ -157,10 +165,14 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     return C
 
 
-def ln_fusable(M, K):
+def ln_fusable(M, K, lda=None):
     """Can `linear(..., ln=...)` fold a LayerNorm over K into its A operand here?  (the f16x3 split kernel on its Linear loader, C = 256
-    statistics kernel: the CFM transformer blocks)"""
-    return GEMM_PRECISION == 16 and K == 256 and M > 32 and LN_FUSION
+    statistics kernel: the CFM transformer blocks).  The library is asked (cbx_gemm_ln_fusable mirrors the dispatcher's own conditions:
+    no forced tile / generic-loader knob, 31-bit byte offsets), so a tuning knob or a > 2 GiB activation falls back to layernorm + linear
+    instead of raising."""
+    if not (GEMM_PRECISION == 16 and K == 256 and M > 32 and LN_FUSION):
+        return False
+    return bool(lib.cbx_gemm_ln_fusable(int(M), int(K), int(K if lda is None else lda)))
 
 
 def row_stats(x, stats, eps=1e-5):

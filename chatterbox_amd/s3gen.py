@@ -340,7 +340,8 @@ class FlowEngine:
         T = mu.shape[1]
         xv = ref["embedding"].to(dev).float().view(1, -1).contiguous()
         emb = torch.empty_like(xv)  # F.normalize(embedding, dim=1) (flow.py:150): x / ||x|| = rmsnorm(x) / sqrt(C)
-        ops.layernorm(xv, torch.ones(xv.shape[1], device=dev), None, emb, 0.0, rms=True, scale=1.0 / math.sqrt(xv.shape[1]))
+        # eps = 1e-24 / C under the root = F.normalize's max(||x||, 1e-12): a zero embedding gives 0, not NaN
+        ops.layernorm(xv, torch.ones(xv.shape[1], device=dev), None, emb, 1e-24 / xv.shape[1], rms=True, scale=1.0 / math.sqrt(xv.shape[1]))
         spk = torch.empty(1, 80, device=dev)
         ops.linear(emb, self.spk_w, spk, bias=self.spk_b)
         # mel_len1 = prompt_feat.shape[1] (flow.py:170-175): normally 2P; one frame more when the prompt is not a whole number of

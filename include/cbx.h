@@ -15,8 +15,10 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 6  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
-                              5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32) */
+#define CBX_ABI_VERSION 7  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+                              5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
+                              7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
+                                 per-device range flag, cbx_gemm_ln_fusable */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -73,13 +75,59 @@ typedef struct cbx_gemm_t {
     const float* ln_b;        /* [K] */
 } cbx_gemm_t;
 int cbx_gemm_f32(const cbx_gemm_t* p, void* stream);
-/* Device word that every precision-16 launch (GEMM and flash attention) ORs a 1 into when it meets an operand outside the fp16 range
- * (its result is then not meaningful and the caller repeats the computation at precision 6, which has the fp32 exponent range).
- * NULL (the default) = not reported.  Process-global; the word must stay allocated while such launches are in flight. */
+/* Device word that every precision-16 launch (GEMM, flash attention, plane-format producers) ORs a 1 into when it meets an operand outside
+ * the fp16 range (its result is then not meaningful and the caller repeats the computation at precision 6, which has the fp32 exponent
+ * range).  NULL (the default) = not reported.  One word PER DEVICE: the call registers the word for the calling thread's current device and
+ * a launch reports into the word of the device it runs on; the word must stay allocated while such launches are in flight. */
 int cbx_set_range_flag(int* dev_flag);
 /* stats[r] = {mean, rstd = 1/sqrt(var + eps)} of row r of x (C = 256: the CFM transformer blocks), computed exactly as cbx_layernorm_f32
  * computes them; feeds cbx_gemm_t.ln_stats.  Replaces the statistics half of F.layer_norm (matcha/transformer.py:243-316 norm1 / norm3). */
 int cbx_row_stats_f32(const float* x, float* stats, long rows, int C, long ldx, float eps, void* stream);
+
+/* Would cbx_gemm_f32 accept ln_stats for a precision-16 Linear with M rows, K columns and row stride lda (floats)?  0 when a tuning knob
+ * (cbx_set_split_tile, CBX_SPLIT_GENERIC_LOADER) or a > 2 GiB operand rules the folded form out: the caller then runs
+ * cbx_layernorm_f32 + a plain Linear (F.layer_norm + F.linear, matcha/transformer.py:243-316). */
+int cbx_gemm_ln_fusable(long M, int K, long lda);
+
+/* ---- PLANE-FORMAT operands (ABI v7): the f16x3 arithmetic without per-tile conversion ----
+ * A "planes" tensor stores an fp32 tensor X as two fp16 planes X = h + l / 2048, h = RNE16(X), l = RNE16(2048 (X - h)): element (row, c)
+ * of plane h at base[row*ld + c], of plane l at base[row*ld + lo + c] (halves) -- the same 4 bytes per element as fp32, 22 significand
+ * bits (the f16x3 mode of cbx_gemm_t.precision; |X| <= 65504, producers raise the cbx_set_range_flag word otherwise).
+ * Constant weights are split once at load, activations are WRITTEN in plane format by their producer (the epilogues below), and the
+ * consumer's K loop is a plain fp16 MFMA loop fed by direct global -> LDS loads.
+ *
+ * cbx_gemm_planes: C[z][m][n] and / or P[z][m][n] = alpha * ( act( sum_{tap,c} A[z][m*stride + tap*dil - pad_left][c] * W[n][tap*Cin + c]
+ *                                                                  + bias[n] ) + R[z][m][n] )
+ * A, W planes (W in [N][K] layout); C fp32 and / or P planes (either may be NULL); R fp32 residual.  Rows outside [0, min(Tin, lens[z]))
+ * read as zero.  K % 32 == 0, Cin % 32 == 0.  Replaces the F.linear / F.conv1d calls of the CFM estimator: CausalConv1d / ResnetBlock1D
+ * (models/s3gen/decoder.py:49-98, matcha/decoder.py:56-61), BasicTransformerBlock projections and FeedForward (matcha/transformer.py:243-316),
+ * final_proj (decoder.py:331-333). */
+typedef struct cbx_gemm_pl_t {
+    const void* A; const void* W;   /* fp16 planes */
+    float* C;                       /* fp32 output or NULL */
+    void* P;                        /* planes output or NULL */
+    const float* bias;              /* [N] or NULL */
+    const float* R;                 /* fp32 residual or NULL */
+    const float* act_param;         /* per-column activation parameter or NULL */
+    const int* lens;                /* per-z number of valid INPUT rows or NULL */
+    int M, N, K;                    /* output rows per batch, columns, K = taps * Cin */
+    int Cin, taps, dil, stride, pad_left, Tin, nz1;
+    int act; float act_slope, alpha;
+    long lda, a_lo, a_s1;           /* halves */
+    long ldw, w_lo;                 /* halves */
+    long ldc, c_s1;                 /* floats */
+    long ldr, r_s1;                 /* floats */
+    long ldp, p_lo, p_s1;           /* halves */
+} cbx_gemm_pl_t;
+int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
+/* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */
+int cbx_set_planes_tile(int t);
+/* x (rows, C) fp32 -> planes (weights at load; estimator inputs).  C, ldx, ldp, p_lo multiples of 4. */
+int cbx_split_planes_f32(const float* x, void* planes, long rows, int C, long ldx, long ldp, long p_lo, void* stream);
+/* cbx_layernorm_f32 (C = 256, LayerNorm form) whose result is written in plane format: nn.LayerNorm (+ Mish + time bias) feeding a conv /
+ * Linear (decoder.py:49-63, matcha/transformer.py:243-316 norm1 / norm3). */
+int cbx_layernorm_planes_f32(const float* x, void* planes, const float* w, const float* b, const float* post_add, long rows, int C,
+                             long ldx, long ldp, long p_lo, float eps, int act, float out_scale, void* stream);
 
 /* ---- skinny-M weight-streaming GEMM for decode (M = 2*B rows <= 64), HBM-roofline kernel ----
  * out[ks][m][n] = sum_{k in slice ks} x[m][k] * W[n][k]  (+ bias on slice 0);  ksplit > 1 leaves partial sums that
@@ -158,6 +206,12 @@ int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, flo
                              int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                              long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, int precision,
                              void* stream);
+
+/* cbx_flash_attn_split_f32 at precision 16 whose output is written in plane format (o_sb / o_st / o_lo in halves): the attention result
+ * feeds only the to_out projection (matcha/transformer.py:275-283 via diffusers Attention), a cbx_gemm_planes. */
+int cbx_flash_attn_split_po(const float* q, const float* k, const float* v, void* o_planes, const int* key_lens,
+                            int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
+                            long v_sb, long v_st, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
 
 /* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).
  * cache layout [row][head][pos][64]; ctx_lens[row] = number of valid positions (including the new token). */

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -34,7 +34,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     from chatterbox_amd import _lib
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
-    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
+    structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
                "cbx_sampler_t": _lib.SamplerParams}
     lines = []
     for cname, cls in structs.items():
@@ -314,3 +314,57 @@ def test_safetensors_reader_writer_and_conds_container(tmp_path):
     formats.save_packed({"x": torch.ones(3)}, tmp_path / "p.cbxpack", fp1, "kind-a")
     assert formats.load_packed(tmp_path / "p.cbxpack", fp1, "kind-a") is not None
     assert formats.load_packed(tmp_path / "p.cbxpack", fp2, "kind-a") is None and formats.load_packed(tmp_path / "p.cbxpack", fp1, "kind-b") is None
+
+
+def test_safetensors_zero_dim_tensors_and_scalar_emotion_roundtrip(tmp_path):
+    """0-d tensors (num_batches_tracked, a float emotion_adv) must serialise; a stale packed-layout version must not load."""
+    from safetensors.torch import load_file
+    from chatterbox_amd import formats
+    from chatterbox_amd.api import Conditionals, T3Cond
+    sd = {"bn.num_batches_tracked": torch.tensor(7), "s": torch.tensor(0.25), "v": torch.arange(3.0)}
+    formats.write_safetensors(sd, tmp_path / "z.safetensors")
+    back = load_file(str(tmp_path / "z.safetensors"))
+    assert all(torch.equal(back[k], sd[k]) and back[k].shape == sd[k].shape for k in sd)
+    cond = synth.t3_cond()
+    cond["emotion_adv"] = 0.5  # the dataclass default is a python float
+    c = Conditionals(T3Cond(**cond), synth.s3gen_ref())
+    c.save(tmp_path / "voice.safetensors")
+    assert float(Conditionals.load(tmp_path / "voice.safetensors").t3.emotion_adv) == 0.5
+    fp = formats.fingerprint(sd)
+    formats.save_packed({"x": torch.ones(3)}, tmp_path / "p.cbxpack", fp, formats.packed_kind("k"))
+    assert formats.load_packed(tmp_path / "p.cbxpack", fp, formats.packed_kind("k")) is not None
+    old = formats.PACKED_LAYOUT_VERSION
+    try:
+        formats.PACKED_LAYOUT_VERSION = old + 1
+        assert formats.load_packed(tmp_path / "p.cbxpack", fp, formats.packed_kind("k")) is None
+    finally:
+        formats.PACKED_LAYOUT_VERSION = old
+    # the fingerprint sees an edit anywhere in the head / tail 4 KiB, not only at 64 sampled positions
+    big = {"w": torch.zeros(100000)}
+    big2 = {"w": big["w"].clone()}
+    big2["w"][99999 - 517] = 1.0
+    assert formats.fingerprint(big) != formats.fingerprint(big2)
+
+
+def test_turbo_prompt_uses_the_15s_encoder_cut():
+    """ADVICE r02 / reference tts_turbo.py:112,258: Turbo tokenises up to 15 s of the 16 kHz prompt (375 tokens), English / MTL 6 s."""
+    import numpy as np
+    from chatterbox_amd import api, frontend as fe
+
+    class FakeAnalyzer(fe.PromptAnalyzer):
+        def __init__(self):
+            self.cuts = []
+            self.ve = type("VE", (), {"embeds_from_wavs": staticmethod(lambda wavs, sample_rate: torch.zeros(1, 256))})()
+            self.tokenizer = self._tok
+
+        def _tok(self, wav, max_len=None):
+            self.cuts.append(wav.shape[-1])
+            n = min(wav.shape[-1] // 640, max_len)
+            return torch.zeros(1, n, dtype=torch.long), torch.tensor([n])
+
+    a = FakeAnalyzer()
+    w16 = np.zeros(20 * fe.S3_SR, dtype=np.float32)
+    _, tok = a.t3_prompt(w16, 375, enc_cond_len=api.ChatterboxTurboTTS.ENC_COND_LEN)
+    assert a.cuts[-1] == 15 * fe.S3_SR and tok.shape[1] == 375
+    _, tok = a.t3_prompt(w16, 150)
+    assert a.cuts[-1] == 6 * fe.S3_SR and tok.shape[1] == 150

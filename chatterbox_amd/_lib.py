@@ -43,7 +43,7 @@ class GemmPlParams(ctypes.Structure):
         ("M", c_int), ("N", c_int), ("K", c_int),
         ("Cin", c_int), ("taps", c_int), ("dil", c_int), ("stride", c_int), ("pad_left", c_int), ("Tin", c_int), ("nz1", c_int),
         ("act", c_int), ("act_slope", c_float), ("alpha", c_float),
-        ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long),
+        ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long), ("w_s1", c_long),
         ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long),
     ]
 
@@ -103,6 +103,7 @@ _SIGS = {
     "cbx_split_planes_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_f], c_int),
     "cbx_layernorm_planes_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_float, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_split_po": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 9 + [c_float, c_int, c_f], c_int),
+    "cbx_flash_attn_planes": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_f], c_int),
     "cbx_row_stats_f32": ([c_f, c_f, c_long, c_int, c_long, c_float, c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),

@@ -15,6 +15,19 @@ __device__ __forceinline__ void cbx_amax4(float& amax, const f32x4 v) {
     asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
     asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
 }
+// Plane pair of two fp32 values (gemm_planes.hip): h = {RNE16(v0), RNE16(v1)}, l = {RNE16(2048 (v0 - h0)), RNE16(2048 (v1 - h1))}, both packed
+// lo | hi << 16.  The residual comes out of ONE mixed-precision fma per element (v_fma_mix{lo,hi}_f16: fp16 operand h, fp32 operands -2048 and
+// 2048 v; the fma is exact, so its fp16 rounding is the only one) instead of cvt + fma + cvt.  The trailing s_nop covers the
+// VALU-write -> MFMA-read wait states hipcc does not pad after an asm statement (the planes often feed an MFMA directly).
+__device__ __forceinline__ void cbx_split2(float v0, float v1, unsigned& h, unsigned& l) {
+    typedef _Float16 cbx_h2 __attribute__((ext_vector_type(2)));
+    typedef float cbx_f2 __attribute__((ext_vector_type(2)));
+    const cbx_f2 v = {v0, v1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, cbx_h2));
+    const cbx_f2 t = v * CBX_F16_LO_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(-CBX_F16_LO_SCALE), "v"(t[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(h), "s"(-CBX_F16_LO_SCALE), "v"(t[1]));
+}
 #endif
 
 extern thread_local char cbx_err_buf[512];

@@ -4,8 +4,9 @@
 //   bits, see gemm_split.hip).  Weights are split ONCE at load; activations are written in plane format by the kernel that produces
 //   them (GEMM / LayerNorm / attention epilogues, cbx_split_planes_f32) -- the same 4 bytes per element as fp32.  The consumer's K loop
 //   is then a plain fp16 MFMA loop:  acc += Ah Bh,  accc += Ah Bl + Al Bh,  C = acc + accc / 2048 (+ epilogue), with
-//     * operand tiles moved global -> LDS by global_load_lds (16 B per lane, no VGPR round trip, no VALU, no ds_write), two LDS stages,
-//       ONE barrier per K tile: the loads of tile t+1 are in flight while tile t is multiplied;
+//     * operand tiles moved global -> LDS by global_load_lds (16 B per lane, no VGPR round trip, no VALU, no ds_write), NS = 2 or 3 LDS
+//       stages, ONE barrier per K tile: the loads of tiles t+1 (.. t+NS-1) are in flight while tile t is multiplied; the wait in front of
+//       the barrier is a COUNTED vmcnt (raw s_barrier: __syncthreads() would drain every DMA in flight);
 //     * the LDS image lane-linear as the DMA writes it, bank conflicts removed by an XOR swizzle applied to the SOURCE address and to
 //       the ds_read_b128 address (cdna_hip_programming.md rule 21): chunk c of row r sits at slot r*CH + (c ^ f(r)),
 //       f(r) = (r / (16 / CH)) & (CH - 1), CH = 16-byte chunks per row and plane (BK / 8);
@@ -29,7 +30,16 @@ __device__ __attribute__((aligned(16))) const unsigned cbx_zero_page[4] = {0u, 0
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK>
+// epilogue activations of the CFM / encoder GEMMs (a compile-time-small switch: the generic cbx_act() unrolled 16 x TM x TN times is
+// most of a kernel's code)
+__device__ __forceinline__ float pl_act(float v, int act, float slope) {
+    if (act == CBX_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    if (act == CBX_ACT_SILU) return v / (1.0f + __expf(-v));
+    if (act == CBX_ACT_LRELU) return v > 0.0f ? v : v * slope;
+    return v;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int NWV = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
     const int n0 = (tile % gridDim.x) * BN, m0 = (tile / gridDim.x) * BM;
 
     const _Float16* Ab = reinterpret_cast<const _Float16*>(p.A) + (long)z * p.a_s1;
-    const _Float16* Wb = reinterpret_cast<const _Float16*>(p.W);
+    const _Float16* Wb = reinterpret_cast<const _Float16*>(p.W) + (long)z * p.w_s1;
     const int lim = p.lens ? min(p.Tin, p.lens[z]) : p.Tin;
     const int nk = p.K / BK;
 
@@ -146,13 +156,19 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
         }
     };
 
-    // ---- main loop: two LDS stages, one barrier per K tile.  __syncthreads() makes hipcc drain this wave's DMAs (vmcnt(0)) before
-    //      the barrier: after it tile kt has landed for every wave and nobody reads the other stage any more.
-    issue(0);
+    // ---- main loop: NS LDS stages, one barrier per K tile.  Before the barrier every wave waits until ITS DMAs of tile kt have landed
+    //      (counted: the NS - 2 younger tiles stay in flight); after it tile kt is complete for everybody and nobody reads the stage
+    //      that tile kt + NS - 1 is about to overwrite (it held tile kt - 1).
+    static_assert(NS == 2 || NS == 3, "two or three LDS stages");
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-        if (kt + 1 < nk) issue((kt + 1) & 1);
-        compute(kt & 1);
+        if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS);
+        compute(kt % NS);
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -166,7 +182,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
         const bool nok = n < p.N;
         const int nc = nok ? n : 0;
         const float bia = p.bias ? p.bias[nc] : 0.f;
-        const float ap = p.act_param ? p.act_param[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * WM + i * 32 + 4 * lh;
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + accc[i][j][r] * (1.0f / CBX_F16_LO_SCALE);
                 v += bia;
-                v = cbx_act(v, p.act, p.act_slope, ap);
+                v = pl_act(v, p.act, p.act_slope);
                 if (Rb) v += res[r];
                 v *= p.alpha;
                 const bool ok = nok && m < p.M;
@@ -222,10 +237,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2>
 int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 2 * (BM + BN) * (BK / 8) * 16;
-    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK>;
+    constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -264,23 +280,31 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int force = g_pl_tile;
     const bool k64 = p.Cin % 64 == 0;
-    // tiles: 128x64 / 8 waves (32x32 per wave, three workgroups per CU) is the default; see profiles/r03_gemm_planes_tiles.log
+    // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log
     switch (force) {
-        case 1: return launch_pl<128, 64, 4, 2, 32>(p, st);
-        case 2: return launch_pl<128, 64, 2, 2, 32>(p, st);   // 4 waves, 64x32 per wave
-        case 3: return launch_pl<128, 128, 2, 2, 32>(p, st);  // 4 waves, 64x64 per wave
-        case 4: return launch_pl<128, 128, 4, 2, 32>(p, st);  // 8 waves, 32x64 per wave
-        case 5: if (k64) return launch_pl<128, 64, 4, 2, 64>(p, st); break;
-        case 6: if (k64) return launch_pl<128, 64, 2, 2, 64>(p, st); break;
-        case 7: if (k64) return launch_pl<128, 128, 2, 2, 64>(p, st); break;
-        case 8: if (k64) return launch_pl<128, 128, 4, 2, 64>(p, st); break;
-        case 9: return launch_pl<64, 64, 2, 2, 32>(p, st);
-        case 10: return launch_pl<256, 64, 4, 2, 32>(p, st);  // 8 waves, 64x32 per wave
+        case 1: return launch_pl<128, 64, 4, 2, 32>(p, st);       // 8 waves 32x32, 48 KB
+        case 2: return launch_pl<128, 64, 2, 2, 32>(p, st);       // 4 waves 64x32, 48 KB
+        case 3: return launch_pl<128, 128, 2, 2, 32>(p, st);      // 4 waves 64x64, 64 KB
+        case 4: return launch_pl<128, 128, 4, 2, 32>(p, st);      // 8 waves 32x64, 64 KB
+        case 5: if (k64) return launch_pl<128, 64, 4, 2, 64>(p, st); break;    // 96 KB
+        case 6: if (k64) return launch_pl<128, 64, 2, 2, 64>(p, st); break;    // 96 KB
+        case 7: if (k64) return launch_pl<128, 128, 2, 2, 64>(p, st); break;   // 128 KB
+        case 8: if (k64) return launch_pl<128, 128, 4, 2, 64>(p, st); break;   // 128 KB
+        case 9: return launch_pl<64, 64, 2, 2, 32>(p, st);        // 4 waves 32x32, 32 KB
+        case 10: return launch_pl<256, 64, 4, 2, 32>(p, st);      // 8 waves 64x32, 80 KB
+        case 11: return launch_pl<256, 128, 4, 2, 32>(p, st);     // 8 waves 64x64, 96 KB
+        case 12: return launch_pl<128, 128, 2, 2, 32, 3>(p, st);  // 4 waves 64x64, 3 stages, 96 KB
+        case 13: return launch_pl<128, 64, 2, 2, 32, 3>(p, st);   // 4 waves 64x32, 3 stages, 72 KB
+        case 14: return launch_pl<128, 128, 2, 4, 32>(p, st);     // 8 waves 64x32, 64 KB
+        case 15: return launch_pl<128, 256, 2, 4, 32>(p, st);     // 8 waves 64x64, 96 KB
+        case 16: return launch_pl<64, 128, 2, 2, 32>(p, st);      // 4 waves 32x64, 48 KB
+        case 17: return launch_pl<128, 128, 4, 2, 32, 3>(p, st);  // 8 waves 32x64, 3 stages, 96 KB
         default: break;
     }
-    const long g128 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.nz1;
-    if (g128 < 128) return launch_pl<64, 64, 2, 2, 32>(p, st);
-    return launch_pl<128, 64, 4, 2, 32>(p, st);
+    const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
+    if (g128 < 96) return launch_pl<64, 64, 2, 2, 32>(p, st);
+    if (g128 < 384 || p.N <= 64) return launch_pl<128, 64, 2, 2, 32>(p, st);
+    return launch_pl<128, 128, 2, 2, 32>(p, st);
 }
 
 extern "C" int cbx_split_planes_f32(const float* x, void* planes, long rows, int C, long ldx, long ldp, long p_lo, void* stream) {

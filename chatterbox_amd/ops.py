@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import GemmParams, GemvParams, SamplerParams, check, lib
+from ._lib import GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -210,6 +210,111 @@ def conv1d(x, w, out, *, taps, cin, bias=None, dil=1, stride=1, pad_left=0, up=1
                 ldc2=0 if out2 is None else out2.stride(1), c2_s=(0 if out2 is None else out2.stride(0), 0), act1=act,
                 act2=act2, act1_param=act_param, act2_param=act2_param, act1_slope=act_slope, act2_slope=act2_slope,
                 alpha=alpha, beta=beta)
+
+
+# ----------------------------------------------------------------------------- plane-format operands (ABI v7, gemm_planes.hip)
+
+class Planes:
+    """An fp32 tensor (rows, C) stored as two fp16 planes x = h + l / 2048, row by row: `t` (rows, 2 * C) fp16 = [h | l].  `cols(c0, n)`
+    is the operand made of n columns from c0 on (a pointer offset: row stride and plane offset stay those of the whole tensor)."""
+
+    def __init__(self, rows, C, device, zero=False, t=None, c0=0, width=None):
+        self.t = t if t is not None else (torch.zeros if zero else torch.empty)(rows, 2 * C, dtype=torch.float16, device=device)
+        assert self.t.dtype == torch.float16 and self.t.is_cuda and self.t.stride(1) == 1
+        self.rows, self.Call, self.c0 = self.t.shape[0], self.t.shape[1] // 2, c0
+        self.C = self.Call - c0 if width is None else width
+
+    def cols(self, c0, n):
+        assert 0 <= c0 and c0 + n <= self.C
+        return Planes(0, 0, None, t=self.t, c0=self.c0 + c0, width=n)
+
+    def rows_view(self, r0, n):
+        return Planes(0, 0, None, t=self.t[r0:r0 + n], c0=self.c0, width=self.C)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 2 * self.c0
+
+    @property
+    def ld(self):
+        return self.t.stride(0)
+
+    @property
+    def lo(self):
+        return self.Call
+
+    def float(self):
+        """Back to fp32 (tests): h + l / 2048."""
+        h = self.t[:, self.c0:self.c0 + self.C].float()
+        return h + self.t[:, self.Call + self.c0:self.Call + self.c0 + self.C].float() / 2048.0
+
+
+def split_planes(x, out=None):
+    """x (rows, C) fp32 (unit inner stride, C % 4 == 0) -> Planes; `out` may be a column range of a wider Planes."""
+    rows, C = x.shape
+    assert x.stride(1) == 1
+    out = out if out is not None else Planes(rows, C, x.device)
+    assert out.C == C
+    check(lib.cbx_split_planes_f32(_p(_f32(x, "x")), out.ptr, rows, C, x.stride(0), out.ld, out.lo, _stream()), "cbx_split_planes_f32")
+    return out
+
+
+def layernorm_planes(x, w, b, out, eps=1e-5, act=NONE, post_add=None, scale=1.0):
+    """LayerNorm (C = 256) (+ activation + per-channel post_add) of fp32 rows, written in plane format."""
+    rows, C = x.shape
+    assert x.stride(1) == 1 and out.C == C
+    check(lib.cbx_layernorm_planes_f32(_p(_f32(x, "x")), out.ptr, _p(w), _p(b), _p(post_add), rows, C, x.stride(0), out.ld, out.lo, eps, act,
+                                       scale, _stream()), "cbx_layernorm_planes_f32")
+    return out
+
+
+def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, act_slope=0.0, alpha=1.0, lens=None, Cin=0, taps=1, dil=1,
+                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0):
+    """Raw access to cbx_gemm_planes (include/cbx.h): A, W, P are Planes operands, C / R fp32 tensors (their data_ptr() is the base)."""
+    p = GemmPlParams()
+    p.A, p.W, p.C, p.P = A.ptr, W.ptr, _p(C), None if P is None else P.ptr
+    p.bias, p.R, p.lens = _p(bias), _p(R), _p(lens)
+    if lens is not None:
+        assert lens.dtype == torch.int32
+    p.M, p.N, p.K = M, N, K
+    p.Cin, p.taps, p.dil, p.stride, p.pad_left, p.Tin, p.nz1 = Cin or (K // taps), taps, dil, stride, pad_left, Tin, nz1
+    p.act, p.act_slope, p.alpha = act, act_slope, alpha
+    p.lda, p.a_lo, p.a_s1 = A.ld, A.lo, a_s1
+    p.ldw, p.w_lo, p.w_s1 = W.ld, W.lo, w_s1
+    p.ldc, p.c_s1, p.ldr, p.r_s1 = ldc, c_s1, ldr, r_s1
+    if P is not None:
+        p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
+    _timed("gemm_planes", 2.0 * M * N * K * nz1, 4.0 * nz1 * (M * K / max(1, taps) + N * K + M * N),
+           lambda: check(lib.cbx_gemm_planes(ctypes.byref(p), _stream()), "cbx_gemm_planes"))
+
+
+def linear_planes(x, w, *, out=None, outp=None, bias=None, act=NONE, residual=None, act_slope=0.0):
+    """epilogue(x @ w^T) for Planes x (M, K), w (N, K): fp32 `out` (M, N) and / or Planes `outp`; residual fp32 (may alias out)."""
+    M, K, N = x.rows, x.C, w.rows
+    assert w.C == K and (out is not None or outp is not None)
+    gemm_planes(x, w, M=M, N=N, K=K, C=out, P=outp, bias=bias, R=residual, act=act, act_slope=act_slope,
+                ldc=0 if out is None else out.stride(0), ldr=0 if residual is None else residual.stride(0))
+
+
+def conv1d_planes(x, w, *, B, T, taps, cin, out=None, outp=None, bias=None, pad_left=0, lens=None, act=NONE, residual=None):
+    """Channel-last causal Conv1d as implicit GEMM on plane operands: x Planes over (B * T, cin) rows, w Planes (N, taps * cin);
+    fp32 out (B, T, N) and / or Planes outp over (B * T, N)."""
+    N = w.rows
+    assert w.C == taps * cin and x.C >= cin
+    gemm_planes(x, w, M=T, N=N, K=taps * cin, Cin=cin, taps=taps, pad_left=pad_left, Tin=T, lens=lens, nz1=B, a_s1=T * x.ld,
+                C=out, P=outp, bias=bias, R=residual, act=act, ldc=0 if out is None else out.stride(1), c_s1=0 if out is None else out.stride(0),
+                ldr=0 if residual is None else residual.stride(1), r_s1=0 if residual is None else residual.stride(0),
+                p_s1=0 if outp is None else T * outp.ld)
+
+
+def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, causal=False):
+    """q, k: Planes column ranges (Z * T rows, H * 64 columns); vt: Planes over (Z * H * 64 rows, >= T rounded up to 8 columns) = V^T
+    (batch stride vt_sb halves); out: Planes (Z * T rows, H * 64)."""
+    args = (q.ptr, k.ptr, vt.ptr, out.ptr, _p(key_lens), Z, H, T, T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo, vt_sb, vt.ld, vt.lo,
+            T * out.ld, out.ld, out.lo, scale, int(causal))
+    _timed("flash_attn_planes", 4.0 * Z * H * T * T * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * 4 * T,
+           lambda: check(lib.cbx_flash_attn_planes(*args, _stream()), "cbx_flash_attn_planes"))
+    return out
 
 
 def bmm(a, b, out, *, nn=False, alpha=1.0):

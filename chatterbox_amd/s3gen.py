@@ -110,6 +110,10 @@ class FlowEngine:
                         n=(d(sd[q + "final_block.block.2.weight"]), d(sd[q + "final_block.block.2.bias"])),
                         proj=(d(weights.pack_conv(sd[q + "final_proj.weight"])), d(sd[q + "final_proj.bias"])))
         self._pe_cache, self._tb_cache = {}, {}  # device-resident constants: rel-pos tables per length, time biases per schedule
+        # CFM estimator on plane-format operands (round 3; gemm_planes.hip / attention_planes.hip): the f16x3 arithmetic with weights
+        # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
+        self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
+        self._pw = None
 
     # ------------------------------------------------------------------ conformer encoder
     def _rel_pos_table(self, T, dev=None, dm=512):
@@ -259,6 +263,82 @@ class FlowEngine:
         ops.conv1d(a, self.fin["proj"][0], ws["v"], taps=1, cin=256, bias=self.fin["proj"][1])
         return ws["v"]
 
+    # ------------------------------------------------------------------ CFM estimator on plane-format operands
+    def _plane_weights(self):
+        if self._pw is None:
+            sp = ops.split_planes
+
+            def stage(s):
+                d = dict(c1=sp(s["c1"][0]), c2=sp(s["c2"][0]), res=sp(s["res"][0]), tb=[])
+                for t in s["tb"]:  # q | k rows of the fused projection; the v rows are the A operand of the swapped (V^T) product
+                    d["tb"].append(dict(wqk=sp(t["wqkv"][:1024]), wv=sp(t["wqkv"][1024:]), wo=sp(t["wo"]), w1=sp(t["w1"]), w2=sp(t["w2"])))
+                if "tail" in s:
+                    d["tail"] = sp(s["tail"][0])
+                return d
+
+            self._pw = dict(stages=[stage(s) for s in self.stages], fin_c=sp(self.fin["c"][0]), fin_proj=sp(self.fin["proj"][0]))
+        return self._pw
+
+    def _resnet_pl(self, sw, pw, inP, cin, rows, T, tb, ws):
+        """CausalResnetBlock1D on plane operands: inP (Planes, rows*T x cin) -> ws['x'] fp32."""
+        M = rows * T
+        a, b, x = ws["ra"], ws["rb"], ws["x"]
+        cv = lambda src, w, c, **k: ops.conv1d_planes(src, w, B=rows, T=T, cin=c, **k)
+        cv(inP, pw["c1"], cin, taps=3, out=a, bias=sw["c1"][1], pad_left=2)
+        ops.layernorm_planes(a.view(M, 256), sw["n1"][0], sw["n1"][1], ws["aP"], 1e-5, act=ops.MISH, post_add=tb)
+        cv(ws["aP"], pw["c2"], 256, taps=3, out=b, bias=sw["c2"][1], pad_left=2)
+        b2 = b.view(M, 256)
+        ops.layernorm(b2, sw["n2"][0], sw["n2"][1], b2, 1e-5, act=ops.MISH)
+        cv(inP, pw["res"], cin, taps=1, out=x, bias=sw["res"][1], residual=b)
+        return x
+
+    def _tblock_pl(self, tw, pw, x, rows, T, lens, ws, outP=None):
+        """BasicTransformerBlock on plane operands.  x (rows,T,256) fp32 residual stream, updated in place -- except by the LAST block of a
+        stage (outP given): its result only feeds convolutions, so it is written in plane format alone."""
+        M = rows * T
+        x2, hP, qkP, vtP, attP, ffP = x.view(M, 256), ws["hP"], ws["qkP"], ws["vtP"], ws["attP"], ws["ffP"]
+        ops.layernorm_planes(x2, tw["n1"][0], tw["n1"][1], hP, 1e-5)
+        ops.linear_planes(hP, pw["wqk"], outp=qkP)
+        # V^T[z] (512 x T) = W_v h[z]^T: the same products with the operands swapped, so the store is the transposed tile
+        ops.gemm_planes(pw["wv"], hP, M=512, N=T, K=256, nz1=rows, w_s1=T * hP.ld, P=vtP, p_s1=512 * vtP.ld)
+        ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=rows, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125, key_lens=lens)
+        ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
+        ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)
+        ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
+        ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
+
+    def _estimator_pl(self, xinP, rows, T, lens, tbias, ws):
+        """ConditionalDecoder.forward (decoder.py:243-333) on plane operands: xinP Planes (rows*T, 320) -> ws['v'] (rows,T,80) fp32."""
+        st, pws = self.stages, self._plane_weights()["stages"]
+        catP, xP, yP = ws["catP"], ws["xP"], ws["yP"]
+        cv = lambda src, w, **k: ops.conv1d_planes(src, w, B=rows, T=T, cin=256, **k)
+
+        def block(k, inP, cin, outP):
+            x = self._resnet_pl(st[k], pws[k], inP, cin, rows, T, tbias[k], ws)
+            for j, (tw, pw) in enumerate(zip(st[k]["tb"], pws[k]["tb"])):
+                self._tblock_pl(tw, pw, x, rows, T, lens, ws, outP if j == len(st[k]["tb"]) - 1 else None)
+
+        skip, xh = catP.cols(256, 256), catP.cols(0, 256)  # [x | skip] of the up block: both halves are written in place by their producers
+        block(0, xinP, 320, skip)
+        cur = xh if self.n_mid == 0 else yP
+        cv(skip, pws[0]["tail"], taps=3, outp=cur, bias=st[0]["tail"][1], pad_left=2)
+        for k in range(1, 1 + self.n_mid):
+            nxt = xh if k == self.n_mid else xP
+            block(k, cur, 256, nxt)
+            cur = nxt
+        block(len(st) - 1, catP, 512, xP)
+        cv(xP, pws[-1]["tail"], taps=3, outp=yP, bias=st[-1]["tail"][1], pad_left=2)
+        pw = self._plane_weights()
+        a = ws["ra"]
+        cv(yP, pw["fin_c"], taps=3, out=a, bias=self.fin["c"][1], pad_left=2)
+        ops.layernorm_planes(a.view(rows * T, 256), self.fin["n"][0], self.fin["n"][1], ws["aP"], 1e-5, act=ops.MISH)
+        cv(ws["aP"], pw["fin_proj"], taps=1, out=ws["v"], bias=self.fin["proj"][1])
+        return ws["v"]
+
+    def _planes_ok(self, rows, T):
+        """The plane-format path serves the f16x3 numerics (precision 16) with 31-bit operand offsets; anything else runs the fp32-operand kernels."""
+        return self.use_planes and ops.GEMM_PRECISION == 16 and rows * T > 32 and T % 2 == 0 and (T + 8) * 2048 * 2 < 2 ** 31
+
     def _time_bias(self, t_vals, r_vals=None):
         """SinusoidalPosEmb -> TimestepEmbedding (-> meanflow mixer) -> every ResNet's Mish+Linear (matcha/decoder.py:20-29,
         105-117; decoder.py:264-268): returns (n_steps, n_resnets, 256)."""
@@ -295,10 +375,18 @@ class FlowEngine:
         cfg = not self.meanflow
         rows = 2 * B if cfg else B
         f = lambda *s: torch.empty(*s, device=dev)
-        ws = dict(ra=f(rows, T, 256), rb=f(rows, T, 256), x=f(rows, T, 256), x2=f(rows, T, 256), y=f(rows, T, 256),
-                  cat=f(rows, T, 512),
-                  h=f(rows * T, 256), qkv=f(rows * T, 1536), att=f(rows * T, 512), ff=f(rows * T, 1024), v=f(rows, T, 80),
-                  stats=f(rows * T, 2))
+        planes = self._planes_ok(rows, T)
+        if planes:
+            M, Tp = rows * T, (T + 7) // 8 * 8
+            PL = lambda C, **k: ops.Planes(M, C, dev, **k)
+            ws = dict(ra=f(rows, T, 256), rb=f(rows, T, 256), x=f(rows, T, 256), v=f(rows, T, 80), aP=PL(256), hP=PL(256), qkP=PL(1024),
+                      attP=PL(512), ffP=PL(1024), xP=PL(256), yP=PL(256), catP=PL(512),
+                      vtP=ops.Planes(rows * 512, Tp, dev, zero=True))  # V^T rows are padded to 8 keys; the pad stays zero
+        else:
+            ws = dict(ra=f(rows, T, 256), rb=f(rows, T, 256), x=f(rows, T, 256), x2=f(rows, T, 256), y=f(rows, T, 256),
+                      cat=f(rows, T, 512),
+                      h=f(rows * T, 256), qkv=f(rows * T, 1536), att=f(rows * T, 512), ff=f(rows * T, 1024), v=f(rows, T, 80),
+                      stats=f(rows * T, 2))
         xin = torch.zeros(rows, T, 320, device=dev)
         xin[:B, :, 0:80] = z
         xin[:B, :, 80:160] = mu
@@ -313,8 +401,16 @@ class FlowEngine:
         if n_steps not in self._tb_cache:  # the schedule is a function of n_steps only: every ResNet's time bias is a load-time constant
             self._tb_cache[n_steps] = self._time_bias(t_span[:-1], t_span[1:] if self.meanflow else None)
         tb = self._tb_cache[n_steps]
+        if planes:  # the packed estimator input in plane format: [mu | spk | cond] are split once, x after every Euler step
+            xin2 = xin.view(rows * T, 320)
+            xinP = ops.split_planes(xin2)
         for k in range(n_steps):
-            v = self._estimator(xin, rows, T, lens_r, tb[k], ws)
+            if planes:
+                if k:
+                    ops.split_planes(xin2[:, :80], xinP.cols(0, 80))
+                v = self._estimator_pl(xinP, rows, T, lens_r, tb[k], ws)
+            else:
+                v = self._estimator(xin, rows, T, lens_r, tb[k], ws)
             ops.cfm_euler(xin, v, B, T, 80, float(t_span[k + 1] - t_span[k]), cfg_rate, cfg=cfg)
         return xin[:B, :, :80]
 

@@ -114,7 +114,7 @@ typedef struct cbx_gemm_pl_t {
     int Cin, taps, dil, stride, pad_left, Tin, nz1;
     int act; float act_slope, alpha;
     long lda, a_lo, a_s1;           /* halves */
-    long ldw, w_lo;                 /* halves */
+    long ldw, w_lo, w_s1;           /* halves; w_s1 = per-batch stride of W (0: shared) */
     long ldc, c_s1;                 /* floats */
     long ldr, r_s1;                 /* floats */
     long ldp, p_lo, p_s1;           /* halves */
@@ -212,6 +212,15 @@ int cbx_flash_attn_split_f32(const float* q, const float* k, const float* v, flo
 int cbx_flash_attn_split_po(const float* q, const float* k, const float* v, void* o_planes, const int* key_lens,
                             int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                             long v_sb, long v_st, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
+
+/* Flash attention (head_dim 64, f16x3 arithmetic) on plane-format operands: q, k [token][d] planes as a cbx_gemm_planes P output holds them,
+ * vt = V^T [d][token] planes (the v projection computed with swapped operands: A = W_v, W = the activations; row stride vt_sd >= Tk rounded
+ * up to 8, tails finite), o [token][d] planes.  All strides / plane offsets in halves; heads are 64 columns (q, k, o) or 64 rows (vt) apart.
+ * No operand conversion, no VALU staging: K and V^T tiles are DMA'd global -> LDS.  Replaces diffusers Attention / F.scaled_dot_product_attention
+ * inside BasicTransformerBlock (matcha/transformer.py:243-316). */
+int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
+                          int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
+                          long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
 
 /* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).
  * cache layout [row][head][pos][64]; ctx_lens[row] = number of valid positions (including the new token). */

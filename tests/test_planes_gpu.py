@@ -1,0 +1,196 @@
+"""Plane-format operands (-m gpu; ABI v7: gemm_planes.hip, attention_planes.hip, the planes LayerNorm): every entry point through the C
+ABI against an fp64 torch reference of the same op on the same seeded inputs.
+
+Tolerance: the f16x3 arithmetic carries 22 significand bits per operand and drops the l*l product; measured at the exact-fp32 MFMA's error
+level (tests/test_ops_gpu.py) -- the fp32 GEMM tolerance 3e-5 * (1 + |ref|) * sqrt(K / 256) is asserted, against fp64.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TILES = list(range(0, 18))  # 0 = the dispatcher's own choice, 1..17 = the menu of gemm_planes.hip
+
+
+def _r(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    err = (got - ref).abs()
+    bad = err > tol * (1.0 + ref.abs())
+    assert not bad.any(), f"{what}: max err {err.max():.3e} (ref max {ref.abs().max():.3e}), {int(bad.sum())} / {bad.numel()} over tol {tol}"
+
+
+def _planes_exact(x):
+    """What a planes tensor holds for fp32 x: h + l / 2048 in fp64."""
+    h = x.half()
+    l = ((x.double() - h.double()) * 2048.0).half()
+    return h.double() + l.double() / 2048.0
+
+
+def test_split_planes_roundtrip_and_range_flag(dev):
+    from chatterbox_amd import ops
+    x = _r((300, 320), 1) * torch.logspace(-3, 3, 320)[None]
+    P = ops.split_planes(x.to(dev))
+    assert torch.equal(P.float().double().cpu(), _planes_exact(x).float().double()) or (P.float().cpu().double() - _planes_exact(x)).abs().max() < 1e-12
+    rel = ((P.float().cpu().double() - x.double()).abs() / x.abs().double().clamp_min(1e-30)).max()
+    assert rel < 2.0 ** -21, f"plane pair keeps 22 significand bits, rel err {rel:.3e}"
+    # a column range of a wider tensor
+    W = ops.Planes(300, 512, dev, zero=True)
+    ops.split_planes(x.to(dev)[:, :80], W.cols(256, 80))
+    assert torch.equal(W.cols(256, 80).float().cpu(), P.cols(0, 80).float().cpu()) and float(W.cols(0, 256).float().abs().max()) == 0.0
+    ops.enable_range_flag(dev)
+    assert not ops.range_flag_tripped()
+    big = x.clone()
+    big[17, 5] = 7e4
+    ops.split_planes(big.to(dev))
+    assert ops.range_flag_tripped() and not ops.range_flag_tripped()
+
+
+@pytest.mark.parametrize("tile", TILES)
+def test_gemm_planes_linear_tiles(dev, tile):
+    """Every tile shape of the menu: ragged M and N, bias + GELU + residual, fp32 and plane outputs."""
+    from chatterbox_amd import ops
+    try:
+        ops.lib.cbx_set_planes_tile(tile)
+        for (M, N, K) in [(1000, 1536, 256), (333, 80, 256), (129, 258, 512), (2048, 256, 1024)]:
+            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+            xP, wP = ops.split_planes(x.to(dev)), ops.split_planes(w.to(dev))
+            ref0 = F.linear(_planes_exact(x), _planes_exact(w), b.double())
+            tol = 3e-5 * max(1.0, math.sqrt(K / 256))
+            for act, fn in ((ops.NONE, lambda t: t), (ops.GELU_ERF, F.gelu), (ops.SILU, F.silu)):
+                out = r.clone().to(dev)
+                outP = ops.Planes(M, N, dev, zero=True)
+                ops.linear_planes(xP, wP, out=out, outp=outP, bias=b.to(dev), act=act, residual=out)
+                ref = fn(ref0) + r.double()
+                _close(out, ref, tol, f"tile {tile} {M}x{N}x{K} act {act} (fp32 out)")
+                _close(outP.float(), ref, tol, f"tile {tile} {M}x{N}x{K} act {act} (plane out)")
+                assert (outP.float() - out).abs().max() <= 2.0 ** -21 * out.abs().max(), "plane output = split of the fp32 output"
+    finally:
+        ops.lib.cbx_set_planes_tile(0)
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3, 7, 11, 12, 15])
+def test_gemm_planes_conv_and_swapped_product(dev, tile):
+    """Causal Conv1d as implicit GEMM on planes (3 taps, left pad, batches, ragged lens), a column-range A operand, and the swapped
+    (V^T) product with a per-batch W operand."""
+    from chatterbox_amd import ops
+    try:
+        ops.lib.cbx_set_planes_tile(tile)
+        B, T, cin, N = 3, 517, 320, 256
+        x, w, b = _r((B, T, cin), 1), _r((N, cin, 3), 2, 1 / math.sqrt(3 * cin)), _r((N,), 3)
+        ref = F.conv1d(F.pad(_planes_exact(x).transpose(1, 2), (2, 0)), _planes_exact(w), b.double()).transpose(1, 2)
+        wp = w.permute(0, 2, 1).reshape(N, 3 * cin).contiguous()  # tap-major packing (weights.pack_conv)
+        wide = ops.Planes(B * T, 512, dev, zero=True)  # A is a column range (64 .. 384) of a wider planes tensor
+        ops.split_planes(x.reshape(B * T, cin).to(dev), wide.cols(64, cin))
+        out, outP = torch.empty(B, T, N, device=dev), ops.Planes(B * T, N, dev)
+        ops.conv1d_planes(wide.cols(64, cin), ops.split_planes(wp.to(dev)), B=B, T=T, taps=3, cin=cin, out=out, outp=outP, bias=b.to(dev), pad_left=2)
+        _close(out, ref, 6e-5, f"conv3 tile {tile}")
+        _close(outP.float().view(B, T, N), ref, 6e-5, f"conv3 planes tile {tile}")
+        # ragged input lengths: rows >= lens[z] read as zero
+        lens = torch.tensor([517, 100, 3], dtype=torch.int32)
+        xm = x.clone()
+        for z in range(B):
+            xm[z, lens[z]:] = 0
+        refm = F.conv1d(F.pad(_planes_exact(xm).transpose(1, 2), (2, 0)), _planes_exact(w), b.double()).transpose(1, 2)
+        ops.conv1d_planes(wide.cols(64, cin), ops.split_planes(wp.to(dev)), B=B, T=T, taps=3, cin=cin, out=out, bias=b.to(dev), pad_left=2,
+                          lens=lens.to(dev))
+        _close(out, refm, 6e-5, f"conv3 lens tile {tile}")
+        # swapped product: VT[z] (D x T) = Wv (D x K) @ h[z]^T, written as planes with row stride >= T rounded up to 8
+        D, K, Tp = 512, 256, (T + 7) // 8 * 8
+        wv, h = _r((D, K), 5, 1 / 16), _r((B * T, K), 6)
+        vt = ops.Planes(B * D, Tp, dev, zero=True)
+        hP = ops.split_planes(h.to(dev))
+        ops.gemm_planes(ops.split_planes(wv.to(dev)), hP, M=D, N=T - 1 if T % 2 else T, K=K, nz1=B, w_s1=T * hP.ld, P=vt, p_s1=D * vt.ld)
+        n = T - 1 if T % 2 else T
+        refv = torch.einsum("dk,ztk->zdt", _planes_exact(wv), _planes_exact(h).view(B, T, K))
+        got = vt.float().view(B, D, Tp)
+        _close(got[:, :, :n], refv[:, :, :n], 3e-5, f"swapped product tile {tile}")
+        assert float(got[:, :, n:].abs().max()) == 0.0, "pad columns stay untouched"
+    finally:
+        ops.lib.cbx_set_planes_tile(0)
+
+
+def test_layernorm_planes(dev):
+    from chatterbox_amd import ops
+    M, C = 1003, 256
+    x, w, b, tb = _r((M, C), 1) * 3 + 0.5, 1 + 0.1 * _r((C,), 2), 0.1 * _r((C,), 3), _r((C,), 4)
+    out = ops.Planes(M, C, dev)
+    ops.layernorm_planes(x.to(dev), w.to(dev), b.to(dev), out)
+    ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5)
+    _close(out.float(), ref, 2e-6, "layernorm planes")
+    ops.layernorm_planes(x.to(dev), w.to(dev), b.to(dev), out, act=ops.MISH, post_add=tb.to(dev))
+    _close(out.float(), F.mish(ref) + tb.double(), 3e-6, "layernorm + mish + time bias planes")
+    plain = torch.empty(M, C, device=dev)
+    ops.layernorm(x.to(dev), w.to(dev), b.to(dev), plain, 1e-5, act=ops.MISH, post_add=tb.to(dev))
+    assert (out.float() - plain).abs().max() <= 2.0 ** -21 * plain.abs().max(), "planes = split of the fp32 LayerNorm kernel's result"
+
+
+@pytest.mark.parametrize("Z,T,lens", [(2, 1000, None), (3, 517, [517, 130, 64]), (1, 64, None), (2, 200, [1, 199])])
+def test_flash_attn_planes(dev, Z, T, lens):
+    """q, k as column ranges of one planes tensor, V^T from the swapped layout; ragged key lengths; vs fp64 softmax attention on the
+    values the planes hold."""
+    from chatterbox_amd import ops
+    H, Tp = 8, (T + 7) // 8 * 8
+    q, k, v = _r((Z, T, H, 64), 1) * 1.5, _r((Z, T, H, 64), 2) * 1.5, _r((Z, T, H, 64), 3)
+    qk = ops.Planes(Z * T, 1024, dev)
+    ops.split_planes(q.reshape(Z * T, 512).to(dev), qk.cols(0, 512))
+    ops.split_planes(k.reshape(Z * T, 512).to(dev), qk.cols(512, 512))
+    vt = ops.Planes(Z * 512, Tp, dev, zero=True)
+    vtt = torch.zeros(Z, 512, Tp)
+    vtt[:, :, :T] = v.reshape(Z, T, 512).transpose(1, 2)
+    ops.split_planes(vtt.reshape(Z * 512, Tp).to(dev), vt)
+    out = ops.Planes(Z * T, 512, dev)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=dev)
+    ops.flash_attn_planes(qk.cols(0, 512), qk.cols(512, 512), vt, out, Z=Z, H=H, T=T, vt_sb=512 * vt.ld, scale=0.125, key_lens=kl)
+    qe, ke, ve = _planes_exact(q), _planes_exact(k), _planes_exact(v)
+    s = torch.einsum("zqhd,zkhd->zhqk", qe, ke) * 0.125
+    if lens is not None:
+        for z, n in enumerate(lens):
+            s[z, :, :, n:] = -math.inf
+    ref = torch.einsum("zhqk,zkhd->zqhd", torch.softmax(s, -1), ve).reshape(Z * T, 512)
+    _close(out.float(), ref, 2e-5, f"flash attention planes Z={Z} T={T} lens={lens}")
+
+
+def test_flash_attn_planes_forced_rescale(dev):
+    """A key whose score jumps far above everything seen before, placed in a late tile: the running-maximum rescale branch must fire
+    and scale O, l exactly once (guide rule 26: the branch is data dependent and rare on random inputs)."""
+    from chatterbox_amd import ops
+    Z, T, H = 1, 512, 8
+    q, k, v = _r((Z, T, H, 64), 1) * 0.3, _r((Z, T, H, 64), 2) * 0.3, _r((Z, T, H, 64), 3)
+    k[0, 300] = q[0, 10] * 40.0  # raw score 40 |q|^2 for query 10 (and large for its neighbours in direction), tile 4
+    qk = ops.Planes(Z * T, 1024, dev)
+    ops.split_planes(q.reshape(Z * T, 512).to(dev), qk.cols(0, 512))
+    ops.split_planes(k.reshape(Z * T, 512).to(dev), qk.cols(512, 512))
+    vt = ops.split_planes(v.reshape(Z, T, 512).transpose(1, 2).reshape(512, T).contiguous().to(dev))
+    out = ops.Planes(Z * T, 512, dev)
+    ops.flash_attn_planes(qk.cols(0, 512), qk.cols(512, 512), vt, out, Z=Z, H=H, T=T, vt_sb=512 * vt.ld, scale=0.125)
+    s = torch.einsum("zqhd,zkhd->zhqk", _planes_exact(q), _planes_exact(k)) * 0.125
+    ref = torch.einsum("zhqk,zkhd->zqhd", torch.softmax(s, -1), _planes_exact(v)).reshape(Z * T, 512)
+    _close(out.float(), ref, 2e-5, "rescale branch")
+
+
+def test_estimator_planes_path_matches_fp32_operand_path(dev, monkeypatch):
+    """The plane-format CFM estimator against the fp32-operand f16x3 path (CBX_PLANES = 0) of the same engine: the same arithmetic on the
+    same operand values, so the mels agree far inside the parity tolerance; ragged batch of two."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.s3gen import FlowEngine
+    sd = synth.s3gen_state_dict(0, n_mid=2, n_enc=1, n_up_enc=1)
+    eng = FlowEngine(sd, dev, precision=16)
+    P, N = 24, 41
+    ref = synth.s3gen_ref(n_prompt_tokens=P)
+    toks = torch.stack([synth.speech_tokens(N, seed=1), synth.speech_tokens(N, seed=2)])
+    lens = torch.tensor([N, N - 13])
+    z = synth.randn((2, 2 * (P + N), 80), seed=5).to(dev)
+    assert eng.use_planes
+    mel_p = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
+    eng.use_planes = False
+    mel_f = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
+    for b, n in enumerate(lens.tolist()):
+        d = (mel_p[b, : 2 * n] - mel_f[b, : 2 * n]).abs()
+        assert d.mean() <= 2e-6 and d.max() <= 3e-5, f"row {b}: mean {d.mean():.2e} max {d.max():.2e}"

@@ -44,7 +44,7 @@ class GemmPlParams(ctypes.Structure):
         ("Cin", c_int), ("taps", c_int), ("dil", c_int), ("stride", c_int), ("pad_left", c_int), ("Tin", c_int), ("nz1", c_int),
         ("act", c_int), ("act_slope", c_float), ("alpha", c_float),
         ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long), ("w_s1", c_long),
-        ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long),
+        ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long), ("reserved0", c_int),
     ]
 
 

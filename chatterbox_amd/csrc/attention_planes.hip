@@ -18,6 +18,7 @@
 //   the softmax.  The softmax scale is folded into the exponent (p = exp2(fma(s, scale*log2 e, -m*scale*log2 e))): Q is used as stored.
 //
 // Replaces diffusers Attention (scaled_dot_product_attention) inside BasicTransformerBlock (reference matcha/transformer.py:243-316).
+#include <stdlib.h>
 #include "cbx_common.h"
 
 namespace {
@@ -36,6 +37,7 @@ struct FlashPlArgs {
     long q_sb, q_st, q_lo, k_sb, k_st, k_lo, vt_sb, vt_sd, vt_lo, o_sb, o_st, o_lo;  // halves
     float scale;
     int causal;
+    int diag;  // -DCBX_DIAG builds only (scripts/diag_planes.sh): 1 no DMA in the loop, 2 no S MFMAs, 4 no softmax, 8 no PV MFMAs, 16 no P split
 };
 
 constexpr int PKT = 64;                  // keys per tile
@@ -122,10 +124,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
     const int swz = (lr >> 1) & 7;
     const int row_off = lr * 128;
 
+#ifdef CBX_DIAG
+    const int dg = a.diag;
+#define DG(bit) (dg & (bit))
+#else
+#define DG(bit) 0
+#endif
     for (int j0 = 0, t = 0; j0 < kend; j0 += PKT, ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j0 + PKT < kend) issue((t + 1) & 1);
+        if (j0 + PKT < kend && !DG(1)) issue((t + 1) & 1);
         const unsigned char* st_k = smem + (t & 1) * PL_STAGE;
         const unsigned char* st_v = st_k + 2 * PL_TILE;
 
@@ -136,6 +144,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
             f32x16 stc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[s][r] = stc[r] = 0.f;
+            if (DG(2)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[s][r] = (float)(r + lane) * 0.01f;
+            } else
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 const int off = s * 32 * 128 + row_off + (((2 * kc + lh) ^ swz) << 4);
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
         // ---- online softmax: register r of sub-tile s is key j0 + 32 s + 16 (r >> 3) + 8 lh + (r & 7)
         const bool full = j0 + PKT <= klen && (!a.causal || j0 + PKT - 1 <= q_lo);  // wave-uniform: nothing to mask in this tile
         float mt = -INFINITY;
+        if (!DG(4)) {
         if (full) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
                 otc[d] *= alpha;
             }
         }
+        }  // !DG(4)
 
         // ---- O^T += V^T P^T : chunk c = 2s + u contracts the 16 keys held in registers 8u..8u+7 of both half-waves
 #pragma unroll
@@ -198,9 +212,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned h2, l2;
+                    if (DG(16)) {
+                        h2 = __builtin_bit_cast(unsigned, st[s][8 * u + 2 * e]);
+                        l2 = __builtin_bit_cast(unsigned, st[s][8 * u + 2 * e + 1]);
+                    } else
                     cbx_split2(st[s][8 * u + 2 * e], st[s][8 * u + 2 * e + 1], h2, l2);
                     ph[e] = h2;
                     pl[e] = l2;
+                }
+                if (DG(8)) {
+                    asm volatile("" ::"v"(ph), "v"(pl));
+                    continue;
                 }
                 const f16x8 pfh = __builtin_bit_cast(f16x8, ph), pfl = __builtin_bit_cast(f16x8, pl);
                 const int c = 2 * s + u;
@@ -248,7 +270,10 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
     CBX_REQUIRE(vt_sd >= (Tk + 7) / 8 * 8, "flash_attn_planes: a V^T row must hold Tk rounded up to 8 keys (got stride %ld for Tk = %d)", vt_sd, Tk);
     FlashPlArgs a{reinterpret_cast<const _Float16*>(q), reinterpret_cast<const _Float16*>(k), reinterpret_cast<const _Float16*>(vt),
                   reinterpret_cast<_Float16*>(o), key_lens, Tq, Tk, q_sb, q_st, q_lo, k_sb, k_st, k_lo, vt_sb, vt_sd, vt_lo, o_sb, o_st, o_lo,
-                  scale, causal};
+                  scale, causal, 0};
+#ifdef CBX_DIAG
+    a.diag = getenv("CBX_ATTN_DIAG") ? atoi(getenv("CBX_ATTN_DIAG")) : 0;
+#endif
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     hipLaunchKernelGGL(flash_attn_pl_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return cbx_check_launch("flash_attn_planes");

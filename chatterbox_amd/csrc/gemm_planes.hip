@@ -160,61 +160,103 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
     //      (counted: the NS - 2 younger tiles stay in flight); after it tile kt is complete for everybody and nobody reads the stage
     //      that tile kt + NS - 1 is about to overwrite (it held tile kt - 1).
     static_assert(NS == 2 || NS == 3, "two or three LDS stages");
+#ifdef CBX_DIAG  // scripts/diag_planes.sh: parts of the kernel switched off (1 no DMA after the prologue, 2 no ds_read / MFMA, 4 no epilogue stores)
+    const int dg = p.reserved0;
+#define DG(bit) (dg & (bit))
+#else
+#define DG(bit) 0
+#endif
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        if (NS == 3 && kt + 1 < nk && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS);
-        compute(kt % NS);
+        if (kt + NS - 1 < nk && !DG(1)) issue((kt + NS - 1) % NS);
+        if (!DG(2)) compute(kt % NS);
     }
 
-    // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cb = p.C ? p.C + (long)z * p.c_s1 : nullptr;
-    _Float16* Pb = p.P ? reinterpret_cast<_Float16*>(p.P) + (long)z * p.p_s1 : nullptr;
-    const float* Rb = p.R ? p.R + (long)z * p.r_s1 : nullptr;
+    // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    //      Lean by construction: every store / residual load is ONE buffer instruction (32-bit lane offset + a scalar row offset); rows >= M fall
+    //      behind num_records and are dropped by the hardware, lanes whose column is >= N carry an out-of-range offset; the activation
+    //      and the output kinds are branched on once per tile, never per element.
+    constexpr int OOB = (int)0x80000000;
+    const int Mrem = p.M;
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.C ? p.C + (long)z * p.c_s1 : nullptr, 0, p.C ? (int)((((long)Mrem - 1) * p.ldc + p.N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.R ? p.R + (long)z * p.r_s1 : nullptr), 0, p.R ? (int)((((long)Mrem - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
+    // plane output: the l plane lies p_lo halves after the h plane of the same row, so one descriptor covers both
+    const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.P ? reinterpret_cast<_Float16*>(p.P) + (long)z * p.p_s1 : nullptr, 0, p.P ? (int)((((long)Mrem - 1) * p.ldp + p.p_lo + p.N) * 2) : 0, 0x00020000);
+    const bool hasC = p.C != nullptr, hasP = p.P != nullptr, hasR = p.R != nullptr;
+    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4, ldp2 = (int)p.ldp * 2;
+    const bool odd = lr & 1;
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + lr;
         const bool nok = n < p.N;
-        const int nc = nok ? n : 0;
-        const float bia = p.bias ? p.bias[nc] : 0.f;
+        const float bia = p.bias ? p.bias[nok ? n : 0] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * WM + i * 32 + 4 * lh;
-            float res[16];
-            if (Rb) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * lh;  // row of register 0
+            float v[16], res[16];
+            if (hasR) {
+                const int ro = nok ? mb * ldr4 + n * 4 : OOB;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) res[r] = Rb[(long)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + nc];
+                for (int r = 0; r < 16; ++r)
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, ro, ((r & 3) + 8 * (r >> 2)) * ldr4, 0));
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + accc[i][j][r] * (1.0f / CBX_F16_LO_SCALE);
-                v += bia;
-                v = pl_act(v, p.act, p.act_slope);
-                if (Rb) v += res[r];
-                v *= p.alpha;
-                const bool ok = nok && m < p.M;
-                if (Cb && ok) Cb[(long)m * p.ldc + n] = v;
-                if (Pb) {
-                    // plane pair of this element, exchanged with the neighbouring column's lane: even lanes store two h, odd lanes two l
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)__builtin_fmaf((float)h, -CBX_F16_LO_SCALE, v * CBX_F16_LO_SCALE);
-                    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-                    const bool odd = lr & 1;
-                    const unsigned word = odd ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
-                    asm("v_max3_f32 %0, |%1|, %0, %0" : "+v"(amax) : "v"(v));
-                    if (ok) *reinterpret_cast<unsigned*>(Pb + (long)m * p.ldp + (odd ? p.p_lo + n - 1 : n)) = word;
+            for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(accc[i][j][r], 1.0f / CBX_F16_LO_SCALE, acc[i][j][r]) + bia;
+            if (p.act == CBX_ACT_GELU_ERF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+            } else if (p.act != CBX_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = pl_act(v[r], p.act, p.act_slope);
+            }
+            if (hasR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += res[r];
+            }
+            if (p.alpha != 1.0f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+            }
+            if (hasC && !DG(4)) {
+                const int co = nok ? mb * ldc4 + n * 4 : OOB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), c_rs, co, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+            }
+            if (hasP) {
+                // The lane pair (even, odd column) owns columns n, n + 1 of every row.  Of each register pair (rows m, m + 1) the even lane
+                // converts row m and the odd lane row m + 1: one exchange gives each lane both columns of its row, which it splits into the h
+                // word and the l word (two 4-byte stores per lane and register pair instead of a conversion per element).
+                const int ne = n & ~1;  // first column of the pair
+                const int po = (ne < p.N ? mb * ldp2 + ne * 2 : OOB) + (odd ? ldp2 : 0);
+                const int plo2 = (int)p.p_lo * 2;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float give = odd ? v[r] : v[r + 1];
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                    const float c0 = odd ? got : v[r], c1 = odd ? v[r + 1] : got;  // columns ne, ne + 1 of this lane's row
+                    unsigned h2, l2;
+                    cbx_split2(c0, c1, h2, l2);
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(c0), "v"(c1));
+                    if (!DG(4)) {
+                        const int so = ((r & 3) + 8 * (r >> 2)) * ldp2;
+                        __builtin_amdgcn_raw_buffer_store_b32(h2, p_rs, po, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(l2, p_rs, po + plo2, so, 0);
+                    }
                 }
             }
         }
     }
-    if (Pb && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+    if (hasP && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
 }
 
 // x (rows, C) fp32 -> planes.  One float4 per thread; two 8-byte stores.
@@ -276,7 +318,11 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE((p.lda | p.a_lo | p.a_s1 | p.ldw | p.w_lo) % 8 == 0 && (((uintptr_t)p.A | (uintptr_t)p.W) & 15) == 0,
                 "gemm_planes: operand planes must be 16-byte aligned (strides / plane offsets multiples of 8 halves)");
     CBX_REQUIRE(!p.P || ((p.N | p.ldp | p.p_lo | p.p_s1) % 2 == 0 && ((uintptr_t)p.P & 3) == 0), "gemm_planes: plane output needs even N / strides");
-    CBX_REQUIRE(p.nz1 == 1 || p.taps >= 1, "gemm_planes: bad batch");
+    CBX_REQUIRE((!p.C || ((long)p.M * p.ldc + p.N) * 4 < 0x7fffffffL) && (!p.R || ((long)p.M * p.ldr + p.N) * 4 < 0x7fffffffL) &&
+                    (!p.P || ((long)p.M * p.ldp + p.p_lo + p.N) * 2 < 0x7fffffffL),
+                "gemm_planes: one batch of an output / residual must span less than 2 GiB (32-bit buffer offsets)");
+    CBX_REQUIRE((!p.C || p.ldc >= p.N) && (!p.R || p.ldr >= p.N) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + p.N)),
+                "gemm_planes: rows must not overlap (ldc, ldr >= N; plane output rows hold [h | l]: ldp >= p_lo + N)");
     hipStream_t st = (hipStream_t)stream;
     const int force = g_pl_tile;
     const bool k64 = p.Cin % 64 == 0;

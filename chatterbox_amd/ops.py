@@ -284,6 +284,7 @@ def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, a
     p.ldc, p.c_s1, p.ldr, p.r_s1 = ldc, c_s1, ldr, r_s1
     if P is not None:
         p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
+    p.reserved0 = GEMM_DIAG
     _timed("gemm_planes", 2.0 * M * N * K * nz1, 4.0 * nz1 * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_planes(ctypes.byref(p), _stream()), "cbx_gemm_planes"))
 

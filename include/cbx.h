@@ -118,6 +118,7 @@ typedef struct cbx_gemm_pl_t {
     long ldc, c_s1;                 /* floats */
     long ldr, r_s1;                 /* floats */
     long ldp, p_lo, p_s1;           /* halves */
+    int reserved0;                  /* 0 (diagnostic switches of a -DCBX_DIAG build) */
 } cbx_gemm_pl_t;
 int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
 /* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */

@@ -20,16 +20,26 @@ tiles = [int(t) for t in os.environ.get("CBX_PL_TILES", ",".join(str(i) for i in
 
 
 def timeit(fn, reps=REPS):
-    for _ in range(3):
+    """us per launch inside a captured hipGraph of `reps` back-to-back launches (no host launch cost: a Python-issued launch costs
+    10-20 us, more than some of these kernels; includes the ~1.5 us dependent-kernel boundary)."""
+    for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3  # us
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3  # us
 
 
 # ramp the clocks

@@ -38,8 +38,9 @@ def test_split_planes_roundtrip_and_range_flag(dev):
     x = _r((300, 320), 1) * torch.logspace(-3, 3, 320)[None]
     P = ops.split_planes(x.to(dev))
     assert torch.equal(P.float().double().cpu(), _planes_exact(x).float().double()) or (P.float().cpu().double() - _planes_exact(x)).abs().max() < 1e-12
-    rel = ((P.float().cpu().double() - x.double()).abs() / x.abs().double().clamp_min(1e-30)).max()
-    assert rel < 2.0 ** -21, f"plane pair keeps 22 significand bits, rel err {rel:.3e}"
+    err = (P.float().cpu().double() - x.double()).abs()
+    # 22 significand bits wherever h is a normal fp16 (|x| >= 6.1e-5); below that the second plane's subnormal spacing / 2048 bounds the error
+    assert bool((err <= x.abs().double() * 2.0 ** -21 + 3e-11).all()), f"plane pair error {float((err / x.abs().double().clamp_min(1e-30)).max()):.3e}"
     # a column range of a wider tensor
     W = ops.Planes(300, 512, dev, zero=True)
     ops.split_planes(x.to(dev)[:, :80], W.cols(256, 80))

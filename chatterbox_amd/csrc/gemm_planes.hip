@@ -347,10 +347,14 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 17: return launch_pl<128, 128, 4, 2, 32, 3>(p, st);  // 8 waves 32x64, 3 stages, 96 KB
         default: break;
     }
+    // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere (more waves to overlap DMA issue,
+    // MFMA and the epilogue); wide outputs 2 x 4 waves of 64 x 32, narrow outputs with a long K the BK = 64 form, N <= 96 half-width tiles
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
-    if (g128 < 96) return launch_pl<64, 64, 2, 2, 32>(p, st);
-    if (g128 < 384 || p.N <= 64) return launch_pl<128, 64, 2, 2, 32>(p, st);
-    return launch_pl<128, 128, 2, 2, 32>(p, st);
+    if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
+    if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
+    if (p.N >= 512) return launch_pl<128, 128, 2, 4, 32>(p, st);
+    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64>(p, st);
+    return launch_pl<128, 128, 4, 2, 32>(p, st);
 }
 
 extern "C" int cbx_split_planes_f32(const float* x, void* planes, long rows, int C, long ldx, long ldp, long p_lo, void* stream) {

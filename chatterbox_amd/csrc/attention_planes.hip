@@ -43,6 +43,7 @@ struct FlashPlArgs {
 constexpr int PKT = 64;                  // keys per tile
 constexpr int PL_TILE = 64 * 8 * 16;     // one plane of one operand tile: 64 rows x 8 chunks x 16 B
 constexpr int PL_STAGE = 4 * PL_TILE;    // K h, K l, V^T h, V^T l
+constexpr float PL_THR = 3.0f;           // version 2: slack of the running maximum (log2 units) before O is rescaled
 
 __device__ __forceinline__ void mma3(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16& acc, f32x16& accc) {
     accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc, 0, 0, 0);
@@ -256,7 +257,245 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
     }
 }
 
+// x of lane (l ^ 32): one v_permlane32_swap instead of a ds_bpermute round trip.  The two operands of the swap must be DIFFERENT registers
+// (vdst lanes 32-63 <-> src lanes 0-31): hipcc folds permlane32_swap(x, x) into "both results equal", so the copy is made opaque.
+__device__ __forceinline__ float half_swap(float x) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    asm volatile("" : "+v"(b));
+    const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // sw[0] = {x_lo, x_lo}, sw[1] = {x_hi, x_hi}
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? sw[0] : sw[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Version 2 ("ping-pong"): 8 waves = two groups of 4, each SIMD hosts one wave of each group.  A group's work per KV tile is a MATRIX block
+// [PV(t-1), S(t)] (48 MFMAs, LDS reads, its share of the DMA issue) and a VECTOR block [softmax(t): S -> P planes in registers, running
+// maximum / sum, O rescale].  The groups run half an iteration apart (group 1 passes one extra barrier first) and every block ends at a
+// workgroup barrier, so on every SIMD one wave is in its matrix block while the other is in its vector block: the matrix pipe and the
+// VALU work at the same time by construction instead of by the luck of the wave scheduler (measured on version 1: S / PV MFMAs, softmax
+// VALU and DMA issue were ADDITIVE, profiles/r03_planes_diag_switches.log).  The two groups own two 128-query blocks and share the K / V^T
+// tiles (half the L2 -> LDS traffic per query).  Tiles sit in a 3-stage LDS ring; in its matrix block t group 0 issues K(t+2), group 1
+// V^T(t+1) (one tile ahead of its use in PV), by buffer_load ... lds with the key-length bound in the K descriptor (rows >= klen return
+// zeros: no per-lane address arithmetic in the loop at all).
+template <bool PRIO>
+__global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // 3 stages x [K h, K l, V^T h, V^T l] x 8 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tile = cbx_xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int qt = tile % gridDim.x, head = (tile / gridDim.x) % gridDim.y, z = tile / (gridDim.x * gridDim.y);
+    const int q0 = qt * 256;
+    const int qi = q0 + wid * 32 + lr;  // this lane's query (group g owns queries q0 + 128 g .. + 128)
+    const _Float16* qb = a.q + (long)z * a.q_sb + head * 64;
+    const _Float16* kb = a.k + (long)z * a.k_sb + head * 64;
+    const _Float16* vb = a.vt + (long)z * a.vt_sb + (long)head * 64 * a.vt_sd;
+    const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
+    const int nt = (klen + PKT - 1) / PKT;
+
+    // ---- DMA: a (K, V^T) tile pair is 32 wave-level loads of 1 KiB; wave w issues loads 4w .. 4w+3: waves 0-3 (group 0) the K tile
+    //      (h rows 0-31, h rows 32-63, l rows 0-31, l rows 32-63), waves 4-7 the V^T tile likewise.
+    const int plane = (wid >> 1) & 1, rbase = (wid & 1) * 32;
+    const __amdgpu_buffer_rsrc_t rs = grp == 0
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kb), 0, klen > 0 ? (int)((((long)klen - 1) * a.k_st + a.k_lo + 64) * 2) : 0, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(vb), 0, (int)(64 * a.vt_sd * 2), 0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rbase + 8 * i + (lane >> 3), pc = lane & 7;
+        const int c = pc ^ ((row >> 1) & 7);
+        if (grp == 0) {  // row slot `row` holds key row with bits 2 and 3 swapped
+            const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+            voff[i] = (int)((key * a.k_st + plane * a.k_lo) * 2) + c * 16;
+        } else {
+            voff[i] = (int)((row * a.vt_sd + plane * a.vt_lo) * 2) + c * 16;
+        }
+    }
+    const int tstep = grp == 0 ? (int)(PKT * a.k_st * 2) : PKT * 2;  // bytes per tile along the key axis
+    const int lds_w = ((grp ? 2 : 0) + plane) * PL_TILE + rbase * 128;  // this wave's first destination inside a stage
+    auto issue = [&](int t) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3
+        unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i], t * tstep, 0, 0);
+    };
+    if (nt > 0) issue(0);
+    if (grp == 0 && nt > 1) issue(1);
+
+    f16x8 qh[4], ql[4];
+    {
+        const bool ok = qi < a.Tq;
+        const _Float16* qp = qb + (long)(ok ? qi : 0) * a.q_st + 8 * lh;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            qh[kc] = *reinterpret_cast<const f16x8*>(qp + 16 * kc);
+            ql[kc] = *reinterpret_cast<const f16x8*>(qp + a.q_lo + 16 * kc);
+        }
+    }
+    const float sc = a.scale * 1.4426950408889634f;
+
+    f32x16 ot[2], otc[2], st[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = otc[d][r] = st[d][r] = 0.f;
+    u32x4 ph[4], pl[4];  // P planes of the previous tile: chunk c = 2s + u holds keys 16c + 8lh .. +8 of the lane's query
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ph[c] = pl[c] = u32x4{0u, 0u, 0u, 0u};
+    float m_run = -INFINITY, mc_run = -INFINITY, l_run = 0.f;
+    const int jmax = klen - 1;
+    const int swz = (lr >> 1) & 7;
+    const int row_off = lr * 128;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // tile 0 (and K(1)) are in LDS for everybody
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1's matrix block t runs beside group 0's vector block t
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t <= nt; ++t) {
+        // ================= matrix block: PV(t-1), S(t)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the previous block (an iteration old): published by the barriers below
+        if (grp == 0) {
+            if (t + 2 < nt) issue(t + 2);
+        } else {
+            if (t + 1 < nt) issue(t + 1);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (t > 0) {
+            const unsigned char* st_v = smem2 + ((t - 1) % 3) * PL_STAGE + 2 * PL_TILE;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 pfh = __builtin_bit_cast(f16x8, ph[c]), pfl = __builtin_bit_cast(f16x8, pl[c]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int off = dt * 32 * 128 + row_off + (((2 * c + lh) ^ swz) << 4);
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(st_v + off);
+                    const f16x8 vl = *reinterpret_cast<const f16x8*>(st_v + PL_TILE + off);
+                    otc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pfh, otc[dt], 0, 0, 0);  // V_l h'  (1/2048 accumulator)
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pfl, ot[dt], 0, 0, 0);    // V_h l''
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pfh, ot[dt], 0, 0, 0);    // V_h h'
+                }
+            }
+        }
+        if (t < nt) {
+            const unsigned char* st_k = smem2 + (t % 3) * PL_STAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x16 stc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[s][r] = stc[r] = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int off = s * 32 * 128 + row_off + (((2 * kc + lh) ^ swz) << 4);
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(st_k + off);
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(st_k + PL_TILE + off);
+                    mma3(kh, kl, qh[kc], ql[kc], st[s], stc);
+                }
+                st[s] += stc * (1.0f / CBX_F16_LO_SCALE);
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= vector block: softmax(t) -> P planes
+        if (t < nt) {
+            const int j0 = t * PKT;
+            float mt = -INFINITY;
+            if (j0 + PKT <= klen) {  // wave-uniform: nothing to mask in this tile
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, st[s][r]), st[s][r + 1]);
+            } else {
+                const int jl = jmax - j0 - 8 * lh;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sv = s * 32 + 16 * (r >> 3) + (r & 7) <= jl ? st[s][r] : -INFINITY;
+                        st[s][r] = sv;
+                        mt = fmaxf(mt, sv);
+                    }
+            }
+            mt = fmaxf(mt, half_swap(mt));  // the other half-wave holds the other keys of the same query
+            // Running maximum with a slack of THR (in units of log2): the shift only moves when the tile maximum exceeds it by more than THR,
+            // so O is rescaled rarely; P' = 2048 p then stays below 2048 * 2^THR (fp16 range: THR <= 4).  THR = 0 is the textbook update.
+            const float m_new = mt * sc > mc_run + PL_THR ? fmaxf(m_run, mt) : m_run;
+            const float mc_new = m_new > -INFINITY ? m_new * sc : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(mc_run - mc_new);
+            // P is produced SCALED by 2048 (the +11 in the exponent; the scale cancels in O / l): P' = h' + l'' with h' = RNE16(P') and the
+            // residual l'' = P' - h' taken UNSCALED (|l''| <= 2^-11 P' needs no further scaling to stay a normal fp16 for every P that matters),
+            // so the split is one cvt_pk per pair and one mixed fma per element, no multiplies; in the second product l'' V_h then has the
+            // scale of h' V_h and shares its accumulator, only h' V_l goes to the 1/2048 accumulator.
+            const float shift = 11.0f - mc_new;
+            float ls = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    u32x4 h4, l4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s][8 * u + 2 * e], sc, shift));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[s][8 * u + 2 * e + 1], sc, shift));
+                        ls += p0 + p1;
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+                        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{p0, p1}, h2t));
+                        unsigned l2;
+                        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h2), "v"(p0));
+                        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(p1));
+                        h4[e] = h2;
+                        l4[e] = l2;
+                    }
+                    ph[2 * s + u] = h4;
+                    pl[2 * s + u] = l4;
+                }
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+            mc_run = m_new > -INFINITY ? mc_new : -INFINITY;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    ot[d] *= alpha;
+                    otc[d] *= alpha;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's stagger barrier
+
+#pragma unroll
+    for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
+    const float l_tot = l_run + half_swap(l_run);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Tq) {
+        _Float16* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h0, l0, h1, l1;
+                cbx_split2(ot[d][g * 4 + 0] * inv, ot[d][g * 4 + 1] * inv, h0, l0);
+                cbx_split2(ot[d][g * 4 + 2] * inv, ot[d][g * 4 + 3] * inv, h1, l1);
+                *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * lh) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(op + a.o_lo + d * 32 + 8 * g + 4 * lh) = make_uint2(l0, l1);
+            }
+    }
+}
+
 }  // namespace
+
+static int g_attn_pl_version = getenv("CBX_ATTN_PL_VERSION") ? atoi(getenv("CBX_ATTN_PL_VERSION")) : 2;
+extern "C" int cbx_set_attn_planes_version(int v) {
+    g_attn_pl_version = v;
+    return 0;
+}
 
 extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
                                      int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
@@ -274,6 +513,24 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
 #ifdef CBX_DIAG
     a.diag = getenv("CBX_ATTN_DIAG") ? atoi(getenv("CBX_ATTN_DIAG")) : 0;
 #endif
+    // version 2 (ping-pong, 256 queries per workgroup) serves the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
+    // (or CBX_ATTN_PL_VERSION) keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
+    const int ver = g_attn_pl_version;
+    const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;
+    if (ver >= 2 && v2ok) {
+        constexpr int lds = 3 * PL_STAGE;
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e1 != hipSuccess || e2 != hipSuccess) return cbx_set_error((int)(e1 != hipSuccess ? e1 : e2), "flash_attn_planes: cannot reserve %d B of LDS", lds);
+            configured = true;
+        }
+        dim3 grid2((Tq + 255) / 256, n_heads, nz1);
+        if (ver == 3) hipLaunchKernelGGL(flash_attn_pl2_kernel<true>, grid2, dim3(512), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(flash_attn_pl2_kernel<false>, grid2, dim3(512), lds, (hipStream_t)stream, a);
+        return cbx_check_launch("flash_attn_planes");
+    }
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     hipLaunchKernelGGL(flash_attn_pl_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return cbx_check_launch("flash_attn_planes");

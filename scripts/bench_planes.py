@@ -114,10 +114,15 @@ with ops.gemm_precision(16):
 qkP, attP = ops.Planes(M, 1024, dev), ops.Planes(M, 512, dev)
 ops.split_planes(qkv[:, :1024], qkP)
 ops.split_planes(torch.randn(ROWS * 512, Tp, device=dev), vtP)
-us_new = timeit(lambda: ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=ROWS, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125,
-                                              key_lens=lens))
 fl = 4.0 * ROWS * 8 * T * T * 64
-print(f"flash attention: split {us_old:6.1f} us {fl / us_old / 1e6:6.1f} TF | planes {us_new:6.1f} us {fl / us_new / 1e6:6.1f} TF fp32-equivalent", flush=True)
+line = f"flash attention: split {us_old:6.1f} us {fl / us_old / 1e6:6.1f} TF |"
+for ver in (1, 2, 3):
+    ops.lib.cbx_set_attn_planes_version(ver)
+    us_new = timeit(lambda: ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=ROWS, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125,
+                                                  key_lens=lens))
+    line += f" planes v{ver} {us_new:6.1f} us {fl / us_new / 1e6:6.1f} TF fp32-equivalent |"
+ops.lib.cbx_set_attn_planes_version(2)
+print(line, flush=True)
 
 # LayerNorm
 x = torch.randn(M, 256, device=dev)

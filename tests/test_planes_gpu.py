@@ -132,8 +132,16 @@ def test_layernorm_planes(dev):
     assert (out.float() - plain).abs().max() <= 2.0 ** -21 * plain.abs().max(), "planes = split of the fp32 LayerNorm kernel's result"
 
 
-@pytest.mark.parametrize("Z,T,lens", [(2, 1000, None), (3, 517, [517, 130, 64]), (1, 64, None), (2, 200, [1, 199])])
-def test_flash_attn_planes(dev, Z, T, lens):
+@pytest.fixture(params=[2, 1, 3])
+def attn_version(request):
+    from chatterbox_amd import ops
+    ops.lib.cbx_set_attn_planes_version(request.param)
+    yield request.param
+    ops.lib.cbx_set_attn_planes_version(2)
+
+
+@pytest.mark.parametrize("Z,T,lens", [(2, 1000, None), (3, 517, [517, 130, 64]), (1, 64, None), (2, 200, [1, 199]), (1, 300, [0])])
+def test_flash_attn_planes(dev, attn_version, Z, T, lens):
     """q, k as column ranges of one planes tensor, V^T from the swapped layout; ragged key lengths; vs fp64 softmax attention on the
     values the planes hold."""
     from chatterbox_amd import ops
@@ -158,7 +166,7 @@ def test_flash_attn_planes(dev, Z, T, lens):
     _close(out.float(), ref, 2e-5, f"flash attention planes Z={Z} T={T} lens={lens}")
 
 
-def test_flash_attn_planes_forced_rescale(dev):
+def test_flash_attn_planes_forced_rescale(dev, attn_version):
     """A key whose score jumps far above everything seen before, placed in a late tile: the running-maximum rescale branch must fire
     and scale O, l exactly once (guide rule 26: the branch is data dependent and rare on random inputs)."""
     from chatterbox_amd import ops

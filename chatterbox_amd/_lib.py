@@ -100,6 +100,7 @@ _SIGS = {
     "cbx_gemm_ln_fusable": ([c_long, c_int, c_long], c_int),
     "cbx_gemm_planes": ([ctypes.POINTER(GemmPlParams), c_f], c_int),
     "cbx_set_planes_tile": ([c_int], c_int),
+    "cbx_set_planes_persist": ([c_int], c_int),
     "cbx_split_planes_f32": ([c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_f], c_int),
     "cbx_layernorm_planes_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_float, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_split_po": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 9 + [c_float, c_int, c_f], c_int),

@@ -314,10 +314,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
     }
     const int tstep = grp == 0 ? (int)(PKT * a.k_st * 2) : PKT * 2;  // bytes per tile along the key axis
     const int lds_w = ((grp ? 2 : 0) + plane) * PL_TILE + rbase * 128;  // this wave's first destination inside a stage
-    auto issue = [&](int t) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3
-        unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w;
+    auto issue = [&](int t) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3.  The whole address is in the VECTOR offset: the
+        unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w;  // descriptor's bounds check ignores a scalar offset
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i], t * tstep, 0, 0);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i] + t * tstep, 0, 0, 0);
     };
     if (nt > 0) issue(0);
     if (grp == 0 && nt > 1) issue(1);

@@ -10,8 +10,8 @@
 //     * the LDS image lane-linear as the DMA writes it, bank conflicts removed by an XOR swizzle applied to the SOURCE address and to
 //       the ds_read_b128 address (cdna_hip_programming.md rule 21): chunk c of row r sits at slot r*CH + (c ^ f(r)),
 //       f(r) = (r / (16 / CH)) & (CH - 1), CH = 16-byte chunks per row and plane (BK / 8);
-//     * masked rows (M tail, causal-conv left padding, rows past a ragged length) fetched from a 16-byte zero page instead of being
-//       predicated: every lane of every load instruction writes its LDS slot, so no tile is ever partially stale.
+//     * masked rows (causal-conv left padding, rows past a ragged length) come back as zeros from the buffer descriptor's bounds check
+//       (buffer_load ... lds): every lane of every load instruction writes its LDS slot, no address arithmetic or predication in the loop.
 //   Same implicit-GEMM address map as gemm_split.hip for Linear and Conv1d (taps, dilation, stride, left pad, per-batch lengths);
 //   no upsampling, W in [N][K] layout, K % BK == 0, Cin % BK == 0.
 //
@@ -25,22 +25,28 @@ namespace {
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __attribute__((aligned(16))) const unsigned cbx_zero_page[4] = {0u, 0u, 0u, 0u};
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// epilogue activations of the CFM / encoder GEMMs (a compile-time-small switch: the generic cbx_act() unrolled 16 x TM x TN times is
-// most of a kernel's code)
-__device__ __forceinline__ float pl_act(float v, int act, float slope) {
-    if (act == CBX_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-    if (act == CBX_ACT_SILU) return v / (1.0f + __expf(-v));
-    if (act == CBX_ACT_LRELU) return v > 0.0f ? v : v * slope;
-    return v;
+// waves per SIMD the register allocation must leave room for: as many workgroups per CU as the LDS admits (two co-resident workgroups
+// overlap one's epilogue with the other's K loop), at most 4 waves per SIMD (128 VGPRs)
+template <int BM, int BN, int BK, int NS, int NWV>
+struct PlOcc {
+    static constexpr int occ = 160 * 1024 / (NS * 2 * (BM + BN) * (BK / 8) * 16);
+    static constexpr int w = occ * NWV / 4;
+    static constexpr int waves_per_simd = w > 4 ? 4 : w < 1 ? 1 : w;
+};
+
+// One 1 KiB global -> LDS DMA (16 B per lane, LDS destination lane-linear from `lds`).  A separate __device__ function on purpose: with the
+// builtin called from a lambda of the kernel template, hipcc (ROCm 7.2) silently drops the kernel's HOST stub (undefined symbol at dlopen).
+__device__ __forceinline__ void pl_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT>
+// (the parentheses keep the template commas away from the variadic __launch_bounds__ macro)
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N>::waves_per_simd))
+void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int NWV = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -60,72 +66,83 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
-    const int z = blockIdx.z;
-    const int tile = cbx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int n0 = (tile % gridDim.x) * BN, m0 = (tile / gridDim.x) * BM;
-
-    const _Float16* Ab = reinterpret_cast<const _Float16*>(p.A) + (long)z * p.a_s1;
-    const _Float16* Wb = reinterpret_cast<const _Float16*>(p.W) + (long)z * p.w_s1;
-    const int lim = p.lens ? min(p.Tin, p.lens[z]) : p.Tin;
+    // ---- persistent tile loop: workgroup b owns the virtual tiles b, b + gridDim.x, ...; the LOADER side (DMA issue) runs NS - 1 K tiles ahead
+    //      of the CONSUMER side (MFMA + epilogue) straight across tile boundaries, so the first K tiles of the next output tile are in flight
+    //      while this one's epilogue computes and stores, and no tile but a workgroup's first pays the load latency.  With gridDim.x = number
+    //      of tiles this is the plain one-tile-per-workgroup kernel.
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int tiles_z = ntn * ntm, total = tiles_z * p.nz1;
     const int nk = p.K / BK;
+    auto tile_of = [&](int vt, int& z, int& m0, int& n0) {
+        z = vt / tiles_z;
+        const int t = cbx_xcd_remap(vt - z * tiles_z, tiles_z);  // tiles that share an A panel run on one XCD (gridDim.x % 8 == 0 keeps vt % 8 = b % 8)
+        n0 = (t % ntn) * BN;
+        m0 = (t / ntn) * BM;
+    };
 
-    // ---- DMA descriptors: load i of this wave fills slots [L*64, L*64 + 64) of a stage, L = wid * LPW + i; the lane's slot fixes
-    //      (plane, row, chunk) for the whole K walk
-    const _Float16* ptr[LPW];
-    int trow[LPW];        // A: input row of the current tap (validity 0 <= trow < lim); B: 0
-    int tlim[LPW];        // A: lim (or 0 for rows >= M); B: 1 / 0
-    int tstep[LPW];       // A: dil; B: 0
-    long wstep[LPW];      // pointer step at a tap wrap (halves): A: dil * lda - Cin; B: 0
+    // ---- DMA descriptors.  Load i of this wave fills slots [L*64, L*64 + 64) of a stage, L = wid * LPW + i; the lane's slot fixes (plane, row,
+    //      chunk) for the whole K walk of a tile, so a load's address is ONE 32-bit byte offset per lane: a per-lane constant (vbase) plus
+    //      wave-uniform tile and K / tap terms.  Validity is the buffer descriptor's business (the bounds check looks at this vector offset;
+    //      a scalar offset would bypass it): rows >= lim lie behind num_records, rows < 0 (causal left padding) wrap to offsets >= 2^31 --
+    //      both come back as zeros -- and rows of the M / N tail read whatever is there (their results are never stored).
+    int vbase[LPW], voff[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         const int s = (wid * LPW + i) * 64 + lane;
         const int q = s / PLANE_SLOTS, rs = s % PLANE_SLOTS;
         const int row = rs / CH, pc = rs % CH;
         const int c = pc ^ ((row / RPS) & (CH - 1));
-        if (row < BM) {
-            const int m = m0 + row;
-            const int t0 = m * p.stride - p.pad_left;
-            trow[i] = t0;
-            tlim[i] = m < p.M ? lim : 0;
-            tstep[i] = p.dil;
-            wstep[i] = (long)p.dil * p.lda - p.Cin;
-            ptr[i] = Ab + (long)t0 * p.lda + (q ? p.a_lo : 0) + c * 8;
-        } else {
-            const int n = n0 + row - BM;
-            trow[i] = 0;
-            tlim[i] = n < p.N ? 1 : 0;
-            tstep[i] = 0;
-            wstep[i] = 0;
-            ptr[i] = Wb + (long)(n < p.N ? n : 0) * p.ldw + (q ? p.w_lo : 0) + c * 8;
-        }
+        vbase[i] = row < BM ? (row * p.stride * (int)p.lda + (q ? (int)p.a_lo : 0) + c * 8) * 2
+                            : ((row - BM) * (int)p.ldw + (q ? (int)p.w_lo : 0) + c * 8) * 2;
     }
-    int ld_c0 = 0;
-    const _Float16* zp = reinterpret_cast<const _Float16*>(cbx_zero_page);
-    auto issue = [&](int stage) {
+    __amdgpu_buffer_rsrc_t a_rs, w_rs;
+    const int a_wstep2 = (int)(((long)p.dil * p.lda - p.Cin) * 2);  // extra byte step of the A offset at a tap wrap
+    auto load_desc = [&](int vt) {
+        int z, m0, n0;
+        tile_of(vt, z, m0, n0);
+        const int lim = p.lens ? min(p.Tin, p.lens[z]) : p.Tin;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.A) + (long)z * p.a_s1), 0,
+                                                 lim > 0 ? (int)((long)lim * p.lda * 2) : 0, 0x00020000);
+        w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.W) + (long)z * p.w_s1), 0,
+                                                 (int)((long)p.N * p.ldw * 2), 0x00020000);
+        const int tA = (m0 * p.stride - p.pad_left) * (int)p.lda * 2, tW = n0 * (int)p.ldw * 2;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const bool ok = (unsigned)trow[i] < (unsigned)tlim[i];
-            const _Float16* src = ok ? ptr[i] : zp;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + stage * STAGE_BYTES + (wid * LPW + i) * 1024), 16, 0, 0);
+            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;  // wave-uniform: a DMA instruction never straddles the A / B boundary
+            voff[i] = vbase[i] + (isA ? tA : tW);
+        }
+    };
+    int l_tile = blockIdx.x, l_kt = 0, l_g = 0;  // loader position: tile, K tile inside it, K tiles issued so far (ring position)
+    int ld_c0 = 0;                               // channel block inside the current conv tap
+    if (l_tile < total) load_desc(l_tile);
+    auto issue = [&]() {  // the loader's next K tile into ring stage l_g % NS
+        unsigned char* dst = smem + (l_g % NS) * STAGE_BYTES + wid * LPW * 1024;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;
+            if (isA) pl_dma16(a_rs, dst + i * 1024, voff[i]);
+            else pl_dma16(w_rs, dst + i * 1024, voff[i]);
+        }
+        ++l_g;
+        if (++l_kt == nk) {  // next output tile of this workgroup
+            l_kt = 0;
+            ld_c0 = 0;
+            l_tile += gridDim.x;
+            if (l_tile < total) load_desc(l_tile);
+            return;
         }
         ld_c0 += BK;
-        const bool wrap = ld_c0 >= p.Cin;  // wave-uniform: next tile starts the next conv tap
+        const bool wrap = ld_c0 >= p.Cin;  // next K tile starts the next conv tap
         ld_c0 = wrap ? 0 : ld_c0;
+        const int stepA = BK * 2 + (wrap ? a_wstep2 : 0);
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            ptr[i] += BK + (wrap ? wstep[i] : 0L);
-            trow[i] += wrap ? tstep[i] : 0;
+            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;
+            voff[i] += isA ? stepA : BK * 2;
         }
     };
 
     f32x16 acc[TM][TN], accc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
-
     const int lr = lane & 31, lh = lane >> 5;
     const int swz = (lr / RPS) & (CH - 1);  // rows of a fragment are base + lr with base % 32 == 0: f(row) = f(lr)
     const int a_off = (wm * WM + lr) * CH * 16, b_off = (BM + wn * WN + lr) * CH * 16;
@@ -156,9 +173,11 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
         }
     };
 
-    // ---- main loop: NS LDS stages, one barrier per K tile.  Before the barrier every wave waits until ITS DMAs of tile kt have landed
-    //      (counted: the NS - 2 younger tiles stay in flight); after it tile kt is complete for everybody and nobody reads the stage
-    //      that tile kt + NS - 1 is about to overwrite (it held tile kt - 1).
+    // ---- main loop: NS LDS stages, one barrier per K tile.  Before the barrier every wave waits until ITS DMAs of the K tile about to be
+    //      consumed have landed -- a COUNTED wait: vector-memory operations complete in issue order, so "at most n outstanding" with n = the
+    //      number of operations issued after those DMAs (younger K tiles, and the previous tile's epilogue loads / stores) is exact and leaves
+    //      everything younger in flight; after the barrier the K tile is complete for everybody and nobody reads the stage the next issue
+    //      overwrites (it held the K tile consumed one iteration ago).
     static_assert(NS == 2 || NS == 3, "two or three LDS stages");
 #ifdef CBX_DIAG  // scripts/diag_planes.sh: parts of the kernel switched off (1 no DMA after the prologue, 2 no ds_read / MFMA, 4 no epilogue stores)
     const int dg = p.reserved0;
@@ -166,16 +185,34 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
 #else
 #define DG(bit) 0
 #endif
+    constexpr int EPI_OPS = TM * TN * 16;  // vector-memory operations every epilogue issues at least (one output kind)
+    constexpr int W_EPI0 = (NS - 2) * LPW + EPI_OPS > 63 ? 63 : (NS - 2) * LPW + EPI_OPS;  // first K tile after an epilogue
+    constexpr int W_EPI1 = LPW + EPI_OPS > 63 ? 63 : LPW + EPI_OPS;                          // NS = 3: second K tile after an epilogue
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue(s);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (NS == 3 && kt + 1 < nk && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk && !DG(1)) issue((kt + NS - 1) % NS);
-        if (!DG(2)) compute(kt % NS);
-    }
+        if (l_tile < total) issue();
+    int c_g = 0;  // consumer ring position
+    for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
+        const bool after_epi = c_tile != (int)blockIdx.x;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = l_g - c_g - 1;  // K tiles issued after the one consumed now (0 .. NS - 2)
+            if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0) : "memory");
+            else if (NS == 3 && after_epi && kt == 1 && younger == 1 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1) : "memory");
+            else if (NS == 3 && younger == 1 && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (l_tile < total && !DG(1)) issue();
+            if (!DG(2)) compute(c_g % NS);
+            ++c_g;
+        }
+        int z, m0, n0;
+        tile_of(c_tile, z, m0, n0);
 
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     //      Lean by construction: every store / residual load is ONE buffer instruction (32-bit lane offset + a scalar row offset); rows >= M fall
@@ -202,61 +239,62 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_pl_kernel(const c
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * WM + i * 32 + 4 * lh;  // row of register 0
-            float v[16], res[16];
-            if (hasR) {
-                const int ro = nok ? mb * ldr4 + n * 4 : OOB;
+            const int ro = nok ? mb * ldr4 + n * 4 : OOB, co = nok ? mb * ldc4 + n * 4 : OOB;
+            const int ne = n & ~1;  // plane output: first column of the lane pair
+            const int po = (ne < p.N ? mb * ldp2 + ne * 2 : OOB) + (odd ? ldp2 : 0);
+            const int plo2 = (int)p.p_lo * 2;
+            // eight accumulator registers at a time (rows 8 h + {0..3} + 4 lh, h = 0..3 -> two passes of two row quads): keeps the live set
+            // inside the 128-VGPR budget that lets two workgroups share a CU
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, ro, ((r & 3) + 8 * (r >> 2)) * ldr4, 0));
-            }
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float v[8], res[8];
+                if (hasR) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(accc[i][j][r], 1.0f / CBX_F16_LO_SCALE, acc[i][j][r]) + bia;
-            if (p.act == CBX_ACT_GELU_ERF) {
+                    for (int r = 0; r < 8; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, ro, (((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * ldr4, 0));
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
-            } else if (p.act != CBX_ACT_NONE) {
+                for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(accc[i][j][r0 + r], 1.0f / CBX_F16_LO_SCALE, acc[i][j][r0 + r]) + bia;
+                if constexpr (ACT == CBX_ACT_GELU_ERF) {  // the activation is a template parameter: one epilogue body per kernel (instruction cache)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = pl_act(v[r], p.act, p.act_slope);
-            }
-            if (hasR) {
+                    for (int r = 0; r < 8; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                } else if constexpr (ACT == CBX_ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += res[r];
-            }
-            if (p.alpha != 1.0f) {
+                    for (int r = 0; r < 8; ++r) v[r] = v[r] / (1.0f + __expf(-v[r]));
+                }
+                if (hasR) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
-            }
-            if (hasC && !DG(4)) {
-                const int co = nok ? mb * ldc4 + n * 4 : OOB;
+                    for (int r = 0; r < 8; ++r) v[r] += res[r];
+                }
+                if (hasC && !DG(4)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), c_rs, co, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
-            }
-            if (hasP) {
-                // The lane pair (even, odd column) owns columns n, n + 1 of every row.  Of each register pair (rows m, m + 1) the even lane
-                // converts row m and the odd lane row m + 1: one exchange gives each lane both columns of its row, which it splits into the h
-                // word and the l word (two 4-byte stores per lane and register pair instead of a conversion per element).
-                const int ne = n & ~1;  // first column of the pair
-                const int po = (ne < p.N ? mb * ldp2 + ne * 2 : OOB) + (odd ? ldp2 : 0);
-                const int plo2 = (int)p.p_lo * 2;
+                    for (int r = 0; r < 8; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), c_rs, co, (((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * ldc4, 0);
+                }
+                if (hasP) {
+                    // The lane pair (even, odd column) owns columns n, n + 1 of every row.  Of each register pair (rows m, m + 1) the even lane
+                    // converts row m and the odd lane row m + 1: one exchange gives each lane both columns of its row, which it splits into the h
+                    // word and the l word (two 4-byte stores per lane and register pair instead of a conversion per element).
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float give = odd ? v[r] : v[r + 1];
-                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-                    const float c0 = odd ? got : v[r], c1 = odd ? v[r + 1] : got;  // columns ne, ne + 1 of this lane's row
-                    unsigned h2, l2;
-                    cbx_split2(c0, c1, h2, l2);
-                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(c0), "v"(c1));
-                    if (!DG(4)) {
-                        const int so = ((r & 3) + 8 * (r >> 2)) * ldp2;
-                        __builtin_amdgcn_raw_buffer_store_b32(h2, p_rs, po, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(l2, p_rs, po + plo2, so, 0);
+                    for (int r = 0; r < 8; r += 2) {
+                        const float give = odd ? v[r] : v[r + 1];
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                        const float c0 = odd ? got : v[r], c1 = odd ? v[r + 1] : got;  // columns ne, ne + 1 of this lane's row
+                        unsigned h2, l2;
+                        cbx_split2(c0, c1, h2, l2);
+                        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(c0), "v"(c1));
+                        if (!DG(4)) {
+                            const int so = (((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * ldp2;
+                            __builtin_amdgcn_raw_buffer_store_b32(h2, p_rs, po, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(l2, p_rs, po + plo2, so, 0);
+                        }
                     }
                 }
             }
         }
     }
-    if (hasP && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+        if (hasP && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+    }  // tile loop
 }
 
 // x (rows, C) fp32 -> planes.  One float4 per thread; two 8-byte stores.
@@ -279,20 +317,36 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2>
-int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
+int g_pl_persist = getenv("CBX_PL_PERSIST") ? atoi(getenv("CBX_PL_PERSIST")) : 1;
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT>
+int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS>;
-    static bool configured = false;
-    if (!configured) {
+    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT>;
+    static int resident = 0;  // workgroups the chip holds at once (advisory: nothing in the kernel depends on co-residency)
+    if (!resident) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return cbx_set_error((int)e, "gemm_planes: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        configured = true;
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WARPS_M * WARPS_N * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        resident = per_cu * prop.multiProcessorCount / 8 * 8;  // a multiple of the XCD count keeps the XCD affinity of the tile order
+        if (resident < 8) resident = 8;
     }
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1);
-    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());
+    const long total = (long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.nz1;
+    const long cap = g_pl_persist > 1 ? g_pl_persist : resident;  // > 1: an explicit workgroup count (tests force multi-tile walks on small shapes)
+    const unsigned grid = (unsigned)(g_pl_persist && total > cap ? cap : total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());
     return cbx_check_launch("gemm_planes");
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2>
+int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
+    if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF>(p, st);
+    if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU>(p, st);
+    return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_NONE>(p, st);
 }
 
 }  // namespace
@@ -300,6 +354,12 @@ int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
 static int g_pl_tile = getenv("CBX_PL_TILE") ? atoi(getenv("CBX_PL_TILE")) : 0;
 extern "C" int cbx_set_planes_tile(int t) {
     g_pl_tile = t;
+    return 0;
+}
+// tuning knob: 1 (default) = persistent workgroups (grid = what the chip holds, each workgroup walks several tiles with its DMA running
+// across tile boundaries); 0 = one tile per workgroup; n > 1 = exactly n workgroups
+extern "C" int cbx_set_planes_persist(int on) {
+    g_pl_persist = on;
     return 0;
 }
 
@@ -311,7 +371,8 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     if (p.nz1 < 1) p.nz1 = 1;
     if (p.Cin <= 0) p.Cin = p.K / p.taps;
     if (p.Tin <= 0) p.Tin = p.M;
-    if (p.alpha == 0.f) p.alpha = 1.f;
+    CBX_REQUIRE(p.alpha == 0.f || p.alpha == 1.f, "gemm_planes: alpha is not supported (must be 0 or 1)");
+    CBX_REQUIRE(p.act == CBX_ACT_NONE || p.act == CBX_ACT_GELU_ERF || p.act == CBX_ACT_SILU, "gemm_planes: activation %d is not served (none, GELU (erf), SiLU)", p.act);
     CBX_REQUIRE(p.A && p.W && (p.C || p.P), "gemm_planes: null operand");
     CBX_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.K == p.taps * p.Cin, "gemm_planes: bad shape M=%d N=%d K=%d taps=%d Cin=%d", p.M, p.N, p.K, p.taps, p.Cin);
     CBX_REQUIRE(p.Cin % 32 == 0, "gemm_planes: Cin=%d must be a multiple of 32 (a K tile must not straddle two conv taps)", p.Cin);
@@ -321,6 +382,11 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE((!p.C || ((long)p.M * p.ldc + p.N) * 4 < 0x7fffffffL) && (!p.R || ((long)p.M * p.ldr + p.N) * 4 < 0x7fffffffL) &&
                     (!p.P || ((long)p.M * p.ldp + p.p_lo + p.N) * 2 < 0x7fffffffL),
                 "gemm_planes: one batch of an output / residual must span less than 2 GiB (32-bit buffer offsets)");
+    CBX_REQUIRE(p.lda >= p.a_lo + p.Cin && p.a_lo >= 0 && p.ldw >= p.w_lo + p.K && p.w_lo >= 0,
+                "gemm_planes: operand rows must hold both planes ([h | l] per row: lda >= a_lo + Cin, ldw >= w_lo + K)");
+    CBX_REQUIRE(((long)p.Tin + p.taps * p.dil + 1) * p.lda * 2 < 0x7fffffffL && (long)(p.N + 256) * p.ldw * 2 < 0x7fffffffL &&
+                    (long)(p.pad_left + 1) * p.lda * 2 < 0x3fffffffL,
+                "gemm_planes: one batch of an operand must span less than 2 GiB (32-bit buffer offsets)");
     CBX_REQUIRE((!p.C || p.ldc >= p.N) && (!p.R || p.ldr >= p.N) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + p.N)),
                 "gemm_planes: rows must not overlap (ldc, ldr >= N; plane output rows hold [h | l]: ldp >= p_lo + N)");
     hipStream_t st = (hipStream_t)stream;

@@ -96,8 +96,8 @@ int cbx_gemm_ln_fusable(long M, int K, long lda);
  * Constant weights are split once at load, activations are WRITTEN in plane format by their producer (the epilogues below), and the
  * consumer's K loop is a plain fp16 MFMA loop fed by direct global -> LDS loads.
  *
- * cbx_gemm_planes: C[z][m][n] and / or P[z][m][n] = alpha * ( act( sum_{tap,c} A[z][m*stride + tap*dil - pad_left][c] * W[n][tap*Cin + c]
- *                                                                  + bias[n] ) + R[z][m][n] )
+ * cbx_gemm_planes: C[z][m][n] and / or P[z][m][n] = act( sum_{tap,c} A[z][m*stride + tap*dil - pad_left][c] * W[n][tap*Cin + c] + bias[n] )
+ *                                                      + R[z][m][n]      (act: none, GELU (erf) or SiLU; act_param / alpha reserved: NULL / 0 or 1)
  * A, W planes (W in [N][K] layout); C fp32 and / or P planes (either may be NULL); R fp32 residual.  Rows outside [0, min(Tin, lens[z]))
  * read as zero.  K % 32 == 0, Cin % 32 == 0.  Replaces the F.linear / F.conv1d calls of the CFM estimator: CausalConv1d / ResnetBlock1D
  * (models/s3gen/decoder.py:49-98, matcha/decoder.py:56-61), BasicTransformerBlock projections and FeedForward (matcha/transformer.py:243-316),
@@ -123,6 +123,8 @@ typedef struct cbx_gemm_pl_t {
 int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
 /* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */
 int cbx_set_planes_tile(int t);
+/* tuning knob: 1 (default) = persistent workgroups walking several output tiles each (DMA runs across tile boundaries), 0 = one tile per workgroup */
+int cbx_set_planes_persist(int on);
 /* x (rows, C) fp32 -> planes (weights at load; estimator inputs).  C, ldx, ldp, p_lo multiples of 4. */
 int cbx_split_planes_f32(const float* x, void* planes, long rows, int C, long ldx, long ldp, long p_lo, void* stream);
 /* cbx_layernorm_f32 (C = 256, LayerNorm form) whose result is written in plane format: nn.LayerNorm (+ Mish + time bias) feeding a conv /

@@ -78,6 +78,10 @@ for name, N, K, taps, epi in shapes:
     with ops.gemm_precision(16):
         us = timeit(old)
     line = f"{name:11s} N={N:5d} K={K:5d} | split {us:6.1f} us {fl / us / 1e6:6.1f} TF |"
+    ops.lib.cbx_set_planes_tile(0)
+    ops.lib.cbx_set_planes_persist(0)
+    line += f" one-tile-per-WG t0: {timeit(new):5.1f} | persistent"
+    ops.lib.cbx_set_planes_persist(1)
     for t in tiles:
         ops.lib.cbx_set_planes_tile(t)
         try:

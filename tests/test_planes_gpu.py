@@ -54,11 +54,14 @@ def test_split_planes_roundtrip_and_range_flag(dev):
 
 
 @pytest.mark.parametrize("tile", TILES)
-def test_gemm_planes_linear_tiles(dev, tile):
-    """Every tile shape of the menu: ragged M and N, bias + GELU + residual, fp32 and plane outputs."""
+@pytest.mark.parametrize("persist", [1, 8, 0])
+def test_gemm_planes_linear_tiles(dev, tile, persist):
+    """Every tile shape of the menu: ragged M and N, bias + GELU + residual, fp32 and plane outputs; persist = 8: eight persistent
+    workgroups walk all tiles (the DMA stream crosses tile boundaries, counted waits behind an epilogue), 0: one tile per workgroup."""
     from chatterbox_amd import ops
     try:
         ops.lib.cbx_set_planes_tile(tile)
+        ops.lib.cbx_set_planes_persist(persist)
         for (M, N, K) in [(1000, 1536, 256), (333, 80, 256), (129, 258, 512), (2048, 256, 1024)]:
             x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
             xP, wP = ops.split_planes(x.to(dev)), ops.split_planes(w.to(dev))
@@ -74,15 +77,18 @@ def test_gemm_planes_linear_tiles(dev, tile):
                 assert (outP.float() - out).abs().max() <= 2.0 ** -21 * out.abs().max(), "plane output = split of the fp32 output"
     finally:
         ops.lib.cbx_set_planes_tile(0)
+        ops.lib.cbx_set_planes_persist(1)
 
 
 @pytest.mark.parametrize("tile", [0, 2, 3, 7, 11, 12, 15])
-def test_gemm_planes_conv_and_swapped_product(dev, tile):
+@pytest.mark.parametrize("persist", [8, 0])
+def test_gemm_planes_conv_and_swapped_product(dev, tile, persist):
     """Causal Conv1d as implicit GEMM on planes (3 taps, left pad, batches, ragged lens), a column-range A operand, and the swapped
     (V^T) product with a per-batch W operand."""
     from chatterbox_amd import ops
     try:
         ops.lib.cbx_set_planes_tile(tile)
+        ops.lib.cbx_set_planes_persist(persist)
         B, T, cin, N = 3, 517, 320, 256
         x, w, b = _r((B, T, cin), 1), _r((N, cin, 3), 2, 1 / math.sqrt(3 * cin)), _r((N,), 3)
         ref = F.conv1d(F.pad(_planes_exact(x).transpose(1, 2), (2, 0)), _planes_exact(w), b.double()).transpose(1, 2)
@@ -115,6 +121,7 @@ def test_gemm_planes_conv_and_swapped_product(dev, tile):
         assert float(got[:, :, n:].abs().max()) == 0.0, "pad columns stay untouched"
     finally:
         ops.lib.cbx_set_planes_tile(0)
+        ops.lib.cbx_set_planes_persist(1)
 
 
 def test_layernorm_planes(dev):

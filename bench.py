@@ -146,15 +146,17 @@ def cpu_baseline(t3_sd, s3_sd, args, n_layers):
     kind = "reference" if ref_import.available() else "port"
     with torch.inference_mode():
         if kind == "reference":
-            t0, t1, t2 = _cpu_reference(ref_import, O, t3_sd, s3_sd, n_layers, tt, u, ref, z, noise, phase, n)
+            t0, t1, t2, toks, mel, wav = _cpu_reference(ref_import, O, t3_sd, s3_sd, n_layers, tt, u, ref, z, noise, phase, n)
         else:
             t0 = time.perf_counter()
             toks = O.t3_inference(t3_sd, n_layers, synth.t3_cond(), torch.stack([tt, tt]), n, u, ban_eos=True)
             t1 = time.perf_counter()
-            O.s3gen_inference(s3_sd, toks.clamp(max=6560)[None], torch.tensor([n]), ref, z, phase, noise, 10)
+            wav, mel = O.s3gen_inference(s3_sd, toks.clamp(max=6560)[None], torch.tensor([n]), ref, z, phase, noise, 10)
             t2 = time.perf_counter()
+            toks, mel, wav = toks.view(-1), mel[0].t(), wav[0]
     audio_s = n / 25.0
-    return dict(value=round(audio_s / (t2 - t0), 4), unit="audio-s/wall-s", cores=torch.get_num_threads(), kind=kind,
+    artefacts = dict(tt=tt, u=u, ref=ref, z=z, noise=noise, phase=phase, n=n, tokens=toks.view(-1)[:n].clone(), mel=mel.clone(), wav=wav.view(-1).clone())
+    return artefacts, dict(value=round(audio_s / (t2 - t0), 4), unit="audio-s/wall-s", cores=torch.get_num_threads(), kind=kind,
                 sample=f"1 utterance of the benched workload: {args.text_tokens} text tokens, {n} speech tokens ({audio_s:.1f} s audio), 10 s voice "
                        f"prompt, 10-step CFG CFM; T3 {t1 - t0:.1f} s + S3Gen/HiFT {t2 - t1:.1f} s on {torch.get_num_threads()} threads "
                        f"(the reference cannot batch: B > 1 = serial loop, same xRT)")
@@ -193,11 +195,37 @@ def _cpu_reference(ref_import, O, t3_sd, s3_sd, n_layers, tt, u, ref, z, noise, 
         mel = g.flow_inference(toks[:, :n].clamp(max=6560), ref_dict=dict(ref), n_cfm_timesteps=10, finalize=True)
         torch.randn_like = lambda t, **kw: noise.clone() if t.shape == noise.shape else torch.zeros_like(t)
         U.Uniform.sample = lambda self, sample_shape=torch.Size(): phase.clone()
-        g.hift_inference(mel)
+        out = g.hift_inference(mel)
         t2 = time.perf_counter()
     finally:
         torch.multinomial, torch.randn_like, U.Uniform.sample = o_mn, o_rl, o_us
-    return t0, t1, t2
+    wav = out[0] if isinstance(out, (tuple, list)) else out
+    wav = wav.view(1, -1).clone()
+    wav[:, : len(g.trim_fade)] *= g.trim_fade  # S3Token2Wav.inference applies it after hift_inference (s3gen.py:360); outside the timed span
+    return t0, t1, t2, toks.view(-1)[:n], mel[0].t(), wav.view(-1)
+
+
+def gpu_parity(eng, art, kind):
+    """BASELINE.md section 4, "parity in the same run": the GPU synthesises the very utterance the CPU baseline just produced (same text,
+    voice, uniforms, CFM noise z, vocoder phase / noise) and the line carries how far the two are apart: sampled tokens identical, mel L1
+    (mean |d| over the generated frames; fp32 tolerance 5e-6 at T = 1000, tests/test_baseline_shapes_gpu.py) and waveform RMSE."""
+    from chatterbox_amd import synth
+    dev, n = eng.dev, art["n"]
+    samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+    toks = eng.t3.generate(synth.t3_cond(), [art["tt"]], max_new_tokens=n, uniforms=art["u"][None].to(dev), ban_eos=True, **samp)[0].cpu().view(-1)[:n]
+    equal = bool(torch.equal(toks, art["tokens"].cpu()))
+    # flow + vocoder on the CPU's own tokens, so that a token difference (if any) does not hide the S3Gen comparison
+    st = art["tokens"].clamp(max=6560)
+    wavs, mel = eng.vocode([st], art["ref"], z=art["z"].transpose(1, 2).contiguous().to(dev), phase=art["phase"], noise=art["noise"],
+                           n_cfm_timesteps=10)
+    m_gpu, m_cpu = mel[0].float().cpu(), art["mel"].float()
+    T = min(m_gpu.shape[0], m_cpu.shape[0])
+    w_gpu, w_cpu = wavs[0].float().cpu().view(-1), art["wav"].float().view(-1)
+    L = min(w_gpu.numel(), w_cpu.numel())
+    return dict(vs=kind, tokens_equal=equal, n_tokens=int(n), mel_l1=float((m_gpu[:T] - m_cpu[:T]).abs().mean()),
+                mel_max_abs=float((m_gpu[:T] - m_cpu[:T]).abs().max()), wav_rmse=float((w_gpu[:L] - w_cpu[:L]).pow(2).mean().sqrt()),
+                wav_peak=float(w_cpu[:L].abs().max()), frames=int(T), samples=int(L),
+                note="one utterance of the benched workload, identical injected randomness on both sides; S3Gen compared on the CPU's tokens")
 
 
 def pmc_traffic(kernel_substr, source="flow_only"):
@@ -208,7 +236,7 @@ def pmc_traffic(kernel_substr, source="flow_only"):
     import csv
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r02", "r01")) if os.path.exists(q)), None)
+        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
         if f is None:
             return None, None
         used = os.path.basename(f)[:3]
@@ -236,7 +264,10 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
                           "gemm_f32_kernel", 1),
              "gemm_split": ("gemm_split_kernel (implicit-GEMM linear/conv of S3Gen, %s)" % pname, "gemm_split_kernel", nprod),
              "flash_attn_f32": (("flash_attn_split_kernel (%s)" % pname) if nprod > 1 else "flash_attn_f32_kernel",
-                                "flash_attn_split_kernel" if nprod > 1 else "flash_attn_f32_kernel", nprod)}
+                                "flash_attn_split_kernel" if nprod > 1 else "flash_attn_f32_kernel", nprod),
+             "gemm_planes": ("gemm_pl_kernel (plane-format f16x3 implicit GEMM of the CFM estimator: fp16 planes DMA'd global -> LDS, no operand "
+                             "conversion)", "gemm_pl_kernel", 3),
+             "flash_attn_planes": ("flash_attn_pl2_kernel (plane-format f16x3 attention of the CFM transformer blocks)", "flash_attn_pl", 3)}
     for kind, (kname, sub, npr) in names.items():
         ks = summ.get(kind)
         if not ks or ks["ms"] <= 0:
@@ -448,7 +479,7 @@ def main():
     pipelined = args.pipelined and not args.serial and not turbo
     # HIP-event timing of every GEMM / attention launch costs ~25 ms per step (4000 event records): it is switched on for the
     # LAST timed step only (all steps in --pipelined mode), so the headline number carries 1/K of that overhead
-    timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32"])
+    timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32", "gemm_planes", "flash_attn_planes"])
     if not turbo:
         eng.t3.time_decode, eng.t3.decode_events = True, []
     timed_steps = args.steps if pipelined else 1
@@ -623,7 +654,8 @@ def main():
             out["streaming"] = stream
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)
+            art, out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)
+            out["parity"] = gpu_parity(eng, art, out["cpu_baseline"]["kind"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -88,6 +88,9 @@ class ChatterboxEngine:
             tok[b, : ns[b]] = t
         lens = torch.tensor(ns, dtype=torch.int32)
         same = all(n == Nmax for n in ns)
+        refs = list(gen_ref) if isinstance(gen_ref, (list, tuple)) else [gen_ref] * B  # one voice for all, or one per utterance (s3gen.py:173-229)
+        assert len(refs) == B, f"{len(refs)} voices for {B} utterances"
+        shorts = [int(r["prompt_feat"].reshape(-1, 80).shape[0]) - 2 * int(r["prompt_token"].numel()) for r in refs]
 
         def run():
             t0 = time.perf_counter()
@@ -95,20 +98,20 @@ class ChatterboxEngine:
             if sync:  # per-stage wall times; the pipelined mode never blocks the host between stages
                 torch.cuda.synchronize()
             t1 = time.perf_counter()
-            short = 2 * Nmax - mel.shape[1]  # > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195)
-            mel_lens = None if same else (2 * lens - short).to(self.dev)
+            # short_b > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195); per voice when the batch mixes voices
+            mel_lens = None if same and len(set(shorts)) == 1 else (2 * lens - torch.tensor(shorts, dtype=torch.int32)).to(self.dev)
             wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
             if sync:
                 torch.cuda.synchronize()
             t2 = time.perf_counter()
             self.last_timing.update(flow_s=t1 - t0, hift_s=t2 - t1)
-            return wav, mel, short
+            return wav, mel
 
-        wav, mel, short = _range_checked(self, run, check=sync)
+        wav, mel = _range_checked(self, run, check=sync)
         out = []
         for b, n in enumerate(ns):
             keep = max(1, n - 1) if drop_last_token else n
-            out.append(wav[b, : min(keep * SAMPLES_PER_TOKEN, (2 * n - short) * (SAMPLES_PER_TOKEN // 2))])
+            out.append(wav[b, : min(keep * SAMPLES_PER_TOKEN, (2 * n - shorts[b]) * (SAMPLES_PER_TOKEN // 2))])
         return out, mel
 
     @ops.on_device

@@ -422,34 +422,55 @@ class FlowEngine:
             return self._inference(tokens, token_lens, ref, z, n_steps, hold_back)
 
     def _inference(self, tokens, token_lens, ref, z=None, n_steps=10, hold_back=None):
-        """tokens (B,N) int64 (right-padded), token_lens (B,), ref dict as produced by S3Gen.embed_ref, z optional
-        injected noise (B, 2P+2N, 80) channel-last.  Returns mel (B, 2(P+N) - prompt_feat frames, 80) channel-last: (B, 2N, 80) for a
-        whole-token prompt (frames >= 2*len undefined).  hold_back (B,) ints: chunked synthesis -- the last hold_back[b] frames of
-        utterance b are not generated (`finalize=False` of flow.py:170-171, whose reference branch raises; semantics restated)."""
+        """tokens (B,N) int64 (right-padded), token_lens (B,), ref dict as produced by S3Gen.embed_ref -- or a LIST of B such dicts, one voice
+        per utterance (the reference takes a ref_dict per call, s3gen.py:173-229; a device batch may mix voices: prompt tokens / prompt mels
+        of different lengths are left-aligned per row) --, z optional injected noise (B, 2(P+N)max, 80) channel-last.  Returns mel
+        (B, frames, 80) channel-last, row b valid for 2 N_b - (prompt_feat frames_b - 2 P_b) frames: (B, 2N, 80) for whole-token prompts.
+        hold_back (B,) ints: chunked synthesis -- the last hold_back[b] frames of utterance b are not generated (`finalize=False` of
+        flow.py:170-171, whose reference branch raises; semantics restated)."""
         dev = self.dev
         B, N = tokens.shape
-        ptok = ref["prompt_token"].to(dev).long().view(1, -1)
-        P = ptok.shape[1]
-        tok = torch.cat([ptok.expand(B, -1), tokens.to(dev).long()], 1).contiguous()
-        lens = (token_lens.to(dev).to(torch.int32) + P).contiguous()
+        refs = list(ref) if isinstance(ref, (list, tuple)) else [ref] * B
+        assert len(refs) == B, f"{len(refs)} voices for {B} utterances"
+        one = all(r is refs[0] for r in refs)
+        ptoks = [r["prompt_token"].to(dev).long().view(-1) for r in (refs[:1] if one else refs)]
+        Ps = [int(t.numel()) for t in ptoks] * (B if one else 1)
+        Pmax = max(Ps)
+        if one:
+            tok = torch.cat([ptoks[0].view(1, -1).expand(B, -1), tokens.to(dev).long()], 1).contiguous()
+        else:  # row b = [prompt_b | tokens_b | padding]: the encoder and the CFM mask by length, so what the padding holds is irrelevant
+            tok = torch.zeros(B, Pmax + N, dtype=torch.long, device=dev)
+            for b in range(B):
+                tok[b, : Ps[b]] = ptoks[b]
+                tok[b, Ps[b]: Ps[b] + N] = tokens[b].to(dev).long()
+        lens = (token_lens.to(dev).to(torch.int32) + torch.tensor(Ps, dtype=torch.int32, device=dev)).contiguous()
         mu = self.encode(tok, lens)
         T = mu.shape[1]
-        xv = ref["embedding"].to(dev).float().view(1, -1).contiguous()
+        xv = torch.stack([r["embedding"].to(dev).float().view(-1) for r in (refs[:1] if one else refs)]).contiguous()
         emb = torch.empty_like(xv)  # F.normalize(embedding, dim=1) (flow.py:150): x / ||x|| = rmsnorm(x) / sqrt(C)
         # eps = 1e-24 / C under the root = F.normalize's max(||x||, 1e-12): a zero embedding gives 0, not NaN
         ops.layernorm(xv, torch.ones(xv.shape[1], device=dev), None, emb, 1e-24 / xv.shape[1], rms=True, scale=1.0 / math.sqrt(xv.shape[1]))
-        spk = torch.empty(1, 80, device=dev)
+        spk = torch.empty(xv.shape[0], 80, device=dev)
         ops.linear(emb, self.spk_w, spk, bias=self.spk_b)
         # mel_len1 = prompt_feat.shape[1] (flow.py:170-175): normally 2P; one frame more when the prompt is not a whole number of
         # 40 ms tokens (embed_ref trims the tokens, not the mel, s3gen.py:152-158) -- the output then has 2N - (mel_len1 - 2P) frames
-        pf = ref["prompt_feat"].to(dev).float().view(1, -1, 80)
-        Pm = pf.shape[1]
+        pfs = [r["prompt_feat"].to(dev).float().view(-1, 80) for r in (refs[:1] if one else refs)]
+        Pms = [int(t.shape[0]) for t in pfs] * (B if one else 1)
         cond = torch.zeros(B, T, 80, device=dev)
-        cond[:, :Pm] = pf
+        if one:
+            cond[:, : Pms[0]] = pfs[0]
+        else:
+            for b in range(B):
+                cond[b, : Pms[b]] = pfs[b]
         if z is None:
             z = torch.randn(B, T, 80, device=dev)
         mel_lens = (2 * lens).to(torch.int32)
         if hold_back is not None:  # chunked synthesis: the encoder's 3-token lookahead frames are masked out of the CFM like padding
             mel_lens = (mel_lens - torch.as_tensor(hold_back, dtype=torch.int32).to(dev)).contiguous()
-        x = self.cfm(mu, mel_lens, spk.expand(B, -1), cond, z.to(dev), n_steps)
-        return x[:, Pm:, :].contiguous()
+        x = self.cfm(mu, mel_lens, spk.expand(B, -1) if one else spk, cond, z.to(dev), n_steps)
+        if all(pm == Pms[0] for pm in Pms):
+            return x[:, Pms[0]:, :].contiguous()
+        out = torch.zeros(B, T - min(Pms), 80, device=dev)  # generated frames left-aligned per row
+        for b in range(B):
+            out[b, : T - Pms[b]] = x[b, Pms[b]:]
+        return out

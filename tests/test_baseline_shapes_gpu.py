@@ -33,6 +33,12 @@ TOL_WAV_SAME_SOURCE = 1e-4                                   # HiFT decode, same
 TOL_WAV_FULL = {"s3gen_t1000": 1e-3, "vc_t3500": 1.35e-3}
 TOL_WAV_E2E_60S = 3.7e-3
 TOL_WAV_BF16_MODE = 2e-2                                     # SURVEY.md 8d "bf16-MFMA mode" waveform tolerance (mode 3, opt-in)
+# End to end at the bench shape (T3 tokens -> own CFM mel -> own F0 -> waveform, 8 s): floor 1.31e-4 (oracle vs reference on the same inputs,
+# measured when tests/golden/make_golden_e2e.py was run) -> 5x = 6.5e-4; mel of that run: the fp32 tolerance of TOL_MEL
+TOL_WAV_E2E_8S = 6.5e-4
+# F0 predictor (Hz, max-abs) on the reference's mels: floors 2.3e-4 (500 frames) / 2.7e-4 (3000 frames) -> 5x.  This is the quantity the
+# full-inference waveform tolerances above rest on: the excitation phase is 2 pi h * cumsum(f0) / sr
+TOL_F0 = {"f0_t1000": 1.2e-3, "f0_t3500": 1.4e-3}
 
 
 def _fp(sd):
@@ -176,6 +182,60 @@ def test_hift_full_length_vs_reference(dev, s3_sd, name):
         wav, _ = eng.inference(mel, phase, noise)
         rmse = _window_rmse(wav[0].cpu(), g, b)
         assert rmse <= TOL_WAV_FULL[name], f"{name} utt {b}: waveform RMSE {rmse:.3e} (signal rms {float(g['wav_rms'][b]):.3e})"
+
+
+@pytest.mark.parametrize("name,key", [("s3gen_t1000", "f0_t1000"), ("vc_t3500", "f0_t3500")])
+def test_f0_max_abs_at_500_and_3000_frames(dev, s3_sd, name, key):
+    """The F0 predictor on the reference's own mel at 10 s and 60 s against the reference's F0 (tests/golden/make_golden_e2e.py), max-abs in
+    Hz: bounds the input of the phase integration that the waveform tolerances of the full-inference tests are derived from."""
+    from chatterbox_amd.hift import HiFTEngine
+    g, e = _need(name), _need("e2e_b8")
+    mel = torch.from_numpy(g["mel"][0]).t().contiguous()[None].to(dev)
+    f0 = HiFTEngine(s3_sd, dev).f0_predict(mel)[0].cpu()
+    ref = torch.from_numpy(e[key])
+    assert f0.shape == ref.shape
+    err = (f0 - ref).abs()
+    assert err.max() <= TOL_F0[key], f"{name}: F0 max-abs {err.max():.3e} Hz at {ref.numel()} frames (f0 up to {ref.max():.0f} Hz), mean {err.mean():.3e}"
+    # the voiced / unvoiced decision (f0 > 0 after the abs()) must agree wherever the reference is clearly voiced
+    assert bool(((f0 > 1.0) == (ref > 1.0))[ref > 5.0].all())
+
+
+def test_e2e_synthesize_b8_250_tokens_vs_reference(dev, s3_sd):
+    """`ChatterboxEngine.synthesize` AT THE BENCH SHAPE in the default numerics: 8 utterances in one device batch (T3 30 layers, 64 text tokens,
+    250 sampled tokens each -> drop_invalid_tokens -> 10-step CFG CFM -> HiFT).  Utterance 0 carries the injected randomness of the
+    reference run of tests/golden/make_golden_e2e.py: its tokens, its waveform windows (and, through a second call on those tokens, its
+    mel) must match the reference's end-to-end output."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.engine import ChatterboxEngine, drop_invalid_tokens
+    e, t3g = _need("e2e_b8"), _need("t3_l30_b8")
+    B, steps, P = int(t3g["B"]), int(t3g["steps"]), int(e["P"])
+    eng = ChatterboxEngine(synth.t3_state_dict(30, 0), s3_sd, dev, n_t3_layers=30)
+    assert eng.flow.precision == 16 and eng.flow.use_planes
+    texts = [synth.text_tokens(int(t3g["n_text"]), seed=1 + b) for b in range(B)]
+    u = torch.from_numpy(t3g["uniforms"]).to(dev)
+    ns = [int(drop_invalid_tokens(torch.from_numpy(t3g["tokens"][b]).long()).numel()) for b in range(B)]
+    N0, Nmax = int(e["N"]), max(ns)
+    assert ns[0] == N0
+    T0, Tmax = 2 * (P + N0), 2 * (P + Nmax)
+    z = synth.randn((B, Tmax, 80), seed=77)
+    z[0, :T0] = synth.randn((1, 80, T0), seed=105)[0].t()
+    phase = (synth.rand((B, 9, 1), seed=78) * 2 - 1) * math.pi
+    phase[0] = (synth.rand((1, 9, 1), seed=106) * 2 - 1)[0] * math.pi
+    phase[:, 0] = 0
+    noise = synth.randn((B, 9, 960 * Nmax), seed=79)
+    noise[0, :, : 960 * N0] = synth.randn((1, 9, 960 * N0), seed=106)[0]
+    wavs, st = eng.synthesize(texts, synth.t3_cond(), synth.s3gen_ref(n_prompt_tokens=P), max_new_tokens=steps, uniforms=u, z=z.to(dev),
+                              phase=phase, noise=noise, drop_last_token=False, **SAMP)
+    assert [int(t.numel()) for t in st] == ns
+    assert torch.equal(st[0].cpu(), torch.from_numpy(e["tokens"]).long()), "utterance 0: speech tokens differ from the reference's"
+    w0 = wavs[0].float().cpu()
+    assert w0.numel() == 960 * N0
+    rmse = _window_rmse(w0, dict(win_start=e["win_start"], wav_win=e["wav_win"][None]), 0)
+    assert rmse <= TOL_WAV_E2E_8S, f"end-to-end waveform RMSE {rmse:.3e} (signal rms {float(e['wav_rms']):.3e}) in the batch of {B}"
+    # the CFM mel of utterance 0 inside the ragged batch (vocode returns it)
+    _, mel = eng.vocode(st, synth.s3gen_ref(n_prompt_tokens=P), z=z.to(dev), phase=phase, noise=noise)
+    err = (mel[0, : 2 * N0].float().cpu() - torch.from_numpy(e["mel"]).t()).abs()
+    assert err.mean() <= TOL_MEL[16][0] and err.max() <= TOL_MEL[16][1], f"mel L1 {err.mean():.3e} max {err.max():.3e}"
 
 
 # ----------------------------------------------------------------------------- configs[4]: 60 s VC, T = 3500, CFG estimator

@@ -368,3 +368,17 @@ def test_turbo_prompt_uses_the_15s_encoder_cut():
     assert a.cuts[-1] == 15 * fe.S3_SR and tok.shape[1] == 375
     _, tok = a.t3_prompt(w16, 150)
     assert a.cuts[-1] == 6 * fe.S3_SR and tok.shape[1] == 150
+
+
+def test_example_script_fixture_is_the_reference_text():
+    """tests/golden/example_scripts.json (the acceptance scripts tests/test_examples_gpu.py executes) is the reference's text, byte for byte,
+    wherever the reference is present; everywhere: the stored hashes match the stored text."""
+    import hashlib
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "example_scripts.json"), encoding="utf-8"))
+    assert set(fx) == {"example_tts.py", "example_tts_turbo.py", "example_tts_nano.py", "example_vc.py"}
+    for name, e in fx.items():
+        assert hashlib.sha256(e["text"].encode("utf-8")).hexdigest() == e["sha256"]
+        ref = os.path.join("/root/reference", name)
+        if os.path.exists(ref):
+            assert open(ref, encoding="utf-8").read() == e["text"], f"{name}: fixture differs from the reference (re-run tests/golden/make_golden_examples.py)"

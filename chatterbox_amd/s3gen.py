@@ -439,10 +439,12 @@ class FlowEngine:
         if one:
             tok = torch.cat([ptoks[0].view(1, -1).expand(B, -1), tokens.to(dev).long()], 1).contiguous()
         else:  # row b = [prompt_b | tokens_b | padding]: the encoder and the CFM mask by length, so what the padding holds is irrelevant
-            tok = torch.zeros(B, Pmax + N, dtype=torch.long, device=dev)
+            nb = [int(v) for v in token_lens.tolist()]
+            L = max(p + n for p, n in zip(Ps, nb))  # longest row: the batch is 2 L mel frames long
+            tok = torch.zeros(B, L, dtype=torch.long, device=dev)
             for b in range(B):
                 tok[b, : Ps[b]] = ptoks[b]
-                tok[b, Ps[b]: Ps[b] + N] = tokens[b].to(dev).long()
+                tok[b, Ps[b]: Ps[b] + nb[b]] = tokens[b, : nb[b]].to(dev).long()
         lens = (token_lens.to(dev).to(torch.int32) + torch.tensor(Ps, dtype=torch.int32, device=dev)).contiguous()
         mu = self.encode(tok, lens)
         T = mu.shape[1]
@@ -468,9 +470,10 @@ class FlowEngine:
         if hold_back is not None:  # chunked synthesis: the encoder's 3-token lookahead frames are masked out of the CFM like padding
             mel_lens = (mel_lens - torch.as_tensor(hold_back, dtype=torch.int32).to(dev)).contiguous()
         x = self.cfm(mu, mel_lens, spk.expand(B, -1) if one else spk, cond, z.to(dev), n_steps)
-        if all(pm == Pms[0] for pm in Pms):
+        if one or all(pm == Pms[0] and p == Ps[0] for pm, p in zip(Pms, Ps)):
             return x[:, Pms[0]:, :].contiguous()
-        out = torch.zeros(B, T - min(Pms), 80, device=dev)  # generated frames left-aligned per row
+        Ws = [2 * (Ps[b] + nb[b]) - Pms[b] for b in range(B)]  # generated frames per row: 2 n_b - (prompt_feat frames_b - 2 P_b)
+        out = torch.zeros(B, max(Ws), 80, device=dev)            # left-aligned per row
         for b in range(B):
-            out[b, : T - Pms[b]] = x[b, Pms[b]:]
+            out[b, : Ws[b]] = x[b, Pms[b]: Pms[b] + Ws[b]]
         return out

@@ -120,7 +120,10 @@ def _run_example(name, tmp_path, monkeypatch, hub, max_tokens=40):
     monkeypatch.setattr(huggingface_hub, "hf_hub_download", hf)
     monkeypatch.setattr(huggingface_hub, "snapshot_download", snap)
     saved = {}
+    import importlib.machinery
     ta = types.ModuleType("torchaudio")
+    ta.__spec__ = importlib.machinery.ModuleSpec("torchaudio", None)  # transformers probes optional packages with importlib.util.find_spec
+    ta.__version__ = "0.0.0+shim"
 
     def save(path, wav, sr, **kw):
         saved[str(path)] = (wav.detach().cpu(), sr)
@@ -140,8 +143,7 @@ def _run_example(name, tmp_path, monkeypatch, hub, max_tokens=40):
 
         monkeypatch.setattr(cls, "generate", capped)
     monkeypatch.chdir(tmp_path)
-    w, sr = synth.prompt_wav(seconds=7.0, sr=24000)
-    wavfile.write(str(tmp_path / "YOUR_FILE.wav"), sr, np.asarray(w, dtype=np.float32))  # the placeholder path of example_tts.py / example_vc.py
+    wavfile.write(str(tmp_path / "YOUR_FILE.wav"), 24000, synth.prompt_wav(seconds=7.0, sr=24000).numpy().astype(np.float32))  # the placeholder path of example_tts.py / example_vc.py
     src = SCRIPTS[name]["text"]
     exec(compile(src, name, "exec"), {"__name__": "__main__"})
     return saved

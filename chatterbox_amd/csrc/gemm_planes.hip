@@ -30,10 +30,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // waves per SIMD the register allocation must leave room for: as many workgroups per CU as the LDS admits (two co-resident workgroups
 // overlap one's epilogue with the other's K loop), at most 4 waves per SIMD (128 VGPRs)
-template <int BM, int BN, int BK, int NS, int NWV>
+template <int BM, int BN, int BK, int NS, int NWV, bool LD>
 struct PlOcc {
     static constexpr int occ = 160 * 1024 / (NS * 2 * (BM + BN) * (BK / 8) * 16);
-    static constexpr int w = occ * NWV / 4;
+    static constexpr int w = LD ? (NWV + 1 + 3) / 4 : occ * NWV / 4;  // loader-wave form: one workgroup (NWV + 1 waves) per CU
     static constexpr int waves_per_simd = w > 4 ? 4 : w < 1 ? 1 : w;
 };
 
@@ -43,9 +43,13 @@ __device__ __forceinline__ void pl_dma16(const __amdgpu_buffer_rsrc_t rs, unsign
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT>
+// LD = loader-wave form: the workgroup has one EXTRA wave that does nothing but issue the DMAs of every K tile and wait for them; the
+// NWV consumer waves only read LDS, multiply and run the epilogue.  A vector-memory instruction costs its issuing wave 100-200 cycles while
+// the CU's address path is busy, and a wave issues in order: in the symmetric form every wave's MFMAs queue behind its own DMA issue
+// (measured: DMA time and MFMA time ADD, profiles/r03_planes_diag_switches.log); with a dedicated loader they overlap.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, bool LD>
 // (the parentheses keep the template commas away from the variadic __launch_bounds__ macro)
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N>::waves_per_simd))
+__global__ __launch_bounds__((WARPS_M * WARPS_N + (LD ? 1 : 0)) * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N, LD>::waves_per_simd))
 void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int NWV = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -57,15 +61,17 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int STAGE_BYTES = STAGE_SLOTS * 16;
     constexpr int NLOAD = STAGE_SLOTS / 64;         // wave-level DMA instructions (1 KiB each) per stage
     static_assert((BM * CH) % 64 == 0 && (BN * CH) % 64 == 0, "a DMA instruction must not straddle the A / B boundary");
-    static_assert(NLOAD % NWV == 0, "DMA instructions must divide evenly over the waves");
+    static_assert(LD || NLOAD % NWV == 0, "DMA instructions must divide evenly over the waves");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && (CH == 4 || CH == 8), "tile shape");
-    constexpr int LPW = NLOAD / NWV;
+    constexpr int LPW = LD ? NLOAD : NLOAD / NWV;  // DMA instructions per K tile issued by one (loader) wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
+    const bool is_loader = LD && wid == NWV;
+    const int lbase = LD ? 0 : wid * LPW;  // first DMA instruction (of a stage) this wave issues
     // ---- persistent tile loop: workgroup b owns the virtual tiles b, b + gridDim.x, ...; the LOADER side (DMA issue) runs NS - 1 K tiles ahead
     //      of the CONSUMER side (MFMA + epilogue) straight across tile boundaries, so the first K tiles of the next output tile are in flight
     //      while this one's epilogue computes and stores, and no tile but a workgroup's first pays the load latency.  With gridDim.x = number
@@ -85,10 +91,11 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     //      wave-uniform tile and K / tap terms.  Validity is the buffer descriptor's business (the bounds check looks at this vector offset;
     //      a scalar offset would bypass it): rows >= lim lie behind num_records, rows < 0 (causal left padding) wrap to offsets >= 2^31 --
     //      both come back as zeros -- and rows of the M / N tail read whatever is there (their results are never stored).
-    int vbase[LPW], voff[LPW];
+    int vbase[LPW];
+    int offA = 0, offW = 0;  // wave-uniform parts of the A / W offsets: tile origin + K / tap advance (added in the VALU: see above)
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
-        const int s = (wid * LPW + i) * 64 + lane;
+        const int s = (lbase + i) * 64 + lane;
         const int q = s / PLANE_SLOTS, rs = s % PLANE_SLOTS;
         const int row = rs / CH, pc = rs % CH;
         const int c = pc ^ ((row / RPS) & (CH - 1));
@@ -105,23 +112,19 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
                                                  lim > 0 ? (int)((long)lim * p.lda * 2) : 0, 0x00020000);
         w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.W) + (long)z * p.w_s1), 0,
                                                  (int)((long)p.N * p.ldw * 2), 0x00020000);
-        const int tA = (m0 * p.stride - p.pad_left) * (int)p.lda * 2, tW = n0 * (int)p.ldw * 2;  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;  // wave-uniform: a DMA instruction never straddles the A / B boundary
-            voff[i] = vbase[i] + (isA ? tA : tW);
-        }
+        offA = (m0 * p.stride - p.pad_left) * (int)p.lda * 2;
+        offW = n0 * (int)p.ldw * 2;
     };
     int l_tile = blockIdx.x, l_kt = 0, l_g = 0;  // loader position: tile, K tile inside it, K tiles issued so far (ring position)
     int ld_c0 = 0;                               // channel block inside the current conv tap
-    if (l_tile < total) load_desc(l_tile);
+    if ((!LD || is_loader) && l_tile < total) load_desc(l_tile);
     auto issue = [&]() {  // the loader's next K tile into ring stage l_g % NS
-        unsigned char* dst = smem + (l_g % NS) * STAGE_BYTES + wid * LPW * 1024;
+        unsigned char* dst = smem + (l_g % NS) * STAGE_BYTES + lbase * 1024;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;
-            if (isA) pl_dma16(a_rs, dst + i * 1024, voff[i]);
-            else pl_dma16(w_rs, dst + i * 1024, voff[i]);
+            const bool isA = ((lbase + i) * 64) % PLANE_SLOTS < BM * CH;
+            if (isA) pl_dma16(a_rs, dst + i * 1024, vbase[i] + offA);
+            else pl_dma16(w_rs, dst + i * 1024, vbase[i] + offW);
         }
         ++l_g;
         if (++l_kt == nk) {  // next output tile of this workgroup
@@ -134,12 +137,8 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         ld_c0 += BK;
         const bool wrap = ld_c0 >= p.Cin;  // next K tile starts the next conv tap
         ld_c0 = wrap ? 0 : ld_c0;
-        const int stepA = BK * 2 + (wrap ? a_wstep2 : 0);
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const bool isA = ((wid * LPW + i) * 64) % PLANE_SLOTS < BM * CH;
-            voff[i] += isA ? stepA : BK * 2;
-        }
+        offA += BK * 2 + (wrap ? a_wstep2 : 0);
+        offW += BK * 2;
     };
 
     f32x16 acc[TM][TN], accc[TM][TN];
@@ -178,7 +177,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     //      number of operations issued after those DMAs (younger K tiles, and the previous tile's epilogue loads / stores) is exact and leaves
     //      everything younger in flight; after the barrier the K tile is complete for everybody and nobody reads the stage the next issue
     //      overwrites (it held the K tile consumed one iteration ago).
-    static_assert(NS == 2 || NS == 3, "two or three LDS stages");
+    static_assert(NS >= 2 && NS <= 4 && (LD || NS <= 3), "two or three LDS stages (the loader-wave form: up to four)");
 #ifdef CBX_DIAG  // scripts/diag_planes.sh: parts of the kernel switched off (1 no DMA after the prologue, 2 no ds_read / MFMA, 4 no epilogue stores)
     const int dg = p.reserved0;
 #define DG(bit) (dg & (bit))
@@ -186,12 +185,30 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
 #define DG(bit) 0
 #endif
     constexpr int EPI_OPS = TM * TN * 16;  // vector-memory operations every epilogue issues at least (one output kind)
-    constexpr int W_EPI0 = (NS - 2) * LPW + EPI_OPS > 63 ? 63 : (NS - 2) * LPW + EPI_OPS;  // first K tile after an epilogue
-    constexpr int W_EPI1 = LPW + EPI_OPS > 63 ? 63 : LPW + EPI_OPS;                          // NS = 3: second K tile after an epilogue
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (l_tile < total) issue();
+    [[maybe_unused]] constexpr int W_EPI0 = (NS - 2) * LPW + EPI_OPS > 63 ? 63 : (NS - 2) * LPW + EPI_OPS;  // first K tile after an epilogue
+    [[maybe_unused]] constexpr int W_EPI1 = LPW + EPI_OPS > 63 ? 63 : LPW + EPI_OPS;                          // NS = 3: second K tile after an epilogue
     int c_g = 0;  // consumer ring position
+    if (is_loader) {  // ---- the loader wave: wait for K tile g, release it to the consumers at the barrier, issue K tile g + NS - 1
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (l_tile < total) issue();
+        for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x)
+            for (int kt = 0; kt < nk; ++kt) {
+                const int younger = l_g - c_g - 1;  // K tiles issued after the one released now: they stay in flight
+                if (NS >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
+                else if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW > 63 ? 63 : LPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (l_tile < total) issue();
+                ++c_g;
+            }
+        return;
+    }
+    if (!LD) {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (l_tile < total) issue();
+    }
     for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -201,13 +218,15 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
         const bool after_epi = c_tile != (int)blockIdx.x;
         for (int kt = 0; kt < nk; ++kt) {
-            const int younger = l_g - c_g - 1;  // K tiles issued after the one consumed now (0 .. NS - 2)
-            if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0) : "memory");
-            else if (NS == 3 && after_epi && kt == 1 && younger == 1 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1) : "memory");
-            else if (NS == 3 && younger == 1 && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!LD) {
+                const int younger = l_g - c_g - 1;  // K tiles issued after the one consumed now (0 .. NS - 2)
+                if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0) : "memory");
+                else if (NS == 3 && after_epi && kt == 1 && younger == 1 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1) : "memory");
+                else if (NS == 3 && younger == 1 && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            if (l_tile < total && !DG(1)) issue();
+            if (!LD && l_tile < total && !DG(1)) issue();
             if (!DG(2)) compute(c_g % NS);
             ++c_g;
         }
@@ -319,18 +338,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 int g_pl_persist = getenv("CBX_PL_PERSIST") ? atoi(getenv("CBX_PL_PERSIST")) : 1;
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, bool LD>
 int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT>;
+    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD>;
+    constexpr int THREADS = (WARPS_M * WARPS_N + (LD ? 1 : 0)) * 64;
     static int resident = 0;  // workgroups the chip holds at once (advisory: nothing in the kernel depends on co-residency)
     if (!resident) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return cbx_set_error((int)e, "gemm_planes: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), WARPS_M * WARPS_N * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         resident = per_cu * prop.multiProcessorCount / 8 * 8;  // a multiple of the XCD count keeps the XCD affinity of the tile order
         if (resident < 8) resident = 8;
@@ -338,15 +358,15 @@ int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     const long total = (long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.nz1;
     const long cap = g_pl_persist > 1 ? g_pl_persist : resident;  // > 1: an explicit workgroup count (tests force multi-tile walks on small shapes)
     const unsigned grid = (unsigned)(g_pl_persist && total > cap ? cap : total);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, p, cbx_range_flag());
     return cbx_check_launch("gemm_planes");
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2, bool LD = false>
 int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
-    if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF>(p, st);
-    if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU>(p, st);
-    return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_NONE>(p, st);
+    if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF, LD>(p, st);
+    if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU, LD>(p, st);
+    return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_NONE, LD>(p, st);
 }
 
 }  // namespace
@@ -411,15 +431,25 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 15: return launch_pl<128, 256, 2, 4, 32>(p, st);     // 8 waves 64x64, 96 KB
         case 16: return launch_pl<64, 128, 2, 2, 32>(p, st);      // 4 waves 32x64, 48 KB
         case 17: return launch_pl<128, 128, 4, 2, 32, 3>(p, st);  // 8 waves 32x64, 3 stages, 96 KB
+        case 18: return launch_pl<256, 128, 4, 2, 32, 3>(p, st);  // 8 waves 64x64, 3 stages, 144 KB
+        case 19: return launch_pl<128, 256, 2, 4, 32, 3>(p, st);  // 8 waves 64x64, 3 stages, 144 KB
+        // loader-wave forms (8 consumer waves + 1 loader wave, one workgroup per CU)
+        case 21: if (k64) return launch_pl<128, 128, 4, 2, 64, 2, true>(p, st); break;  // 128 KB
+        case 22: return launch_pl<128, 128, 2, 4, 32, 3, true>(p, st);   // 96 KB
+        case 23: return launch_pl<256, 128, 4, 2, 32, 3, true>(p, st);   // 144 KB, 64x64 per wave
+        case 24: return launch_pl<128, 128, 4, 2, 32, 2, true>(p, st);   // 64 KB
+        case 25: return launch_pl<128, 128, 2, 4, 32, 4, true>(p, st);   // 4 stages, 128 KB
         default: break;
     }
-    // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere (more waves to overlap DMA issue,
-    // MFMA and the epilogue); wide outputs 2 x 4 waves of 64 x 32, narrow outputs with a long K the BK = 64 form, N <= 96 half-width tiles
+    // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere.  The loader-wave form
+    // (128 x 128 x 64, one workgroup of 8 + 1 waves per CU) wins wherever the epilogue is light: wide plain outputs (-5..-12 %) and narrow
+    // outputs with a long K (-3 %); an epilogue with a GELU wants two co-resident workgroups (the symmetric 2 x 4 waves of 64 x 32);
+    // N <= 96 takes half-width tiles, small grids 64 x 64.
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
     if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
     if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
-    if (p.N >= 512) return launch_pl<128, 128, 2, 4, 32>(p, st);
-    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64>(p, st);
+    if (p.N >= 512) return k64 && p.act == CBX_ACT_NONE ? launch_pl<128, 128, 4, 2, 64, 2, true>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
+    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, true>(p, st);
     return launch_pl<128, 128, 4, 2, 32>(p, st);
 }
 

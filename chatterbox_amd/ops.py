@@ -308,6 +308,18 @@ def conv1d_planes(x, w, *, B, T, taps, cin, out=None, outp=None, bias=None, pad_
                 p_s1=0 if outp is None else T * outp.ld)
 
 
+def mlp_planes(h, w1, w2, b1, b2, x, outp=None, write_x=True):
+    """x (M, 256) fp32 (+)= W2 GELU(W1 h + b1) + b2 (one launch): h Planes (M, 256), w1 Planes (F, 256), w2 Planes (256, F); the result goes to x
+    (write_x) and / or to the Planes outp."""
+    M, D, F = h.rows, h.C, w1.rows
+    assert w1.C == D and w2.rows == D and w2.C == F and x.shape == (M, D) and x.stride(1) == 1
+    _timed("mlp_planes", 4.0 * M * D * F, 4.0 * (3 * M * D + 2 * D * F),
+           lambda: check(lib.cbx_mlp_planes(h.ptr, w1.ptr, w2.ptr, _p(b1), _p(b2), _p(_f32(x, "x")), None if outp is None else outp.ptr, M, D, F,
+                                            h.ld, h.lo, w1.ld, w1.lo, w2.ld, w2.lo, x.stride(0), 0 if outp is None else outp.ld,
+                                            0 if outp is None else outp.lo, int(write_x), _stream()), "cbx_mlp_planes"))
+    return x
+
+
 def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, causal=False):
     """q, k: Planes column ranges (Z * T rows, H * 64 columns); vt: Planes over (Z * H * 64 rows, >= T rounded up to 8 columns) = V^T
     (batch stride vt_sb halves); out: Planes (Z * T rows, H * 64)."""

@@ -113,6 +113,9 @@ class FlowEngine:
         # CFM estimator on plane-format operands (round 3; gemm_planes.hip / attention_planes.hip): the f16x3 arithmetic with weights
         # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
         self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
+        # ff1 + GELU + ff2 + residual in one launch (cbx_mlp_planes): measured EQUAL to the two GEMMs it replaces at the bench shape (81.6 vs 80 us:
+        # with 64 tokens per workgroup it re-streams W1 / W2 through L2 -> LDS once per token tile, 640 MB per call) -- opt-in, not the default
+        self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
         self._pw = None
 
     # ------------------------------------------------------------------ conformer encoder
@@ -304,8 +307,11 @@ class FlowEngine:
         ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=rows, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125, key_lens=lens)
         ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
         ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)
-        ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
-        ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
+        if self.fused_mlp:  # ff1 + GELU + ff2 + residual in one launch: the 1024-wide intermediate never leaves the chip
+            ops.mlp_planes(hP, pw["w1"], pw["w2"], tw["b1"], tw["b2"], x2, outp=outP, write_x=outP is None)
+        else:
+            ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
+            ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
 
     def _estimator_pl(self, xinP, rows, T, lens, tbias, ws):
         """ConditionalDecoder.forward (decoder.py:243-333) on plane operands: xinP Planes (rows*T, 320) -> ws['v'] (rows,T,80) fp32."""

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=None, help="speech tokens of the CPU-baseline utterance (default: --tokens, i.e. the benched workload)")
-    ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "gemm_split", "flash_attn_f32", "gemv_f32"],
+    ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "gemm_f32", "gemm_split", "flash_attn_f32", "gemv_f32", "gemm_planes", "flash_attn_planes"],
                     help="kernel class reported as `roofline` (auto: the one with the largest share of a step); the others go to "
                          "`roofline_secondary`.  All three are timed with HIP events on the launch stream")
     ap.add_argument("--s3gen-precision", type=int, default=None, choices=[1, 3, 6, 16],
@@ -655,7 +655,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
             log("cpu baseline ...")
             art, out["cpu_baseline"] = cpu_baseline(t3_sd, s3_sd, args, args.t3_layers)
-            out["parity"] = gpu_parity(eng, art, out["cpu_baseline"]["kind"])
+            if not args.no_parity:
+                out["parity"] = gpu_parity(eng, art, out["cpu_baseline"]["kind"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

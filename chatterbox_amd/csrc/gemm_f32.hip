@@ -44,9 +44,13 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void gemm_f32_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
     const int z = blockIdx.z, z1 = z / p.nz2, z2 = z - z1 * p.nz2;
-    // n-tiles of one m-tile (they share the A panel) are kept on one XCD
+    // XCD-aware tile order: an XCD's L2 sees a contiguous run of tile ids.  With n fastest the run shares A panels and walks ALL of W
+    // (every XCD fetches the whole weight: 8 W + A bytes in total); with m fastest it shares W panels and walks all of A (8 A + W).  The
+    // bigger operand is the one to fetch once: m fastest whenever the weight is the larger operand (N > M: the T3 prefill projections,
+    // where the n-fastest order measured a 3.1x over-fetch, profiles/r02_t3_eager_pmc_FETCH_SIZE.csv).
     const int tile = cbx_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int n0 = (tile % gridDim.x) * BN, m0 = (tile / gridDim.x) * BM;
+    const bool mfast = p.N > p.M && p.nz1 * p.nz2 == 1;
+    const int n0 = (mfast ? tile / gridDim.y : tile % gridDim.x) * BN, m0 = (mfast ? tile % gridDim.y : tile / gridDim.x) * BM;
 
     const float* __restrict__ Ab = p.A + (long)z1 * p.a_s1 + (long)z2 * p.a_s2;
     const float* __restrict__ Wb = p.W + (long)z1 * p.w_s1 + (long)z2 * p.w_s2;

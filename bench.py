@@ -374,21 +374,23 @@ def gemv_sweeps(t3, rows, reps=6):
     return res
 
 
-def decode_step_entry(t3, n_layers):
+def decode_step_entry(t3, n_layers, gpt2=False):
     """Whole decode step (every kernel of the captured hipGraph: GEMVs + attention + sampler), timed INSIDE the timed region with two
     HIP events around the replay loop of each generate() call.  Algorithmic bytes per step: all streamed weights
-    (4 N K per projection + head) + the KV cache read of every row at its current context (2 * ctx * 1024 * 4 B per layer per row)."""
+    (4 N K per projection + head) + the KV cache read of every row at its current context (2 * ctx * 1024 * 4 B per layer per row).
+    gpt2: the Turbo / Nano T3 (c_attn 3 D^2, c_proj D^2, c_fc and mlp c_proj 4 D^2 each; no CFG: one row per utterance)."""
     if not t3.decode_events:
         return None
     torch.cuda.synchronize()
-    w_bytes = 4.0 * (n_layers * (4 * t3.D * t3.D + 3 * t3.D * t3.F) + t3.V * t3.D)
+    n_layers = n_layers or t3.L
+    w_bytes = 4.0 * (n_layers * 12 * t3.D * t3.D + t3.V * t3.D) if gpt2 else 4.0 * (n_layers * (4 * t3.D * t3.D + 3 * t3.D * t3.F) + t3.V * t3.D)
     ms = steps = kv = 0.0
     for e0, e1, n, s0, rows in t3.decode_events:
         ms += e0.elapsed_time(e1)
         steps += n
-        B = rows // 2
-        for b in range(B):  # both CFG rows of utterance b read ctx = s0 + t keys at decode step t = 1..n
-            kv += 2 * sum(2.0 * (s0[b] + t) * t3.D * 4 * n_layers for t in range(1, n + 1))
+        B = rows if gpt2 else rows // 2
+        for b in range(B):  # every row of utterance b (both CFG rows of the Llama T3) reads ctx = s0 + t keys at decode step t = 1..n
+            kv += (1 if gpt2 else 2) * sum(2.0 * (s0[b] + t) * t3.D * 4 * n_layers for t in range(1, n + 1))
     tot = w_bytes * steps + kv
     gbs = tot / (ms * 1e-3) / 1e9
     return dict(bound="hbm", what="T3 decode step = one hipGraph replay (5 launches per layer + head + sampler), timed with HIP events inside "
@@ -480,8 +482,7 @@ def main():
     # HIP-event timing of every GEMM / attention launch costs ~25 ms per step (4000 event records): it is switched on for the
     # LAST timed step only (all steps in --pipelined mode), so the headline number carries 1/K of that overhead
     timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32", "gemm_planes", "flash_attn_planes"])
-    if not turbo:
-        eng.t3.time_decode, eng.t3.decode_events = True, []
+    eng.t3.time_decode, eng.t3.decode_events = True, []
     timed_steps = args.steps if pipelined else 1
     ops.TIMER = timer if pipelined else None
     if world > 1:
@@ -521,8 +522,7 @@ def main():
     # ---- outside the timed region: (a) eager replay of the decode step for the gemv roofline, (b) one step at each of the other
     # S3Gen precisions so that the exact-fp32 figure is reported by the same run
     alt, gemv, dstep, cfg3, stream = {}, None, None, None, None
-    if not turbo:
-        eng.t3.time_decode = False
+    eng.t3.time_decode = False
     run_cfg3 = (args.config3 or world == 8) and not turbo
     if run_cfg3:  # configs[3]: 256 utterances, contiguous shards (dist.shard_range), 32 per GPU at 8 GPUs; every rank takes part
         lo, hi = cdist.shard_range(256, rank, world)
@@ -562,6 +562,8 @@ def main():
                     value=round(float(st3[1]) / float(st3[0]), 2), unit="audio-s/wall-s", wall_s=round(float(st3[0]), 3))
     if rank == 0:
         summ = timer.summary()
+        if turbo:
+            dstep = decode_step_entry(eng.t3, None, gpt2=True)
         if not turbo:
             dstep = decode_step_entry(eng.t3, args.t3_layers)
             gemv = gemv_sweeps(eng.t3, 2 * B)

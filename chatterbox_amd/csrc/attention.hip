@@ -446,13 +446,17 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
     CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
-    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : 4;  // key rows in flight per 16-lane group
+    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: by grid size)
     const dim3 grid(n_heads, rows), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (g_da_u == 8)
+    // One workgroup per (row, head) walks its whole context: a step costs a memory round trip whatever it carries.  With >= 128 workgroups (the
+    // batched Llama path: 16 rows x 16 heads) 4 rows per lane group and step is best (profiles/r02_t3_decode_variants.log); a small grid
+    // (Turbo / Nano at batch 1: 12-16 workgroups, 11.8 us per launch at context 700) wants everything it can keep in flight: 16 rows per step.
+    const int da_u = g_da_u > 0 ? g_da_u : ((long)rows * n_heads < 128 ? 16 : 4);
+    if (da_u == 8)
         hipLaunchKernelGGL(decode_attn_rope_kernel<8>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
                            o_packed, cache_row_stride, cache_head_stride, scale);
-    else if (g_da_u == 16)
+    else if (da_u == 16)
         hipLaunchKernelGGL(decode_attn_rope_kernel<16>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
                            o_packed, cache_row_stride, cache_head_stride, scale);
     else

@@ -55,11 +55,18 @@ __device__ __forceinline__ void rep_penalty(float* l, const unsigned char* seen,
 // Sort-free: token i is dropped iff mass{p_j <= p_i} <= 1 - top_p; the cut value is found by bisection on the
 // (monotone) bit pattern of the un-normalised probabilities.
 __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
+    constexpr int EPT = (MAXV + NT - 1) / NT;  // elements per thread: their un-normalised probabilities are computed ONCE and kept in registers
     float m = -INFINITY;
     for (int i = threadIdx.x; i < V; i += NT) m = fmaxf(m, l[i]);
     m = block_max(m, red);
+    float e[EPT];
     float z = 0.f;
-    for (int i = threadIdx.x; i < V; i += NT) z += __expf(l[i] - m);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + j * NT;
+        e[j] = i < V ? __expf(l[i] - m) : 2.0f;  // 2 > every threshold in [0, 1]: a slot past the vocabulary never counts
+        z += i < V ? e[j] : 0.f;
+    }
     z = block_sum(z, red);
     const float budget = (1.0f - top_p) * z;
     unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget
@@ -67,18 +74,17 @@ __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
         unsigned mid = lo + (hi - lo) / 2;
         float thr = __uint_as_float(mid);
         float s = 0.f;
-        for (int i = threadIdx.x; i < V; i += NT) {
-            float e = __expf(l[i] - m);
-            if (e <= thr) s += e;
-        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) s += e[j] <= thr ? e[j] : 0.f;
         s = block_sum(s, red);
         if (s <= budget) lo = mid; else hi = mid;
     }
     const float cut = __uint_as_float(lo);
     __syncthreads();
-    for (int i = threadIdx.x; i < V; i += NT) {
-        float e = __expf(l[i] - m);
-        if (e <= cut && e < 1.0f) l[i] = -INFINITY;  // the arg-max is always kept (min_tokens_to_keep = 1)
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + j * NT;
+        if (i < V && e[j] <= cut && e[j] < 1.0f) l[i] = -INFINITY;  // the arg-max is always kept (min_tokens_to_keep = 1)
     }
     __syncthreads();
 }
@@ -86,21 +92,32 @@ __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
 // HF TopKLogitsWarper: scores < k-th largest -> -inf (bisection on the order-preserving integer image).
 __device__ void top_k_filter(float* l, int V, int k, float* red) {
     if (k <= 0 || k >= V) return;
+    constexpr int EPT = (MAXV + NT - 1) / NT;
     auto key = [](float f) -> unsigned {
         unsigned u = __float_as_uint(f);
         return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     };
+    unsigned ky[EPT];  // the thread's keys, computed once (0 for slots past the vocabulary: never >= a threshold >= 1)
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + j * NT;
+        ky[j] = i < V ? key(l[i]) : 0u;
+    }
     unsigned lo = 0u, hi = 0xFFFFFFFFu;  // largest key with count{key(l) >= key} >= k
     while (lo < hi) {
         unsigned mid = lo + (hi - lo) / 2 + 1;
         float c = 0.f;
-        for (int i = threadIdx.x; i < V; i += NT) c += key(l[i]) >= mid ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) c += ky[j] >= mid ? 1.f : 0.f;
         c = block_sum(c, red);
         if (c >= (float)k) lo = mid; else hi = mid - 1;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < V; i += NT)
-        if (key(l[i]) < lo) l[i] = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + j * NT;
+        if (i < V && ky[j] < lo) l[i] = -INFINITY;
+    }
     __syncthreads();
 }
 

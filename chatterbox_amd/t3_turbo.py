@@ -64,6 +64,7 @@ class T3TurboEngine:
         self.ks_o = 4 if self.D % 512 == 0 else 2
         self.ks_p = 8
         self._state = {}
+        self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled (bench.py)
 
     def _forward_decode(self, st):
         ws = st["dws"]
@@ -235,7 +236,13 @@ class T3TurboEngine:
             for k, v in saved.items():
                 st[k].copy_(v)
             st["graph"] = gr
+        ev = None
+        if self.time_decode:  # two HIP events around the decode loop on its launch stream (bench.py: in-run decode-step roofline)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        n_replays = 0
         for i in range(1, n_samples):
+            n_replays += 1
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()
             elif debug_logits:
@@ -246,6 +253,9 @@ class T3TurboEngine:
                 self._decode_step(st)
             if not ban_eos and (i % poll_every == 0) and bool(st["done"].all()):
                 break
+        if ev is not None:
+            ev[1].record()
+            self.decode_events.append((ev[0], ev[1], n_replays, list(s0), B))
         n = st["n_generated"].tolist()
         toks = st["out_tokens"].cpu()
         out = []

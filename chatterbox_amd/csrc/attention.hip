@@ -262,11 +262,16 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
                                                                int n_heads, long ld_qkv, long o_ld, int o_packed, long row_stride,
-                                                               long head_stride, float scale) {
+                                                               long head_stride, float scale, float* split_ws, int* split_cnt) {
+    // gridDim.z = S > 1: the context of a (row, head) is split over S workgroups (on S CUs: one workgroup cannot pull a long context
+    // faster than its CU's memory path, 50-60 GB/s); each leaves {max, sum, 64 numerators} in split_ws and the LAST to arrive (a ticket on
+    // split_cnt, agent-scope release before it, acquire after it: cdna_hip_programming.md guideline 16) merges them in split order.
     __shared__ __attribute__((aligned(16))) float q_s[64], k_new[64], v_new[64];
     __shared__ __attribute__((aligned(16))) float st_acc[16][64];
     __shared__ float st_m[16], st_l[16];
+    __shared__ int s_last;
     const int row = blockIdx.y, head = blockIdx.x;
+    const int S = gridDim.z, sp = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     const int pos = positions[row];
@@ -285,7 +290,10 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
         }
     };
-    int p0 = wid * 4 + sub;
+    // this workgroup's positions: [p_lo, p_hi), 16-aligned slices of [0, ctx); the new token (position pos) belongs to the last slice
+    const int slice = S > 1 ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
+    const int p_lo = sp * slice, p_hi = min(ctx, p_lo + slice);
+    int p0 = p_lo + wid * 4 + sub;
     load_chunk(p0);
 
     if (wid == 0) {
@@ -298,8 +306,10 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         q_s[lane] = qn * scale;
         k_new[lane] = kn;
         v_new[lane] = vn0;
-        kb[(long)pos * 64 + lane] = kn;
-        vb[(long)pos * 64 + lane] = vn0;
+        if (sp == S - 1) {  // one workgroup appends the new token to the cache
+            kb[(long)pos * 64 + lane] = kn;
+            vb[(long)pos * 64 + lane] = vn0;
+        }
     }
     __syncthreads();
     const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             t += __shfl_xor(t, 4);
             t += __shfl_xor(t, 2);
             t += __shfl_xor(t, 1);
-            d[u] = p < ctx ? t : -INFINITY;
+            d[u] = p < p_hi ? t : -INFINITY;
             mt = fmaxf(mt, d[u]);
         }
         if (mt > -INFINITY) {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             m = mt;
         }
         p0 += 16 * DA_U;
-        if (p0 >= ctx) break;
+        if (p0 >= p_hi) break;
         load_chunk(p0);
     }
     const int g = wid * 4 + sub;
@@ -346,17 +356,55 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         st_l[g] = l;
     }
     __syncthreads();
+    float M = -INFINITY, num = 0.f, den = 0.f;
     if (tid < 64) {
-        float M = st_m[0];
+        M = st_m[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) M = fmaxf(M, st_m[i]);
-        float num = 0.f, den = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float f = st_m[i] > -INFINITY ? __expf(st_m[i] - M) : 0.f;
             num += f * st_acc[i][tid];
             den += f * st_l[i];
         }
+    }
+    if (S > 1) {
+        float* wsb = split_ws + ((long)(row * n_heads + head) * S) * 66;
+        if (tid < 64) {
+            wsb[sp * 66 + 2 + tid] = num;
+            if (tid == 0) {
+                wsb[sp * 66] = M;
+                wsb[sp * 66 + 1] = den;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&split_cnt[row * n_heads + head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == S - 1;
+            if (s_last) {
+                __hip_atomic_store(&split_cnt[row * n_heads + head], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid < 64) {  // merge in split order (fixed: the result does not depend on who arrived last)
+            // the per-split scalars through agent-scope loads (a uniform plain load may take the scalar cache, which the acquire does not cover)
+            M = -INFINITY;
+            for (int i = 0; i < S; ++i) M = fmaxf(M, __hip_atomic_load(&wsb[i * 66], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            num = den = 0.f;
+            for (int i = 0; i < S; ++i) {
+                const float mi = __hip_atomic_load(&wsb[i * 66], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float f = mi > -INFINITY ? __expf(mi - M) : 0.f;
+                num += f * wsb[i * 66 + 2 + tid];
+                den += f * __hip_atomic_load(&wsb[i * 66 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (tid < 64) {
         long oi = (long)row * o_ld + head * 64 + tid;
         if (o_packed) {  // operand layout of the o-projection GEMV (include/cbx.h "packed GEMV weight layout", K = n_heads * 64)
             const int n = head * 64 + tid;
@@ -441,27 +489,51 @@ extern "C" int cbx_set_decode_attn_unroll(int u) {
     return 0;
 }
 
+// Workspace of the split-context form (one per device; registered by the engines: 66 floats per (row, head, split) + one ZEROED int per
+// (row, head)).  Without it -- or with >= 128 (row, head) pairs -- one workgroup walks a whole context.
+static float* g_da_ws[64] = {nullptr};
+static int* g_da_cnt[64] = {nullptr};
+static long g_da_pairs[64] = {0};
+extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, long max_pairs) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return cbx_set_error(CBX_EINVAL, "set_decode_attn_workspace: no current device");
+    g_da_ws[d] = ws;
+    g_da_cnt[d] = zeroed_counters;
+    g_da_pairs[d] = ws && zeroed_counters ? max_pairs : 0;
+    return 0;
+}
+constexpr int DA_MAX_SPLIT = 8;
+
 extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                                         float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
     CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
     if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: by grid size)
-    const dim3 grid(n_heads, rows), block(256);
+    static const int no_split = getenv("CBX_DA_NO_SPLIT") ? atoi(getenv("CBX_DA_NO_SPLIT")) : 0;
+    const long pairs = (long)rows * n_heads;
+    int d = 0, S = 1;
+    if (!no_split && pairs < 128 && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 && g_da_pairs[d] >= pairs) {
+        S = (int)(256 / pairs);  // fill the chip: Turbo / Nano at batch 1 = 12-16 pairs -> 8 workgroups each
+        S = S > DA_MAX_SPLIT ? DA_MAX_SPLIT : S < 1 ? 1 : S;
+    }
+    const dim3 grid(n_heads, rows, S), block(256);
     hipStream_t st = (hipStream_t)stream;
-    // One workgroup per (row, head) walks its whole context: a step costs a memory round trip whatever it carries.  With >= 128 workgroups (the
-    // batched Llama path: 16 rows x 16 heads) 4 rows per lane group and step is best (profiles/r02_t3_decode_variants.log); a small grid
-    // (Turbo / Nano at batch 1: 12-16 workgroups, 11.8 us per launch at context 700) wants everything it can keep in flight: 16 rows per step.
-    const int da_u = g_da_u > 0 ? g_da_u : ((long)rows * n_heads < 128 ? 16 : 4);
+    float* ws = S > 1 ? g_da_ws[d] : nullptr;
+    int* cnt = S > 1 ? g_da_cnt[d] : nullptr;
+    // One workgroup per (row, head[, split]) walks its context: a step costs a memory round trip whatever it carries.  With >= 128 workgroups (the
+    // batched Llama path: 16 rows x 16 heads) 4 rows per lane group and step is best (profiles/r02_t3_decode_variants.log); small grids
+    // keep 16 rows per step in flight and split the context (Turbo / Nano at batch 1: 11.8 us per launch at context 700 before).
+    const int da_u = g_da_u > 0 ? g_da_u : (pairs < 128 ? 16 : 4);
     if (da_u == 8)
         hipLaunchKernelGGL(decode_attn_rope_kernel<8>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale);
+                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
     else if (da_u == 16)
         hipLaunchKernelGGL(decode_attn_rope_kernel<16>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale);
+                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
     else
         hipLaunchKernelGGL(decode_attn_rope_kernel<4>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale);
+                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
     return cbx_check_launch("decode_attn_rope");
 }
 

@@ -432,6 +432,24 @@ def decode_attn(q, kc, vc, out, ctx_lens, scale):
     return out
 
 
+_DA_WS = {}  # device index -> (partials, arrival counters) of the split-context decode attention
+
+
+def ensure_decode_attn_workspace(device):
+    """Register, once per device, the workspace cbx_decode_attn_rope_f32 splits a context through when rows * heads < 128
+    (called by the T3 engines at construction: an allocation + fill must not happen inside a stream capture)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx in _DA_WS:
+        return
+    with torch.cuda.device(idx):
+        ws = torch.empty(128 * 8 * 66, dtype=torch.float32, device=f"cuda:{idx}")
+        cnt = torch.zeros(128, dtype=torch.int32, device=f"cuda:{idx}")
+        torch.cuda.current_stream().synchronize()
+        check(lib.cbx_set_decode_attn_workspace(_p(ws), _p(cnt), 128), "cbx_set_decode_attn_workspace")
+    _DA_WS[idx] = (ws, cnt)
+
+
 def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False):
     """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)
     [out_packed: the packed operand image of the o-projection gemv, (ceil(rows/16)*16, H*64)]."""

@@ -45,6 +45,7 @@ class T3Engine:
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
         self.dev = torch.device(device)
+        ops.ensure_decode_attn_workspace(self.dev)
         if n_layers is None:
             n_layers = 0
             while f"tfmr.layers.{n_layers}.input_layernorm.weight" in sd:

@@ -19,6 +19,7 @@ class T3TurboEngine:
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None):
         self.dev = dev = torch.device(device)
+        ops.ensure_decode_attn_workspace(self.dev)
         if n_layers is None:
             n_layers = 0
             while f"tfmr.h.{n_layers}.ln_1.weight" in sd:

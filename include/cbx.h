@@ -254,6 +254,9 @@ int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float
 int cbx_set_split_tile(int t);
 /* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
 int cbx_set_decode_attn_unroll(int u);
+/* Workspace of cbx_decode_attn_rope_f32's split-context form, used when rows * n_heads < 128 (Turbo / Nano at small batch): ws = 66 * 8 floats
+ * per (row, head), zeroed_counters = one int per (row, head), initialised to 0 once; registered for the calling thread's current device. */
+int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, long max_pairs);
 
 /* Row softmax over materialised scores with optional relative-position term and key mask
  * (RelPositionMultiHeadedAttention.forward, transformer/attention.py:249-330):

@@ -523,6 +523,38 @@ def test_decode_attn_rope_fused(dev):
         _close(kc[r, :, :n], kc0[r, :, :n], 0.0, "cache untouched")
 
 
+@pytest.mark.parametrize("rows,H,rope", [(1, 12, False), (1, 16, True), (2, 16, True), (5, 12, False)])
+def test_decode_attn_rope_split_context(dev, rows, H, rope):
+    """rows * heads < 128 (Turbo / Nano at small batch): the context of a (row, head) is walked by up to 8 workgroups and merged by
+    the last to arrive.  Every context length 1..40 and a few long ones, launched back to back (the arrival counters reset
+    themselves), against torch SDPA; and against the one-workgroup form of the same kernel."""
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    ops.ensure_decode_attn_workspace(dev)
+    maxp = 1024
+    kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    cd, sd_ = (cos.to(dev), sin.to(dev)) if rope else (None, None)
+    for n in list(range(0, 40)) + [127, 128, 129, 511, 700, 1023]:
+        pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
+        qkv = _r((rows, 3 * H * 64), 100 + n)
+        kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.empty(rows, H * 64, device=dev)
+        ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
+        q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
+        if rope:
+            c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
+            q, k = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
+        for r in range(rows):
+            m = int(pos[r])
+            kk = torch.cat([kc0[r, :, :m], k[r][:, None]], 1)
+            vv = torch.cat([vc0[r, :, :m], v[r][:, None]], 1)
+            ref = F.scaled_dot_product_attention(q[r].reshape(H, 1, 64), kk, vv)
+            _close(out[r].view(H, 64), ref[:, 0], 2e-5, f"split decode attention ctx {m + 1} row {r}")
+            _close(kc[r, :, m], k[r], 1e-6, "k appended")
+            _close(vc[r, :, m], v[r], 0.0, "v appended")
+    assert int(ops._DA_WS[torch.device(dev).index or 0][1].abs().sum()) == 0, "arrival counters are back at zero"
+
+
 def _unpack_operand(img, rows, K):
     """Inverse of the packed GEMV operand layout (include/cbx.h): image (ceil(rows/16)*16, K) -> row-major (rows, K)."""
     T = img.shape[0] // 16

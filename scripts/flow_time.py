@@ -14,7 +14,8 @@ lens = torch.full((B,), N, dtype=torch.int32, device=dev)
 ref = synth.s3gen_ref()
 z = synth.randn((B, 2 * (250 + N), 80), seed=9).to(dev)
 mels = {}
-for planes in ([False, True, False, True] if flow.use_planes and flow.precision == 16 else [flow.use_planes]):  # A/B inside one process
+modes = [False, True, False, True] if flow.use_planes and flow.precision == 16 and not os.environ.get("CBX_FLOW_NO_AB") else [flow.use_planes]
+for planes in modes:  # A/B inside one process
     flow.use_planes = planes
     ts = []
     for it in range(4):

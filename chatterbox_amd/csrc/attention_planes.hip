@@ -276,7 +276,10 @@ __device__ __forceinline__ float half_swap(float x) {
 // tiles (half the L2 -> LDS traffic per query).  Tiles sit in a 3-stage LDS ring; in its matrix block t group 0 issues K(t+2), group 1
 // V^T(t+1) (one tile ahead of its use in PV), by buffer_load ... lds with the key-length bound in the K descriptor (rows >= klen return
 // zeros: no per-lane address arithmetic in the loop at all).
-template <bool PRIO>
+// FREE: the free-running loop -- every wave runs S(t), softmax(t), P V(t) back to back on its own 32 queries and meets the others ONCE per
+// tile (the ring hand-off: tile t + 1 landed, tile t - 1 free); no stagger, no matrix / vector phases.  The two waves of a SIMD drift
+// apart by themselves, which is all the overlap the hardware gives (profiles/r03_mfma_valu_inwave_micro.log).
+template <bool PRIO, bool FREE = false>
 __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // 3 stages x [K h, K l, V^T h, V^T l] x 8 KiB
 
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i] + t * tstep, 0, 0, 0);
     };
     if (nt > 0) issue(0);
-    if (grp == 0 && nt > 1) issue(1);
+    if ((FREE || grp == 0) && nt > 1) issue(1);
 
     f16x8 qh[4], ql[4];
     {
@@ -349,20 +352,31 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                // tile 0 (and K(1)) are in LDS for everybody
-    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1's matrix block t runs beside group 0's vector block t
+    if (!FREE && grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1's matrix block t runs beside group 0's vector block t
     __builtin_amdgcn_sched_barrier(0);
 
     for (int t = 0; t <= nt; ++t) {
-        // ================= matrix block: PV(t-1), S(t)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the previous block (an iteration old): published by the barriers below
-        if (grp == 0) {
-            if (t + 2 < nt) issue(t + 2);
-        } else {
-            if (t + 1 < nt) issue(t + 1);
+        if constexpr (FREE) {
+            if (t == nt) break;
+            if (t > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t + 1 (issued an iteration ago)
+                __builtin_amdgcn_s_barrier();                      // tile t + 1 is in LDS for everybody; everybody is done with tile t - 1
+            }
+            if (t + 2 < nt) issue(t + 2);  // into the stage of tile t - 1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ================= matrix block: PV(t-1), S(t)   [FREE: S(t) here, PV(t) after the softmax]
+        if constexpr (!FREE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the previous block (an iteration old): published by the barriers below
+            if (grp == 0) {
+                if (t + 2 < nt) issue(t + 2);
+            } else {
+                if (t + 1 < nt) issue(t + 1);
+            }
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
-        if (t > 0) {
-            const unsigned char* st_v = smem2 + ((t - 1) % 3) * PL_STAGE + 2 * PL_TILE;
+        auto pv = [&](int tv) {
+            const unsigned char* st_v = smem2 + (tv % 3) * PL_STAGE + 2 * PL_TILE;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const f16x8 pfh = __builtin_bit_cast(f16x8, ph[c]), pfl = __builtin_bit_cast(f16x8, pl[c]);
@@ -376,7 +390,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pfh, ot[dt], 0, 0, 0);    // V_h h'
                 }
             }
-        }
+        };
+        if (!FREE && t > 0) pv(t - 1);
         if (t < nt) {
             const unsigned char* st_k = smem2 + (t % 3) * PL_STAGE;
 #pragma unroll
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!FREE) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= vector block: softmax(t) -> P planes
@@ -465,10 +480,14 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (FREE) {
+            pv(t);
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's stagger barrier
+    if (!FREE && grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's stagger barrier
 
 #pragma unroll
     for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
@@ -523,11 +542,14 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
         if (!configured) {
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>((flash_attn_pl2_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e2 == hipSuccess) e2 = e3;
             if (e1 != hipSuccess || e2 != hipSuccess) return cbx_set_error((int)(e1 != hipSuccess ? e1 : e2), "flash_attn_planes: cannot reserve %d B of LDS", lds);
             configured = true;
         }
         dim3 grid2((Tq + 255) / 256, n_heads, nz1);
         if (ver == 3) hipLaunchKernelGGL(flash_attn_pl2_kernel<true>, grid2, dim3(512), lds, (hipStream_t)stream, a);
+        else if (ver == 4) hipLaunchKernelGGL((flash_attn_pl2_kernel<false, true>), grid2, dim3(512), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(flash_attn_pl2_kernel<false>, grid2, dim3(512), lds, (hipStream_t)stream, a);
         return cbx_check_launch("flash_attn_planes");
     }

@@ -276,7 +276,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
                 for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(accc[i][j][r0 + r], 1.0f / CBX_F16_LO_SCALE, acc[i][j][r0 + r]) + bia;
                 if constexpr (ACT == CBX_ACT_GELU_ERF) {  // the activation is a template parameter: one epilogue body per kernel (instruction cache)
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                    for (int r = 0; r < 8; ++r) v[r] = cbx_gelu_erf(v[r]);
                 } else if constexpr (ACT == CBX_ACT_SILU) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = v[r] / (1.0f + __expf(-v[r]));

@@ -45,7 +45,7 @@ __device__ __forceinline__ void mlp_dma16(const __amdgpu_buffer_rsrc_t rs, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float v) { return cbx_gelu_erf(v); }
 
 #define MLP_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 

@@ -156,9 +156,22 @@ class FlowEngine:
         ops.linear(h, lw["w1"], f, bias=lw["b1"], act=ops.SILU)
         ops.linear(f, lw["w2"], x, bias=lw["b2"], residual=x)
 
-    @ops.on_device
+    # bytes of the materialised rel-pos score tensors (ac, bd, probabilities: 4 * T2^2 floats per head) one encoder call may hold; a
+    # larger batch is walked in row groups (rows are independent).  60 s of audio = 1.15 GB per utterance: of 288 GB, not a capacity
+    # problem, but a bound keeps one long VC batch from taking the allocator's whole pool.
+    ENC_SCORE_BYTES = int(float(os.environ.get("CBX_ENC_SCORE_GB", "32")) * 2 ** 30)
+
     def encode(self, tok, lens):
         """tok (B,N) int64 padded with any valid id, lens (B,) int32 -> mu (B, 2N, 80) channel-last."""
+        B, N = tok.shape
+        per_row = 8 * 4 * (2 * N) ** 2 * 4
+        group = max(1, min(B, self.ENC_SCORE_BYTES // max(per_row, 1)))
+        if group >= B:
+            return self._encode_rows(tok, lens)
+        return torch.cat([self._encode_rows(tok[i:i + group], lens[i:i + group]) for i in range(0, B, group)], 0)
+
+    @ops.on_device
+    def _encode_rows(self, tok, lens):
         dev, (B, N) = self.dev, tok.shape
         T2 = 2 * N
         f = lambda *s: torch.empty(*s, device=dev)

@@ -120,7 +120,7 @@ ops.split_planes(qkv[:, :1024], qkP)
 ops.split_planes(torch.randn(ROWS * 512, Tp, device=dev), vtP)
 fl = 4.0 * ROWS * 8 * T * T * 64
 line = f"flash attention: split {us_old:6.1f} us {fl / us_old / 1e6:6.1f} TF |"
-for ver in (1, 2, 3):
+for ver in (1, 2, 3, 4):
     ops.lib.cbx_set_attn_planes_version(ver)
     us_new = timeit(lambda: ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=ROWS, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125,
                                                   key_lens=lens))

@@ -35,6 +35,24 @@ def test_linear(dev, M, N, K):
         _close(out, fn(F.linear(x, w, b)) + r, 3e-5 * max(1.0, math.sqrt(K / 256)), f"linear act={act}")
 
 
+def test_gelu_erf_accuracy(dev):
+    """The branch-free erf of the GELU epilogue (cbx_common.h: cbx_gelu_erf) against fp64 on a dense grid over [-8, 8], the branch
+    seam |x| / sqrt 2 = 1, the clamp at 4 and denormal-small inputs: |error| <= 1.5e-7 max(1, |gelu|), i.e. the rounding level of F.gelu in fp32."""
+    from chatterbox_amd import ops
+    x = torch.cat([torch.linspace(-8, 8, 1 << 20), torch.linspace(1.40, 1.43, 4096), torch.linspace(5.6, 5.7, 4096),
+                   torch.tensor([0.0, 1e-30, -1e-30, 1e-8, 30.0, -30.0, 1e4, -1e4])])
+    x = x[: x.numel() // 8 * 8].reshape(-1, 8).contiguous()
+    out = torch.empty_like(x, device=dev)
+    ops.act(x.to(dev), out, ops.GELU_ERF)
+    ref = F.gelu(x.double())
+    err = (out.cpu().double() - ref).abs()
+    assert (err <= 1.5e-7 * ref.abs().clamp(min=1.0)).all(), f"gelu max abs err {err.max():.3e}"
+    big = x.abs() > 6
+    assert torch.equal(out.cpu()[big & (x > 0)], x[big & (x > 0)]) and (out.cpu()[big & (x < 0)].abs() == 0).all(), "saturation"
+    f32 = (F.gelu(x) .double() - ref).abs().max()
+    assert err.max() <= 2.5 * max(float(f32), 6e-8), f"not worse than 2.5x torch's own fp32 gelu ({f32:.3e})"
+
+
 def test_linear_strided_accumulate_and_second_output(dev):
     from chatterbox_amd import ops
     M, N, K = 200, 96, 64

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------
 // U = key rows per lane group in flight per step (env CBX_DA_U: 4 / 8 / 16).  The first step's K/V loads are issued BEFORE the
 // RoPE / LDS hand-off of q (they do not depend on it), so the q path's global round trip overlaps the cache stream.
-template <int DA_U>
+template <int DA_U, bool SPLIT>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) float q_s[64], k_new[64], v_new[64];
     __shared__ __attribute__((aligned(16))) float st_acc[16][64];
     __shared__ float st_m[16], st_l[16];
-    __shared__ int s_last;
+    __shared__ int s_last[1];
     const int row = blockIdx.y, head = blockIdx.x;
-    const int S = gridDim.z, sp = blockIdx.z;
+    const int S = SPLIT ? (int)gridDim.z : 1, sp = SPLIT ? (int)blockIdx.z : 0;  // !SPLIT: the one-workgroup form, compiled without any of the hand-off
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     const int pos = positions[row];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         }
     };
     // this workgroup's positions: [p_lo, p_hi), 16-aligned slices of [0, ctx); the new token (position pos) belongs to the last slice
-    const int slice = S > 1 ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
+    const int slice = SPLIT ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
     const int p_lo = sp * slice, p_hi = min(ctx, p_lo + slice);
     int p0 = p_lo + wid * 4 + sub;
     load_chunk(p0);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         q_s[lane] = qn * scale;
         k_new[lane] = kn;
         v_new[lane] = vn0;
-        if (sp == S - 1) {  // one workgroup appends the new token to the cache
+        if (!SPLIT || sp == S - 1) {  // one workgroup appends the new token to the cache
             kb[(long)pos * 64 + lane] = kn;
             vb[(long)pos * 64 + lane] = vn0;
         }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             den += f * st_l[i];
         }
     }
-    if (S > 1) {
+    if constexpr (SPLIT) {
         float* wsb = split_ws + ((long)(row * n_heads + head) * S) * 66;
         if (tid < 64) {
             wsb[sp * 66 + 2 + tid] = num;
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int ticket = __hip_atomic_fetch_add(&split_cnt[row * n_heads + head], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = ticket == S - 1;
-            if (s_last) {
+            s_last[0] = ticket == S - 1;
+            if (s_last[0]) {
                 __hip_atomic_store(&split_cnt[row * n_heads + head], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last[0]) return;
         if (tid < 64) {  // merge in split order (fixed: the result does not depend on who arrived last)
             // the per-split scalars through agent-scope loads (a uniform plain load may take the scalar cache, which the acquire does not cover)
             M = -INFINITY;
@@ -525,15 +525,19 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     // batched Llama path: 16 rows x 16 heads) 4 rows per lane group and step is best (profiles/r02_t3_decode_variants.log); small grids
     // keep 16 rows per step in flight and split the context (Turbo / Nano at batch 1: 11.8 us per launch at context 700 before).
     const int da_u = g_da_u > 0 ? g_da_u : (pairs < 128 ? 16 : 4);
-    if (da_u == 8)
-        hipLaunchKernelGGL(decode_attn_rope_kernel<8>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
-    else if (da_u == 16)
-        hipLaunchKernelGGL(decode_attn_rope_kernel<16>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
-    else
-        hipLaunchKernelGGL(decode_attn_rope_kernel<4>, grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, ld_qkv, o_ld,
-                           o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);
+#define CBX_DA_LAUNCH(U)                                                                                                                   \
+    do {                                                                                                                                   \
+        if (S > 1)                                                                                                                         \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,   \
+                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);                               \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,  \
+                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);                               \
+    } while (0)
+    if (da_u == 8) CBX_DA_LAUNCH(8);
+    else if (da_u == 16) CBX_DA_LAUNCH(16);
+    else CBX_DA_LAUNCH(4);
+#undef CBX_DA_LAUNCH
     return cbx_check_launch("decode_attn_rope");
 }
 

@@ -39,9 +39,18 @@ class T3TurboEngine:
                 wfc=tw(sd[p + "mlp.c_fc.weight"]), bfc=d(sd[p + "mlp.c_fc.bias"]),
                 wpr=tw(sd[p + "mlp.c_proj.weight"]), bpr=d(sd[p + "mlp.c_proj.bias"])))
         # decode path: lane-ordered packed images of the streamed weights (every wave-level load = 1 KiB contiguous, cbx.h)
+        # decode tuning (same knobs as T3Engine._TUNE; CBX_TURBO_TUNE="d_ks=4,d_nw=8,o_nw=8,half_tiles=0" overrides for an A/B):
+        # 8-column tiles for the two N = D projections (twice the workgroups), split-K factor / waves of the MLP projection
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1)
+        for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            self.tune[k.strip()] = int(v)
         for lw in self.layers:
             for k in ("wqkv", "wo", "wfc", "wpr"):
                 lw[k + "_pk"] = ops.pack_gemv_weight(lw[k])
+            if self.tune["half_tiles"]:
+                lw["wo_pk8"] = ops.pack_gemv_weight(lw["wo"], half_tile=True)
+                lw["wpr_pk8"] = ops.pack_gemv_weight(lw["wpr"], half_tile=True)
         self.lnf = (d(sd["tfmr.ln_f.weight"]), d(sd["tfmr.ln_f.bias"]))
         self.decode_mode = os.environ.get("CBX_T3_DECODE", "v2")
         self.wpe = d(sd["tfmr.wpe.weight"])
@@ -89,8 +98,9 @@ class T3TurboEngine:
         bias + residual in its epilogue, the MLP projection emits split-K partial images that the next consumer sums into its operand
         (same structure as T3Engine._forward_decode_v2)."""
         ws, D = st["dws"], self.D
-        B, dks = st["B"], 4
-        cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"]
+        B, tn = st["B"], self.tune
+        dks, ht = tn["d_ks"], bool(tn["half_tiles"])
+        cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"][:dks]
         pk = dict(w_packed=True, x_packed=True, M=B)
         ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.wpe, ids2=st["positions"], out_packed=True)
         red = {}
@@ -99,10 +109,10 @@ class T3TurboEngine:
             if red:
                 cur, nxt = nxt, cur
             ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ops.gemv(att, lw["wo_pk"], cur, N=D, K=D, nw=8, bias=lw["bo"], res=cur, out_packed=True, **pk)
+            ops.gemv(att, lw["wo_pk8"] if ht else lw["wo_pk"], cur, N=D, K=D, nw=tn["o_nw"], bias=lw["bo"], res=cur, out_packed=True, half_tile=ht, **pk)
             ops.gemv(cur, lw["wfc_pk"], g, N=4 * D, K=D, nw=8, norm_w=lw["ln2"][0], ln_cw=lw["c_fc"][0], ln_cb=lw["c_fc"][1],
                      act=ops.GELU_TANH, out_packed=True, **pk)
-            ops.gemv(g, lw["wpr_pk"], pd, N=D, K=4 * D, ksplit=dks, nw=8, bias=lw["bpr"], out_packed=True, **pk)
+            ops.gemv(g, lw["wpr_pk8"] if ht else lw["wpr_pk"], pd, N=D, K=4 * D, ksplit=dks, nw=tn["d_nw"], bias=lw["bpr"], out_packed=True, half_tile=ht, **pk)
             red = dict(xpart=pd, x_out=nxt)
         red["x_out"] = None
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1], **red, **pk)

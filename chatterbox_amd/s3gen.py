@@ -356,7 +356,9 @@ class FlowEngine:
 
     def _planes_ok(self, rows, T):
         """The plane-format path serves the f16x3 numerics (precision 16) with 31-bit operand offsets; anything else runs the fp32-operand kernels."""
-        return self.use_planes and ops.GEMM_PRECISION == 16 and rows * T > 32 and T % 2 == 0 and (T + 8) * 2048 * 2 < 2 ** 31
+        # (cbx_gemm_planes addresses one batch of an operand / output with 32-bit byte offsets: the widest plane tensor, the feed-forward
+        # intermediate, has 4096-byte rows and is passed as ONE batch of rows * T rows)
+        return self.use_planes and ops.GEMM_PRECISION == 16 and rows * T > 32 and T % 2 == 0 and (rows * T + 512) * 4096 < 2 ** 31
 
     def _time_bias(self, t_vals, r_vals=None):
         """SinusoidalPosEmb -> TimestepEmbedding (-> meanflow mixer) -> every ResNet's Mish+Linear (matcha/decoder.py:20-29,

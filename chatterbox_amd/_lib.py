@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 7  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 8  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -45,6 +45,7 @@ class GemmPlParams(ctypes.Structure):
         ("act", c_int), ("act_slope", c_float), ("alpha", c_float),
         ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long), ("w_s1", c_long),
         ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long), ("reserved0", c_int),
+        ("PT", c_f), ("pt_n0", c_int), ("pt_T", c_int), ("pt_ld", c_long), ("pt_lo", c_long), ("pt_zs", c_long),  # ABI v8
     ]
 
 

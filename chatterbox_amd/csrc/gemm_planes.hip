@@ -245,8 +245,12 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         const_cast<float*>(p.R ? p.R + (long)z * p.r_s1 : nullptr), 0, p.R ? (int)((((long)Mrem - 1) * p.ldr + p.N) * 4) : 0, 0x00020000);
     // plane output: the l plane lies p_lo halves after the h plane of the same row, so one descriptor covers both
     const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(
-        p.P ? reinterpret_cast<_Float16*>(p.P) + (long)z * p.p_s1 : nullptr, 0, p.P ? (int)((((long)Mrem - 1) * p.ldp + p.p_lo + p.N) * 2) : 0, 0x00020000);
-    const bool hasC = p.C != nullptr, hasP = p.P != nullptr, hasR = p.R != nullptr;
+        p.P ? reinterpret_cast<_Float16*>(p.P) + (long)z * p.p_s1 : nullptr, 0, p.P ? (int)((((long)Mrem - 1) * p.ldp + p.p_lo + (p.PT ? p.pt_n0 : p.N)) * 2) : 0, 0x00020000);
+    // transposed plane output (V^T of the fused q | k | v projection): whole tiles, never a part of one (pt_n0 % 256 == 0)
+    const bool vt_tile = p.PT != nullptr && n0 >= p.pt_n0;
+    const __amdgpu_buffer_rsrc_t t_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<_Float16*>(p.PT), 0, p.PT ? (int)((((long)(p.M / (p.pt_T > 0 ? p.pt_T : 1)) - 1) * p.pt_zs + ((long)(p.N - p.pt_n0) - 1) * p.pt_ld + p.pt_lo + p.pt_T) * 2) : 0, 0x00020000);
+    const bool hasC = p.C != nullptr && !vt_tile, hasP = p.P != nullptr && !vt_tile, hasR = p.R != nullptr && !vt_tile;
     const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4, ldp2 = (int)p.ldp * 2;
     const bool odd = lr & 1;
     float amax = 0.f;
@@ -290,6 +294,26 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
                     for (int r = 0; r < 8; ++r)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), c_rs, co, (((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * ldc4, 0);
                 }
+                if (vt_tile) {
+                    // registers 4q .. 4q+3 of this pass are FOUR CONSECUTIVE ROWS (tokens) of the lane's column: the transposed image wants
+                    // exactly that -- 4 halves of the h plane and 4 of the l plane per 8-byte store, no lane exchange.  pt_T % 4 == 0 keeps the four
+                    // tokens inside one group of pt_T rows.
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        unsigned h01, l01, h23, l23;
+                        cbx_split2(v[4 * q], v[4 * q + 1], h01, l01);
+                        cbx_split2(v[4 * q + 2], v[4 * q + 3], h23, l23);
+                        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[4 * q]), "v"(v[4 * q + 1]));
+                        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[4 * q + 2]), "v"(v[4 * q + 3]));
+                        const int m = mb + 8 * (r0 / 4 + q);
+                        const int zz = m / p.pt_T, t = m - zz * p.pt_T;
+                        const long eo = (long)zz * p.pt_zs + (long)(n - p.pt_n0) * p.pt_ld + t;
+                        const int bo = (nok && m < p.M) ? (int)(eo * 2) : OOB;
+                        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2v{h01, h23}, t_rs, bo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2v{l01, l23}, t_rs, bo + (int)p.pt_lo * 2, 0, 0);
+                    }
+                }
                 if (hasP) {
                     // The lane pair (even, odd column) owns columns n, n + 1 of every row.  Of each register pair (rows m, m + 1) the even lane
                     // converts row m and the odd lane row m + 1: one exchange gives each lane both columns of its row, which it splits into the h
@@ -312,7 +336,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
             }
         }
     }
-        if (hasP && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+        if ((hasP || vt_tile) && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
     }  // tile loop
 }
 
@@ -399,6 +423,7 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE((p.lda | p.a_lo | p.a_s1 | p.ldw | p.w_lo) % 8 == 0 && (((uintptr_t)p.A | (uintptr_t)p.W) & 15) == 0,
                 "gemm_planes: operand planes must be 16-byte aligned (strides / plane offsets multiples of 8 halves)");
     CBX_REQUIRE(!p.P || ((p.N | p.ldp | p.p_lo | p.p_s1) % 2 == 0 && ((uintptr_t)p.P & 3) == 0), "gemm_planes: plane output needs even N / strides");
+    CBX_REQUIRE(p.PT || (p.pt_n0 == 0 && p.pt_T == 0), "gemm_planes: pt_n0 / pt_T without PT");
     CBX_REQUIRE((!p.C || ((long)p.M * p.ldc + p.N) * 4 < 0x7fffffffL) && (!p.R || ((long)p.M * p.ldr + p.N) * 4 < 0x7fffffffL) &&
                     (!p.P || ((long)p.M * p.ldp + p.p_lo + p.N) * 2 < 0x7fffffffL),
                 "gemm_planes: one batch of an output / residual must span less than 2 GiB (32-bit buffer offsets)");
@@ -407,7 +432,17 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE(((long)p.Tin + p.taps * p.dil + 1) * p.lda * 2 < 0x7fffffffL && (long)(p.N + 256) * p.ldw * 2 < 0x7fffffffL &&
                     (long)(p.pad_left + 1) * p.lda * 2 < 0x3fffffffL,
                 "gemm_planes: one batch of an operand must span less than 2 GiB (32-bit buffer offsets)");
-    CBX_REQUIRE((!p.C || p.ldc >= p.N) && (!p.R || p.ldr >= p.N) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + p.N)),
+    const int Np = p.PT ? p.pt_n0 : p.N;  // columns that go to C / P / R
+    if (p.PT) {
+        CBX_REQUIRE(p.P && !p.C && !p.R && p.act == CBX_ACT_NONE && p.nz1 == 1 && p.taps == 1 && p.stride == 1 && !p.lens,
+                    "gemm_planes: the transposed column range serves a plain Linear with plane output (no C / R / activation / batches / conv)");
+        CBX_REQUIRE(p.pt_n0 > 0 && p.pt_n0 % 256 == 0 && p.pt_n0 < p.N && p.pt_T > 0 && p.pt_T % 4 == 0 && p.M % p.pt_T == 0,
+                    "gemm_planes: pt_n0 %% 256 == 0, 0 < pt_n0 < N, pt_T %% 4 == 0, M %% pt_T == 0 (got pt_n0=%d pt_T=%d M=%d N=%d)", p.pt_n0, p.pt_T, p.M, p.N);
+        CBX_REQUIRE((p.pt_ld | p.pt_lo | p.pt_zs) % 4 == 0 && ((uintptr_t)p.PT & 7) == 0 && p.pt_ld >= p.pt_T && p.pt_lo > 0,
+                    "gemm_planes: transposed planes need 8-byte alignment (pt_ld, pt_lo, pt_zs multiples of 4 halves)");
+        CBX_REQUIRE(((long)(p.M / p.pt_T) * p.pt_zs + (long)(p.N - p.pt_n0) * p.pt_ld + p.pt_lo) * 2 < 0x7fffffffL, "gemm_planes: the transposed output must span less than 2 GiB");
+    }
+    CBX_REQUIRE((!p.C || p.ldc >= Np) && (!p.R || p.ldr >= Np) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + Np)),
                 "gemm_planes: rows must not overlap (ldc, ldr >= N; plane output rows hold [h | l]: ldp >= p_lo + N)");
     hipStream_t st = (hipStream_t)stream;
     const int force = g_pl_tile;

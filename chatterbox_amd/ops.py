@@ -269,8 +269,9 @@ def layernorm_planes(x, w, b, out, eps=1e-5, act=NONE, post_add=None, scale=1.0)
 
 
 def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, act_slope=0.0, alpha=1.0, lens=None, Cin=0, taps=1, dil=1,
-                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0):
-    """Raw access to cbx_gemm_planes (include/cbx.h): A, W, P are Planes operands, C / R fp32 tensors (their data_ptr() is the base)."""
+                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0, PT=None, pt_n0=0, pt_T=0, pt_zs=0):
+    """Raw access to cbx_gemm_planes (include/cbx.h): A, W, P are Planes operands, C / R fp32 tensors (their data_ptr() is the base).
+    PT (Planes over (groups * (N - pt_n0), >= pt_T) rows): output columns n >= pt_n0 are written TRANSPOSED per group of pt_T rows."""
     p = GemmPlParams()
     p.A, p.W, p.C, p.P = A.ptr, W.ptr, _p(C), None if P is None else P.ptr
     p.bias, p.R, p.lens = _p(bias), _p(R), _p(lens)
@@ -285,6 +286,8 @@ def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, a
     if P is not None:
         p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
     p.reserved0 = GEMM_DIAG
+    if PT is not None:
+        p.PT, p.pt_n0, p.pt_T, p.pt_ld, p.pt_lo, p.pt_zs = PT.ptr, pt_n0, pt_T, PT.ld, PT.lo, pt_zs
     _timed("gemm_planes", 2.0 * M * N * K * nz1, 4.0 * nz1 * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_planes(ctypes.byref(p), _stream()), "cbx_gemm_planes"))
 

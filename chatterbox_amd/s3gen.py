@@ -116,6 +116,7 @@ class FlowEngine:
         # ff1 + GELU + ff2 + residual in one launch (cbx_mlp_planes): measured EQUAL to the two GEMMs it replaces at the bench shape (81.6 vs 80 us:
         # with 64 tokens per workgroup it re-streams W1 / W2 through L2 -> LDS once per token tile, 640 MB per call) -- opt-in, not the default
         self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
+        self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None
 
     # ------------------------------------------------------------------ conformer encoder
@@ -287,7 +288,8 @@ class FlowEngine:
             def stage(s):
                 d = dict(c1=sp(s["c1"][0]), c2=sp(s["c2"][0]), res=sp(s["res"][0]), tb=[])
                 for t in s["tb"]:  # q | k rows of the fused projection; the v rows are the A operand of the swapped (V^T) product
-                    d["tb"].append(dict(wqk=sp(t["wqkv"][:1024]), wv=sp(t["wqkv"][1024:]), wo=sp(t["wo"]), w1=sp(t["w1"]), w2=sp(t["w2"])))
+                    wqkv = sp(t["wqkv"])  # one image; q | k rows and v rows are row ranges of it
+                    d["tb"].append(dict(wqkv=wqkv, wqk=wqkv.rows_view(0, 1024), wv=wqkv.rows_view(1024, 512), wo=sp(t["wo"]), w1=sp(t["w1"]), w2=sp(t["w2"])))
                 if "tail" in s:
                     d["tail"] = sp(s["tail"][0])
                 return d
@@ -314,9 +316,13 @@ class FlowEngine:
         M = rows * T
         x2, hP, qkP, vtP, attP, ffP = x.view(M, 256), ws["hP"], ws["qkP"], ws["vtP"], ws["attP"], ws["ffP"]
         ops.layernorm_planes(x2, tw["n1"][0], tw["n1"][1], hP, 1e-5)
-        ops.linear_planes(hP, pw["wqk"], outp=qkP)
-        # V^T[z] (512 x T) = W_v h[z]^T: the same products with the operands swapped, so the store is the transposed tile
-        ops.gemm_planes(pw["wv"], hP, M=512, N=T, K=256, nz1=rows, w_s1=T * hP.ld, P=vtP, p_s1=512 * vtP.ld)
+        if self.fused_qkv and T % 4 == 0:
+            # to_q | to_k | to_v as ONE Linear: the q | k columns go to qkP, the v columns are stored transposed (V^T[z] = 512 x T per row group of T)
+            ops.gemm_planes(hP, pw["wqkv"], M=M, N=1536, K=256, P=qkP, PT=vtP, pt_n0=1024, pt_T=T, pt_zs=512 * vtP.ld)
+        else:
+            ops.linear_planes(hP, pw["wqk"], outp=qkP)
+            # V^T[z] (512 x T) = W_v h[z]^T: the same products with the operands swapped, so the store is the transposed tile
+            ops.gemm_planes(pw["wv"], hP, M=512, N=T, K=256, nz1=rows, w_s1=T * hP.ld, P=vtP, p_s1=512 * vtP.ld)
         ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=rows, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125, key_lens=lens)
         ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
         ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)

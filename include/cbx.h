@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 7  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 8  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable */
@@ -119,6 +119,12 @@ typedef struct cbx_gemm_pl_t {
     long ldr, r_s1;                 /* floats */
     long ldp, p_lo, p_s1;           /* halves */
     int reserved0;                  /* 0 (diagnostic switches of a -DCBX_DIAG build) */
+    /* ABI v8 -- transposed plane output for a column range (the V^T operand of cbx_flash_attn_planes produced by the SAME launch as the
+     * q | k projection: to_q / to_k / to_v of matcha/transformer.py:243-316 as ONE Linear over [Wq; Wk; Wv]).  PT != NULL: output columns
+     * n >= pt_n0 are not written to C / P; element (m, n) goes to PT[(m / pt_T) * pt_zs + (n - pt_n0) * pt_ld + (m % pt_T)] (h plane; the
+     * l plane pt_lo halves further), i.e. one (N - pt_n0) x pt_T matrix per group of pt_T rows.  Needs P for the columns below pt_n0,
+     * pt_n0 % 256 == 0, pt_T % 4 == 0, M % 4 == 0, no C / R / activation, nz1 == 1. */
+    void* PT; int pt_n0, pt_T; long pt_ld, pt_lo, pt_zs;   /* halves */
 } cbx_gemm_pl_t;
 int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
 /* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */

@@ -124,6 +124,51 @@ def test_gemm_planes_conv_and_swapped_product(dev, tile, persist):
         ops.lib.cbx_set_planes_persist(1)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 4, 9, 14, 21])
+@pytest.mark.parametrize("persist", [1, 8, 0])
+def test_gemm_planes_transposed_column_range(dev, tile, persist):
+    """to_q | to_k | to_v of a transformer block as ONE launch (ABI v8): columns below pt_n0 go to the q | k planes, the v columns are stored
+    transposed per row group of T (the V^T operand of cbx_flash_attn_planes).  Against fp64 on the exact plane values, against the two-launch
+    form (q | k Linear + swapped V^T product), pad columns of V^T untouched, ragged last row tile."""
+    from chatterbox_amd import ops
+    try:
+        ops.lib.cbx_set_planes_tile(tile)
+        ops.lib.cbx_set_planes_persist(persist)
+        for Z, T in ((3, 200), (2, 1000), (1, 36)):
+            M, K, N, n0 = Z * T, 256, 1536, 1024
+            Tp = (T + 7) // 8 * 8
+            h, w = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K))
+            hP, wP = ops.split_planes(h.to(dev)), ops.split_planes(w.to(dev))
+            qkP, vtP = ops.Planes(M, n0, dev), ops.Planes(Z * 512, Tp, dev, zero=True)
+            ops.gemm_planes(hP, wP, M=M, N=N, K=K, P=qkP, PT=vtP, pt_n0=n0, pt_T=T, pt_zs=512 * vtP.ld)
+            ref = F.linear(_planes_exact(h), _planes_exact(w))
+            _close(qkP.float(), ref[:, :n0], 3e-5, f"q|k columns, tile {tile} Z {Z} T {T}")
+            vt = vtP.float().view(Z, 512, Tp)
+            _close(vt[:, :, :T], ref[:, n0:].view(Z, T, 512).transpose(1, 2), 3e-5, f"V^T, tile {tile} Z {Z} T {T}")
+            assert float(vt[:, :, T:].abs().max() if Tp > T else 0.0) == 0.0, "pad keys of V^T stay zero"
+            # the two-launch form computes the same products (cross terms in the other order): equal to rounding of the low accumulator
+            qk2, vt2 = ops.Planes(M, n0, dev), ops.Planes(Z * 512, Tp, dev, zero=True)
+            ops.linear_planes(hP, wP.rows_view(0, n0), outp=qk2)
+            ops.gemm_planes(wP.rows_view(n0, 512), hP, M=512, N=T, K=K, nz1=Z, w_s1=T * hP.ld, P=vt2, p_s1=512 * vt2.ld)
+            assert torch.equal(qkP.t, qk2.t), "q | k planes identical to the separate Linear"
+            assert (vtP.float() - vt2.float()).abs().max() <= 1e-6, "V^T equal to the swapped product"
+    finally:
+        ops.lib.cbx_set_planes_tile(0)
+        ops.lib.cbx_set_planes_persist(1)
+
+
+def test_gemm_planes_transposed_rejects_bad_arguments(dev):
+    from chatterbox_amd import ops
+    h, w = ops.split_planes(_r((200, 256), 1).to(dev)), ops.split_planes(_r((1536, 256), 2).to(dev))
+    qk, vt = ops.Planes(200, 1024, dev), ops.Planes(512, 104, dev, zero=True)
+    with pytest.raises(RuntimeError, match="pt_T"):
+        ops.gemm_planes(h, w, M=200, N=1536, K=256, P=qk, PT=vt, pt_n0=1024, pt_T=50, pt_zs=512 * vt.ld)   # 50 % 4 != 0
+    with pytest.raises(RuntimeError, match="pt_n0"):
+        ops.gemm_planes(h, w, M=200, N=1536, K=256, P=qk, PT=vt, pt_n0=1000, pt_T=100, pt_zs=512 * vt.ld)  # not a multiple of 256
+    with pytest.raises(RuntimeError, match="plain Linear"):
+        ops.gemm_planes(h, w, M=200, N=1536, K=256, P=qk, PT=vt, pt_n0=1024, pt_T=100, pt_zs=512 * vt.ld, act=ops.SILU)
+
+
 def test_layernorm_planes(dev):
     from chatterbox_amd import ops
     M, C = 1003, 256

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
                                                                int n_heads, long ld_qkv, long o_ld, int o_packed, long row_stride,
-                                                               long head_stride, float scale, float* split_ws, int* split_cnt) {
+                                                               long head_stride, float scale, float* split_ws, int* split_cnt,
+                                                               int split_min_ctx) {
     // gridDim.z = S > 1: the context of a (row, head) is split over S workgroups (on S CUs: one workgroup cannot pull a long context
     // faster than its CU's memory path, 50-60 GB/s); each leaves {max, sum, 64 numerators} in split_ws and the LAST to arrive (a ticket on
     // split_cnt, agent-scope release before it, acquire after it: cdna_hip_programming.md guideline 16) merges them in split order.
@@ -271,7 +272,12 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     __shared__ float st_m[16], st_l[16];
     __shared__ int s_last[1];
     const int row = blockIdx.y, head = blockIdx.x;
-    const int S = SPLIT ? (int)gridDim.z : 1, sp = SPLIT ? (int)blockIdx.z : 0;  // !SPLIT: the one-workgroup form, compiled without any of the hand-off
+    // !SPLIT: the one-workgroup form, compiled without any of the hand-off.  SPLIT: a row whose context is shorter than split_min_ctx is
+    // still walked by ONE workgroup (split 0; the others leave at once): the hand-off costs ~5 us on the critical path (release, ticket,
+    // acquire, merge), more than the 1-2 round trips a short context takes (measured: batch-1 Llama decode +15 % with an unconditional split)
+    const int sp = SPLIT ? (int)blockIdx.z : 0;
+    const int S = SPLIT && positions[blockIdx.y] + 1 >= split_min_ctx ? (int)gridDim.z : 1;
+    if (SPLIT && S == 1 && sp != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     const int pos = positions[row];
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         }
     };
     // this workgroup's positions: [p_lo, p_hi), 16-aligned slices of [0, ctx); the new token (position pos) belongs to the last slice
-    const int slice = SPLIT ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
+    const int slice = S > 1 ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
     const int p_lo = sp * slice, p_hi = min(ctx, p_lo + slice);
     int p0 = p_lo + wid * 4 + sub;
     load_chunk(p0);
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         q_s[lane] = qn * scale;
         k_new[lane] = kn;
         v_new[lane] = vn0;
-        if (!SPLIT || sp == S - 1) {  // one workgroup appends the new token to the cache
+        if (sp == S - 1) {  // one workgroup appends the new token to the cache
             kb[(long)pos * 64 + lane] = kn;
             vb[(long)pos * 64 + lane] = vn0;
         }
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             den += f * st_l[i];
         }
     }
-    if constexpr (SPLIT) {
+    if (SPLIT && S > 1) {
         float* wsb = split_ws + ((long)(row * n_heads + head) * S) * 66;
         if (tid < 64) {
             wsb[sp * 66 + 2 + tid] = num;
@@ -503,14 +509,22 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     return 0;
 }
 constexpr int DA_MAX_SPLIT = 8;
+static int g_da_split_min = getenv("CBX_DA_SPLIT_MIN") ? atoi(getenv("CBX_DA_SPLIT_MIN")) : 1024;
+extern "C" int cbx_set_decode_attn_split_min(int min_ctx) {
+    CBX_REQUIRE(min_ctx >= 1, "decode_attn split threshold must be >= 1");
+    g_da_split_min = min_ctx;
+    return 0;
+}
 
 extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                                         float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
     CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
     CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
-    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: by grid size)
+    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: the default, 4)
     static const int no_split = getenv("CBX_DA_NO_SPLIT") ? atoi(getenv("CBX_DA_NO_SPLIT")) : 0;
+    // contexts shorter than this are walked by one workgroup even on a split grid (the hand-off costs more than it saves below ~3 round trips)
+    const int split_min = g_da_split_min;
     const long pairs = (long)rows * n_heads;
     int d = 0, S = 1;
     if (!no_split && pairs < 128 && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 && g_da_pairs[d] >= pairs) {
@@ -521,18 +535,19 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     hipStream_t st = (hipStream_t)stream;
     float* ws = S > 1 ? g_da_ws[d] : nullptr;
     int* cnt = S > 1 ? g_da_cnt[d] : nullptr;
-    // One workgroup per (row, head[, split]) walks its context: a step costs a memory round trip whatever it carries.  With >= 128 workgroups (the
-    // batched Llama path: 16 rows x 16 heads) 4 rows per lane group and step is best (profiles/r02_t3_decode_variants.log); small grids
-    // keep 16 rows per step in flight and split the context (Turbo / Nano at batch 1: 11.8 us per launch at context 700 before).
-    const int da_u = g_da_u > 0 ? g_da_u : (pairs < 128 ? 16 : 4);
+    // One workgroup per (row, head[, split]) walks its context, 4 key rows per 16-lane group and step: best on the batched Llama grid
+    // (16 rows x 16 heads, profiles/r02_t3_decode_variants.log) AND on the small grids of batch 1 -- a same-box A/B of Multilingual /
+    // Nano / Turbo at batch 1 (profiles/r03_decode_attn_b1_ab.log) has 4 rows + no split ahead of 16 rows in flight and of a split
+    // at contexts of 200-700 by 1-4 %; the split only engages on contexts >= cbx_set_decode_attn_split_min (1024).
+    const int da_u = g_da_u > 0 ? g_da_u : 4;
 #define CBX_DA_LAUNCH(U)                                                                                                                   \
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
             hipLaunchKernelGGL((decode_attn_rope_kernel<U, true>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,   \
-                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);                               \
+                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
         else                                                                                                                               \
             hipLaunchKernelGGL((decode_attn_rope_kernel<U, false>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,  \
-                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt);                               \
+                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
     } while (0)
     if (da_u == 8) CBX_DA_LAUNCH(8);
     else if (da_u == 16) CBX_DA_LAUNCH(16);

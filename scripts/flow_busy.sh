@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage: [CBX_B=1] [CBX_N=25] bash scripts/flow_busy.sh
 # GPU-busy fraction of the flow stage: sum of kernel durations (rocprofv3 kernel trace) of 4 flow + HiFT passes next to their wall time.
 mkdir -p gpurun_out/r03b
 cd /tmp && export TMPDIR=/tmp

@@ -8,7 +8,7 @@ from chatterbox_amd.s3gen import FlowEngine
 dev = torch.device("cuda:0")
 sd = synth.s3gen_state_dict(0)
 flow, hift = FlowEngine(sd, dev), HiFTEngine(sd, dev)
-B, N = 8, 250
+B, N = int(os.environ.get("CBX_B", "8")), int(os.environ.get("CBX_N", "250"))
 toks = torch.stack([synth.speech_tokens(N, seed=b) for b in range(B)]).to(dev)
 lens = torch.full((B,), N, dtype=torch.int32, device=dev)
 ref = synth.s3gen_ref()

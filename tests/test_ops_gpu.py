@@ -541,14 +541,16 @@ def test_decode_attn_rope_fused(dev):
         _close(kc[r, :, :n], kc0[r, :, :n], 0.0, "cache untouched")
 
 
+@pytest.mark.parametrize("split_min", [1, 512])
 @pytest.mark.parametrize("rows,H,rope", [(1, 12, False), (1, 16, True), (2, 16, True), (5, 12, False)])
-def test_decode_attn_rope_split_context(dev, rows, H, rope):
+def test_decode_attn_rope_split_context(dev, rows, H, rope, split_min):
     """rows * heads < 128 (Turbo / Nano at small batch): the context of a (row, head) is walked by up to 8 workgroups and merged by
     the last to arrive.  Every context length 1..40 and a few long ones, launched back to back (the arrival counters reset
     themselves), against torch SDPA; and against the one-workgroup form of the same kernel."""
     from chatterbox_amd import ops
     from oracle import ref_torch as O
     ops.ensure_decode_attn_workspace(dev)
+    ops.lib.cbx_set_decode_attn_split_min(split_min)  # 1: every context is split; 512: only the long ones, per row (the default is 1024)
     maxp = 1024
     kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
     cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
@@ -570,6 +572,7 @@ def test_decode_attn_rope_split_context(dev, rows, H, rope):
             _close(out[r].view(H, 64), ref[:, 0], 2e-5, f"split decode attention ctx {m + 1} row {r}")
             _close(kc[r, :, m], k[r], 1e-6, "k appended")
             _close(vc[r, :, m], v[r], 0.0, "v appended")
+    ops.lib.cbx_set_decode_attn_split_min(1024)
     assert int(ops._DA_WS[torch.device(dev).index or 0][1].abs().sum()) == 0, "arrival counters are back at zero"
 
 

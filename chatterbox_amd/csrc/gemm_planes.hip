@@ -474,6 +474,10 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 23: return launch_pl<256, 128, 4, 2, 32, 3, true>(p, st);   // 144 KB, 64x64 per wave
         case 24: return launch_pl<128, 128, 4, 2, 32, 2, true>(p, st);   // 64 KB
         case 25: return launch_pl<128, 128, 2, 4, 32, 4, true>(p, st);   // 4 stages, 128 KB
+        // 16-wave workgroups (1024 threads, one per CU, 4 waves per SIMD): 25 % less operand traffic per FLOP than 128 x 128 at the same 32 x 64 wave tile
+        case 26: return launch_pl<256, 128, 8, 2, 32>(p, st);      // 96 KB
+        case 27: return launch_pl<256, 128, 8, 2, 32, 3>(p, st);   // 144 KB
+        case 28: return launch_pl<128, 256, 4, 4, 32>(p, st);      // 96 KB
         default: break;
     }
     // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere.  The loader-wave form

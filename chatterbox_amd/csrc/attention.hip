@@ -509,7 +509,7 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     return 0;
 }
 constexpr int DA_MAX_SPLIT = 8;
-static int g_da_split_min = getenv("CBX_DA_SPLIT_MIN") ? atoi(getenv("CBX_DA_SPLIT_MIN")) : 1024;
+static int g_da_split_min = getenv("CBX_DA_SPLIT_MIN") ? atoi(getenv("CBX_DA_SPLIT_MIN")) : 512;
 extern "C" int cbx_set_decode_attn_split_min(int min_ctx) {
     CBX_REQUIRE(min_ctx >= 1, "decode_attn split threshold must be >= 1");
     g_da_split_min = min_ctx;
@@ -538,7 +538,8 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     // One workgroup per (row, head[, split]) walks its context, 4 key rows per 16-lane group and step: best on the batched Llama grid
     // (16 rows x 16 heads, profiles/r02_t3_decode_variants.log) AND on the small grids of batch 1 -- a same-box A/B of Multilingual /
     // Nano / Turbo at batch 1 (profiles/r03_decode_attn_b1_ab.log) has 4 rows + no split ahead of 16 rows in flight and of a split
-    // at contexts of 200-700 by 1-4 %; the split only engages on contexts >= cbx_set_decode_attn_split_min (1024).
+    // at contexts of 200-700 by 1-4 %; the split engages on contexts >= cbx_set_decode_attn_split_min (512): a 1000-token Turbo generation
+    // (contexts to ~1450) decodes at 1.03 ms / token with it, 1.20 without (profiles/r03_turbo_long_context.log).
     const int da_u = g_da_u > 0 ? g_da_u : 4;
 #define CBX_DA_LAUNCH(U)                                                                                                                   \
     do {                                                                                                                                   \

@@ -45,29 +45,6 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return r;
 }
 
-// NS block-wide sums at once, each in block_sum's order (lane tree, then waves 0..15), so a 16-way bisection round sees exactly the
-// values 15 rounds of block_sum would have produced -- in 3 barriers instead of 30.  red: (NT / 64 + 1) * NS floats.
-constexpr int NS = 15;
-__device__ __forceinline__ void block_sum_multi(float (&v)[NS], float* red) {
-#pragma unroll
-    for (int t = 0; t < NS; ++t) v[t] = wave_sum(v[t]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int t = 0; t < NS; ++t) red[(threadIdx.x >> 6) * NS + t] = v[t];
-    }
-    __syncthreads();
-    if (threadIdx.x < NS) {
-        float r = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT / 64; ++i) r += red[i * NS + threadIdx.x];
-        red[(NT / 64) * NS + threadIdx.x] = r;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NS; ++t) v[t] = red[(NT / 64) * NS + t];
-}
-
 // HF RepetitionPenaltyLogitsProcessor on the ids seen so far
 __device__ __forceinline__ void rep_penalty(float* l, const unsigned char* seen, int V, float pen) {
     for (int i = threadIdx.x; i < V; i += NT)
@@ -92,29 +69,15 @@ __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
     }
     z = block_sum(z, red);
     const float budget = (1.0f - top_p) * z;
-    unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget < mass{e <= hi}
-    while (lo + 1 < hi) {  // 16-way rounds: thresholds lo + i * stp, i = 1..15 (those below hi); the predicate is monotone
-        const unsigned stp = (hi - lo + 15u) / 16u;
-        float sv[NS];
+    unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget
+    while (lo + 1 < hi) {
+        unsigned mid = lo + (hi - lo) / 2;
+        float thr = __uint_as_float(mid);
+        float s = 0.f;
 #pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const unsigned long long mt = (unsigned long long)lo + (unsigned long long)(t + 1) * stp;
-            const float thr = __uint_as_float(mt < hi ? (unsigned)mt : hi - 1u);  // clipped thresholds repeat a valid one
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) a += e[j] <= thr ? e[j] : 0.f;
-            sv[t] = a;
-        }
-        block_sum_multi(sv, red);
-        unsigned nlo = lo, nhi = hi;
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const unsigned long long mt = (unsigned long long)lo + (unsigned long long)(t + 1) * stp;
-            if (mt >= hi) continue;
-            if (sv[t] <= budget) nlo = (unsigned)mt;
-            else if ((unsigned)mt < nhi) nhi = (unsigned)mt;
-        }
-        lo = nlo, hi = nhi;
+        for (int j = 0; j < EPT; ++j) s += e[j] <= thr ? e[j] : 0.f;
+        s = block_sum(s, red);
+        if (s <= budget) lo = mid; else hi = mid;
     }
     const float cut = __uint_as_float(lo);
     __syncthreads();
@@ -140,29 +103,14 @@ __device__ void top_k_filter(float* l, int V, int k, float* red) {
         const int i = threadIdx.x + j * NT;
         ky[j] = i < V ? key(l[i]) : 0u;
     }
-    unsigned lo = 0u, hi = 0xFFFFFFFFu;  // largest key with count{key(l) >= key} >= k: P(lo) holds, P(hi + 1) does not
-    while (lo < hi) {  // 16-way rounds on the monotone predicate P(mid) = count{key >= mid} >= k
-        const unsigned stp = (unsigned)(((unsigned long long)(hi - lo) + 15ull) / 16ull);
-        float cv[NS];
+    unsigned lo = 0u, hi = 0xFFFFFFFFu;  // largest key with count{key(l) >= key} >= k
+    while (lo < hi) {
+        unsigned mid = lo + (hi - lo) / 2 + 1;
+        float c = 0.f;
 #pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const unsigned long long mt = (unsigned long long)lo + (unsigned long long)(t + 1) * stp;
-            const unsigned mid = mt <= hi ? (unsigned)mt : hi;
-            float c = 0.f;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) c += ky[j] >= mid ? 1.f : 0.f;
-            cv[t] = c;
-        }
-        block_sum_multi(cv, red);
-        unsigned nlo = lo, nhi = hi;
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const unsigned long long mt = (unsigned long long)lo + (unsigned long long)(t + 1) * stp;
-            if (mt > hi) continue;
-            if (cv[t] >= (float)k) nlo = (unsigned)mt;
-            else if ((unsigned)mt - 1u < nhi) nhi = (unsigned)mt - 1u;
-        }
-        lo = nlo, hi = nhi;
+        for (int j = 0; j < EPT; ++j) c += ky[j] >= mid ? 1.f : 0.f;
+        c = block_sum(c, red);
+        if (c >= (float)k) lo = mid; else hi = mid - 1;
     }
     __syncthreads();
 #pragma unroll
@@ -175,7 +123,7 @@ __device__ void top_k_filter(float* l, int V, int k, float* red) {
 
 __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     __shared__ float l[MAXV];
-    __shared__ float red[(NT / 64 + 1) * NS];
+    __shared__ float red[NT / 64];
     __shared__ double redd[NT / 64];
     __shared__ double wave_base[NT / 64];
     __shared__ int chosen;

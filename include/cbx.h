@@ -263,7 +263,7 @@ int cbx_set_decode_attn_unroll(int u);
 /* Workspace of cbx_decode_attn_rope_f32's split-context form, used when rows * n_heads < 128 (Turbo / Nano at small batch): ws = 66 * 8 floats
  * per (row, head), zeroed_counters = one int per (row, head), initialised to 0 once; registered for the calling thread's current device. */
 int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, long max_pairs);
-/* a (row, head) whose context is shorter than min_ctx (default 1024; CBX_DA_SPLIT_MIN) is walked by one workgroup even when the workspace is
+/* a (row, head) whose context is shorter than min_ctx (default 512; CBX_DA_SPLIT_MIN) is walked by one workgroup even when the workspace is
  * registered: the hand-off costs ~5 us, more than a short context's 1-2 memory round trips */
 int cbx_set_decode_attn_split_min(int min_ctx);
 

@@ -550,7 +550,7 @@ def test_decode_attn_rope_split_context(dev, rows, H, rope, split_min):
     from chatterbox_amd import ops
     from oracle import ref_torch as O
     ops.ensure_decode_attn_workspace(dev)
-    ops.lib.cbx_set_decode_attn_split_min(split_min)  # 1: every context is split; 512: only the long ones, per row (the default is 1024)
+    ops.lib.cbx_set_decode_attn_split_min(split_min)  # 1: every context is split; 512 (the default): only the long ones, per row
     maxp = 1024
     kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
     cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
@@ -572,7 +572,7 @@ def test_decode_attn_rope_split_context(dev, rows, H, rope, split_min):
             _close(out[r].view(H, 64), ref[:, 0], 2e-5, f"split decode attention ctx {m + 1} row {r}")
             _close(kc[r, :, m], k[r], 1e-6, "k appended")
             _close(vc[r, :, m], v[r], 0.0, "v appended")
-    ops.lib.cbx_set_decode_attn_split_min(1024)
+    ops.lib.cbx_set_decode_attn_split_min(512)
     assert int(ops._DA_WS[torch.device(dev).index or 0][1].abs().sum()) == 0, "arrival counters are back at zero"
 
 

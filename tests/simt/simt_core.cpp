@@ -1,0 +1,241 @@
+// SIMT emulator core (test infrastructure, see simt_emu.h): fibers, scheduler, barriers, wave exchange buffers.
+#include <sys/mman.h>
+
+#include <vector>
+
+#include "simt_emu.h"
+
+namespace simt {
+
+Lane* g_cur = nullptr;
+dim3 g_blockIdx, g_blockDim, g_gridDim;
+int g_last_error = 0;
+
+namespace {
+
+constexpr size_t STACK_BYTES = 512 * 1024;
+constexpr int MAX_THREADS = 1024;
+constexpr int XSLOT = 128;
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    bool done = false;
+    Lane lane;
+    int xpar = 0;           // parity of the wave exchange buffer this lane uses next
+    unsigned shfl_seq[6];   // pairwise xor shuffles executed per mask
+    const char* waiting = "";
+};
+
+struct WaveState {
+    int lanes = 0, alive = 0, arrived = 0;
+    unsigned gen = 0;
+    alignas(16) unsigned char xbuf[2][WAVE][XSLOT];
+    unsigned shfl_post[WAVE][6];
+    unsigned long long shfl_box[WAVE][6][2];
+};
+
+struct BlockState {
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+};
+
+Fiber g_fibers[MAX_THREADS];
+std::vector<WaveState> g_waves;
+BlockState g_block;
+void* g_sched_sp = nullptr;
+int g_curf = 0;
+unsigned long g_progress = 0;
+const std::function<void()>* g_body = nullptr;
+std::vector<unsigned char> g_dyn;
+bool g_abandon = false;
+
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl simt_switch
+    .type simt_switch,@function
+simt_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size simt_switch, .-simt_switch
+)");
+
+Fiber& cur() { return g_fibers[g_curf]; }
+WaveState& wave() { return g_waves[cur().lane.wave]; }
+
+void release_wave(WaveState& w) {
+    w.arrived = 0;
+    ++w.gen;
+    ++g_progress;
+}
+void release_block() {
+    g_block.arrived = 0;
+    ++g_block.gen;
+    ++g_progress;
+}
+
+void fiber_main() {
+    (*g_body)();
+    Fiber& f = cur();
+    f.done = true;
+    ++g_progress;
+    WaveState& w = g_waves[f.lane.wave];
+    // a finished lane no longer takes part in barriers / exchanges (s_barrier counts the waves still running)
+    if (--w.alive > 0 && w.arrived == w.alive) release_wave(w);
+    if (--g_block.alive > 0 && g_block.arrived == g_block.alive) release_block();
+    simt_switch(&f.sp, g_sched_sp);
+    abort();  // never resumed
+}
+
+void init_fiber(Fiber& f) {
+    if (!f.stack) {
+        f.stack = (char*)mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (f.stack == MAP_FAILED) {
+            perror("simt: mmap of a fiber stack");
+            abort();
+        }
+    }
+    uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                // the "return address" of fiber_main (never used)
+    *--sp = (void*)&fiber_main;     // popped by simt_switch's ret; the slot is 16-byte aligned, so fiber_main starts ABI-aligned
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f.sp = sp;
+    f.done = false;
+    f.xpar = 0;
+    memset(f.shfl_seq, 0, sizeof(f.shfl_seq));
+    f.waiting = "";
+}
+
+}  // namespace
+
+void yield() {
+    Fiber& f = cur();
+    simt_switch(&f.sp, g_sched_sp);
+}
+void note_progress() { ++g_progress; }
+
+void wave_sync() {
+    WaveState& w = wave();
+    if (++w.arrived == w.alive) {
+        release_wave(w);
+        return;
+    }
+    const unsigned g = w.gen;
+    cur().waiting = "wave exchange / MFMA";
+    do yield();
+    while (w.gen == g);
+}
+
+void block_sync() {
+    if (++g_block.arrived == g_block.alive) {
+        release_block();
+        return;
+    }
+    const unsigned g = g_block.gen;
+    cur().waiting = "workgroup barrier";
+    do yield();
+    while (g_block.gen == g);
+}
+
+unsigned char* xslot_mine() { return wave().xbuf[cur().xpar][cur().lane.lane]; }
+unsigned char* xslot_of(int lane) { return wave().xbuf[cur().xpar][lane]; }
+void xflip() { cur().xpar ^= 1; }
+int wave_lanes() { return wave().lanes; }
+
+unsigned long long shfl_xor_pair(unsigned long long bits, int mi) {
+    Fiber& f = cur();
+    WaveState& w = wave();
+    const int l = f.lane.lane, p = l ^ (1 << mi);
+    const unsigned k = f.shfl_seq[mi]++;
+    w.shfl_box[l][mi][k & 1] = bits;
+    w.shfl_post[l][mi] = k + 1;
+    ++g_progress;
+    if (p >= w.lanes) return bits;
+    f.waiting = "xor shuffle partner";
+    while (w.shfl_post[p][mi] < k + 1) yield();
+    ++g_progress;
+    return w.shfl_box[p][mi][k & 1];
+}
+
+void* dyn_lds() { return g_dyn.data(); }
+
+int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>& body) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 0 || nthreads > MAX_THREADS || (long)grid.x * grid.y * grid.z <= 0) {
+        fprintf(stderr, "simt: bad launch geometry (%u x %u x %u threads)\n", block.x, block.y, block.z);
+        g_last_error = hipErrorLaunchFailure;
+        return -1;
+    }
+    if (g_sched_sp != nullptr && g_cur != nullptr) {
+        fprintf(stderr, "simt: nested launch\n");
+        abort();
+    }
+    g_blockDim = block;
+    g_gridDim = grid;
+    g_body = &body;
+    const int nwaves = (nthreads + WAVE - 1) / WAVE;
+    if ((int)g_waves.size() < nwaves) g_waves.resize(nwaves);
+    g_dyn.assign(dyn_bytes + 16, 0xCD);  // LDS is not zero-initialised
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = dim3(bx, by, bz);
+                g_block = BlockState();
+                g_block.alive = nthreads;
+                for (int w = 0; w < nwaves; ++w) {
+                    WaveState& ws = g_waves[w];
+                    ws.lanes = ws.alive = std::min(WAVE, nthreads - w * WAVE);
+                    ws.arrived = 0;
+                    ws.gen = 0;
+                    memset(ws.shfl_post, 0, sizeof(ws.shfl_post));
+                }
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = g_fibers[t];
+                    init_fiber(f);
+                    f.lane.flat = t;
+                    f.lane.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    f.lane.lane = t % WAVE;
+                    f.lane.wave = t / WAVE;
+                }
+                int remaining = nthreads;
+                while (remaining > 0) {
+                    const unsigned long before = g_progress;
+                    for (int t = 0; t < nthreads; ++t) {
+                        Fiber& f = g_fibers[t];
+                        if (f.done) continue;
+                        g_curf = t;
+                        g_cur = &f.lane;
+                        simt_switch(&g_sched_sp, f.sp);
+                        if (f.done) --remaining;
+                    }
+                    if (remaining > 0 && g_progress == before) {
+                        fprintf(stderr, "simt: DEADLOCK in block (%u,%u,%u): %d of %d threads stuck\n", bx, by, bz, remaining, nthreads);
+                        int shown = 0;
+                        for (int t = 0; t < nthreads && shown < 8; ++t)
+                            if (!g_fibers[t].done) fprintf(stderr, "  thread %d waits at: %s\n", t, g_fibers[t].waiting), ++shown;
+                        g_cur = nullptr;
+                        g_last_error = hipErrorLaunchFailure;
+                        return -1;  // the stuck fibers are abandoned; their stacks are re-initialised by the next launch
+                    }
+                }
+            }
+    g_cur = nullptr;
+    return 0;
+}
+
+}  // namespace simt

@@ -1,0 +1,413 @@
+// SIMT emulator for the gfx950 kernels of chatterbox_amd/csrc -- TEST INFRASTRUCTURE, not a product path.
+//
+// The .hip sources are compiled AS THEY ARE (tests/simt/build_emu.py only rewrites the handful of inline-asm statements and the
+// `extern __shared__` declarations) for the x86 host against this header, which stands in for <hip/hip_runtime.h>:
+//   * a workgroup runs as blockDim.x cooperative fibers on ONE OS thread (simt_core.cpp: hand-written context switch, round-robin
+//     scheduler, deadlock detection); `__shared__` is a function-level static, so workgroups run one after the other;
+//   * __syncthreads / s_barrier, the wave-level exchanges (__shfl_*, DPP, permlane, ballot) and the MFMA instructions are rendezvous
+//     points: every lane deposits its operands, waits for its wave, then computes ITS OWN destination registers from the deposited
+//     operands with the register layout of the gfx950 instruction;
+//   * buffer resources carry {base, num_records}; out-of-range loads return zeros and out-of-range stores are dropped, as the hardware's
+//     bounds check does; LDS-DMA (`buffer_load ... lds`, `global_load_lds`) copies synchronously -- one legal completion order;
+//   * s_waitcnt / s_nop / sched_barrier / s_setprio do nothing.
+// What this can and cannot show: index arithmetic, layouts, barriers, reductions and the arithmetic itself (to fp32 rounding) are
+// exercised by the same source the GPU runs; timing, memory-model visibility and missing-wait bugs are not.
+// The library built this way (tests/simt/libcbx_emu.so) exports the SAME C ABI (include/cbx.h) on host pointers.  Only tests load it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+
+#define CBX_SIMT_EMU 1
+#ifndef __HIPCC__
+#define __HIPCC__ 1
+#endif
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __constant__
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { unsigned x, y, z, w; } __attribute__((aligned(16)));
+struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+struct float2 { float x, y; } __attribute__((aligned(8)));
+struct int2 { int x, y; } __attribute__((aligned(8)));
+struct uint2 { unsigned x, y; } __attribute__((aligned(8)));
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+
+// ---------------------------------------------------------------------------------------------------------------- runtime stubs
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorLaunchFailure = 719 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { int multiProcessorCount = 256; size_t sharedMemPerBlock = 160 * 1024; int warpSize = 64; };
+
+namespace simt {
+constexpr int WAVE = 64;
+struct Lane {
+    dim3 tid;
+    int flat, lane, wave;
+};
+extern Lane* g_cur;
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern int g_last_error;
+
+int launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()>& body);
+void* dyn_lds();
+void block_sync();
+void wave_sync();
+void yield();
+void note_progress();
+// this lane's slot / another lane's slot of the wave's exchange buffer for the collective in flight (128 bytes per lane)
+unsigned char* xslot_mine();
+unsigned char* xslot_of(int lane);
+void xflip();
+int wave_lanes();
+// pairwise mailbox of the power-of-two xor shuffles (lane groups of one wave may have diverged: decode attention)
+unsigned long long shfl_xor_pair(unsigned long long bits, int mask_log2);
+}  // namespace simt
+
+#define threadIdx (simt::g_cur->tid)
+#define blockIdx (simt::g_blockIdx)
+#define blockDim (simt::g_blockDim)
+#define gridDim (simt::g_gridDim)
+
+static inline hipError_t hipGetLastError() {
+    const int e = simt::g_last_error;
+    simt::g_last_error = 0;
+    return e;
+}
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "simt emulator: launch failed (deadlock or fault, see stderr)"; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <class F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    ((void)(stream), simt::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); }))
+
+static inline void __syncthreads() { simt::block_sync(); }
+
+// ---------------------------------------------------------------------------------------------------------------- scalar helpers
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+#define __log2f(x) log2f(x)
+#define __exp2f(x) exp2f(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frsqrt_rn(float x) { return 1.0f / sqrtf(x); }
+static inline float __fsqrt_rn(float x) { return sqrtf(x); }
+#define __sinf(x) sinf(x)
+#define __cosf(x) cosf(x)
+static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsigned, f); }
+static inline int __float_as_int(float f) { return __builtin_bit_cast(int, f); }
+static inline float __uint_as_float(unsigned u) { return __builtin_bit_cast(float, u); }
+static inline float __int_as_float(int u) { return __builtin_bit_cast(float, u); }
+static inline long long __double_as_longlong(double d) { return __builtin_bit_cast(long long, d); }
+static inline double __longlong_as_double(long long d) { return __builtin_bit_cast(double, d); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline float __saturatef(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+using std::max;
+using std::min;
+static inline long min(long a, int b) { return a < b ? a : b; }
+static inline long min(int a, long b) { return a < b ? a : b; }
+static inline long max(long a, int b) { return a > b ? a : b; }
+static inline long max(int a, long b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------------------------------------------------------- atomics
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or(p, v, order)
+#define __hip_atomic_fetch_max(p, v, order, scope) simt_atomic_max(p, v)
+#define __hip_atomic_load(p, order, scope) simt_atomic_load(p)
+#define __hip_atomic_store(p, v, order, scope) simt_atomic_store(p, v)
+template <class T> static inline T simt_atomic_load(const T* p) { return *(const volatile T*)p; }
+template <class T, class U> static inline void simt_atomic_store(T* p, U v) { *(volatile T*)p = (T)v; }
+template <class T> static inline T simt_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+// ---------------------------------------------------------------------------------------------------------------- wave exchanges
+
+
+template <class T> static inline T __shfl_xor(T v, int mask, int /*width*/ = 64) {
+    static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+    unsigned long long bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    if (mask > 0 && (mask & (mask - 1)) == 0 && mask < 64) {
+        bits = simt::shfl_xor_pair(bits, __builtin_ctz((unsigned)mask));
+    } else {
+        memcpy(simt::xslot_mine(), &bits, 8);
+        simt::wave_sync();
+        const int src = simt::g_cur->lane ^ mask;
+        if (src < simt::wave_lanes()) memcpy(&bits, simt::xslot_of(src), 8);
+        simt::xflip();
+    }
+    T r;
+    memcpy(&r, &bits, sizeof(T));
+    return r;
+}
+template <class T, class F> static inline T simt_shfl_by(T v, F src_of) {
+    static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+    unsigned long long bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    memcpy(simt::xslot_mine(), &bits, 8);
+    simt::wave_sync();
+    const int src = src_of(simt::g_cur->lane);
+    if (src >= 0 && src < simt::wave_lanes()) memcpy(&bits, simt::xslot_of(src), 8);
+    simt::xflip();
+    T r;
+    memcpy(&r, &bits, sizeof(T));
+    return r;
+}
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    return simt_shfl_by(v, [=](int l) { return (l & ~(width - 1)) | (src & (width - 1)); });
+}
+template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    return simt_shfl_by(v, [=](int l) { return (l & (width - 1)) >= (int)delta ? l - (int)delta : -1; });
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    return simt_shfl_by(v, [=](int l) { return (l & (width - 1)) + (int)delta < width ? l + (int)delta : -1; });
+}
+static inline unsigned long long simt_ballot(bool pred) {
+    const unsigned char b = pred ? 1 : 0;
+    memcpy(simt::xslot_mine(), &b, 1);
+    simt::wave_sync();
+    unsigned long long m = 0;
+    for (int l = 0; l < simt::wave_lanes(); ++l)
+        if (*simt::xslot_of(l)) m |= 1ull << l;
+    simt::xflip();
+    return m;
+}
+static inline unsigned long long __ballot(int pred) { return simt_ballot(pred != 0); }
+static inline int __all(int pred) { return simt_ballot(pred == 0) == 0; }
+static inline int __any(int pred) { return simt_ballot(pred != 0) != 0; }
+#define __builtin_amdgcn_ballot_w64(...) simt_ballot(__VA_ARGS__)
+#define __builtin_amdgcn_readfirstlane(x) (x) /* the sources only use it on wave-uniform values */
+
+// v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100), row_shr / row_shl / row_ror, row_mirror, row_half_mirror, row_bcast are not all
+// needed -- the sources use quad_perm only; anything else fails loudly
+static inline int simt_mov_dpp(int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    if (ctrl < 0 || ctrl > 0xFF) {
+        fprintf(stderr, "simt: unsupported DPP control 0x%x\n", ctrl);
+        abort();
+    }
+    return simt_shfl_by(v, [=](int l) { return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3); });
+}
+#define __builtin_amdgcn_mov_dpp(...) simt_mov_dpp(__VA_ARGS__)
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) simt_mov_dpp(v, ctrl, rm, bm, bc)
+
+typedef unsigned simt_u32x2 __attribute__((ext_vector_type(2)));
+// v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src.  Returns {new vdst, new src}.
+static inline simt_u32x2 simt_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+    const unsigned mine[2] = {vdst, src};
+    memcpy(simt::xslot_mine(), mine, 8);
+    simt::wave_sync();
+    const int l = simt::g_cur->lane;
+    unsigned other[2];
+    memcpy(other, simt::xslot_of(l ^ 32), 8);
+    simt::xflip();
+    simt_u32x2 r;
+    if (l < 32) {  // my src <- vdst of lane l + 32; my vdst unchanged
+        r[0] = vdst;
+        r[1] = other[0];
+    } else {  // my vdst <- src of lane l - 32; my src unchanged
+        r[0] = other[1];
+        r[1] = src;
+    }
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(...) simt_permlane32_swap(__VA_ARGS__)
+
+// ---------------------------------------------------------------------------------------------------------------- no-op instructions
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) simt::yield()
+#define __builtin_amdgcn_s_nop(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() simt::block_sync()
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_exp2f(...) exp2f(__VA_ARGS__)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
+#define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf(fmaxf(a, b), c), fminf(a, b))
+
+// ---------------------------------------------------------------------------------------------------------------- MFMA
+typedef float simt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float simt_f32x16 __attribute__((ext_vector_type(16)));
+
+template <class E> static inline float simt_to_f32(E e) {
+    if constexpr (sizeof(E) == 4) return (float)e;
+    else if constexpr (__is_same(E, _Float16)) return (float)e;
+    else {  // bf16 carried as a 16-bit integer or __bf16
+        unsigned short b;
+        memcpy(&b, &e, 2);
+        return __builtin_bit_cast(float, (unsigned)b << 16);
+    }
+}
+
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane 16k + i, B[k][j] in lane 16k + j, D[4(l / 16) + r][l % 16] in register r of lane l.
+static inline simt_f32x4 simt_mfma_f32_16x16x4f32(float a, float b, simt_f32x4 c, int, int, int) {
+    const float ab[2] = {a, b};
+    memcpy(simt::xslot_mine(), ab, 8);
+    simt::wave_sync();
+    const int l = simt::g_cur->lane, j = l & 15;
+    simt_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float s = d[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, simt::xslot_of(16 * k + i), 4);
+            memcpy(&bv, simt::xslot_of(16 * k + j) + 4, 4);
+            s = fmaf(av, bv, s);
+        }
+        d[r] = s;
+    }
+    simt::xflip();
+    return d;
+}
+// 32x32 accumulator layout: register r of lane l holds D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32].
+static inline simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c, int, int, int) {
+    const float ab[2] = {a, b};
+    memcpy(simt::xslot_mine(), ab, 8);
+    simt::wave_sync();
+    const int l = simt::g_cur->lane, j = l & 31;
+    simt_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+        float s = d[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, simt::xslot_of(32 * k + i), 4);
+            memcpy(&bv, simt::xslot_of(32 * k + j) + 4, 4);
+            s = fmaf(av, bv, s);
+        }
+        d[r] = s;
+    }
+    simt::xflip();
+    return d;
+}
+// v_mfma_f32_32x32x16_{f16,bf16}: A[i][8 (l / 32) + e] in element e of lane l (i = l % 32), B likewise with j; products are exact in fp32, the
+// 16-term sum is formed in double and added to C once (the hardware's internal order is not architected; tests compare with tolerances).
+template <class V8> static inline simt_f32x16 simt_mfma_32x32x16(V8 a, V8 b, simt_f32x16 c) {
+    static_assert(sizeof(V8) == 16, "8 x 16-bit operands");
+    unsigned char* m = simt::xslot_mine();
+    memcpy(m, &a, 16);
+    memcpy(m + 16, &b, 16);
+    simt::wave_sync();
+    const int l = simt::g_cur->lane, j = l & 31;
+    simt_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+        double s = 0.0;
+        for (int kh = 0; kh < 2; ++kh) {
+            V8 av, bv;
+            memcpy(&av, simt::xslot_of(32 * kh + i), 16);
+            memcpy(&bv, simt::xslot_of(32 * kh + j) + 16, 16);
+            for (int e = 0; e < 8; ++e) s += (double)simt_to_f32(av[e]) * (double)simt_to_f32(bv[e]);
+        }
+        d[r] = (float)((double)d[r] + s);
+    }
+    simt::xflip();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(...) simt_mfma_f32_16x16x4f32(__VA_ARGS__)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(...) simt_mfma_f32_32x32x2f32(__VA_ARGS__)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) simt_mfma_32x32x16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt_mfma_32x32x16(a, b, c)
+
+// ---------------------------------------------------------------------------------------------------------------- buffer resources
+struct simt_rsrc {
+    char* base;
+    unsigned num_records;
+};
+#define __amdgpu_buffer_rsrc_t simt_rsrc
+template <class P> static inline simt_rsrc simt_make_rsrc(P* p, short /*stride*/, int num_records, int /*flags*/) {
+    return simt_rsrc{(char*)const_cast<typename std::remove_const<P>::type*>(p), (unsigned)num_records};
+}
+#define __builtin_amdgcn_make_buffer_rsrc(...) simt_make_rsrc(__VA_ARGS__)
+typedef unsigned simt_u32x4 __attribute__((ext_vector_type(4)));
+static inline bool simt_in_range(const simt_rsrc& rs, long off, int bytes) { return off >= 0 && (unsigned long)off + (unsigned)bytes <= rs.num_records; }
+static inline simt_u32x4 simt_buffer_load_b128(simt_rsrc rs, int voff, int soff, int) {
+    simt_u32x4 v = {0, 0, 0, 0};
+    const long off = (long)(unsigned)voff + (long)(unsigned)soff;  // 32-bit unsigned offsets, as the hardware adds them
+    if (simt_in_range(rs, off, 16)) memcpy(&v, rs.base + off, 16);
+    return v;
+}
+static inline unsigned simt_buffer_load_b32(simt_rsrc rs, int voff, int soff, int) {
+    unsigned v = 0;
+    const long off = (long)(unsigned)voff + (long)(unsigned)soff;
+    if (simt_in_range(rs, off, 4)) memcpy(&v, rs.base + off, 4);
+    return v;
+}
+template <class T> static inline void simt_buffer_store(T v, simt_rsrc rs, int voff, int soff, int) {
+    const long off = (long)(unsigned)voff + (long)(unsigned)soff;
+    if (simt_in_range(rs, off, (int)sizeof(T))) memcpy(rs.base + off, &v, sizeof(T));
+}
+#define __builtin_amdgcn_raw_buffer_load_b128(...) simt_buffer_load_b128(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_load_b32(...) simt_buffer_load_b32(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b32(...) simt_buffer_store(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b64(...) simt_buffer_store(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b128(...) simt_buffer_store(__VA_ARGS__)
+// LDS-DMA: every lane moves `size` bytes to lds + lane * size (the instruction's LDS address is wave-uniform, M0-based)
+template <class L> static inline void simt_buffer_load_lds(simt_rsrc rs, L lds, int size, int voff, int soff, int imm, int) {
+    char* dst = (char*)(uintptr_t)lds + (long)simt::g_cur->lane * size;
+    const long off = (long)(unsigned)voff + (long)(unsigned)soff + imm;
+    if (simt_in_range(rs, off, size)) memcpy(dst, rs.base + off, size);
+    else memset(dst, 0, size);
+}
+template <class G, class L> static inline void simt_global_load_lds(G src, L lds, int size, int imm, int) {
+    char* dst = (char*)(uintptr_t)lds + (long)simt::g_cur->lane * size;
+    memcpy(dst, (const char*)(uintptr_t)src + imm, size);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(...) simt_buffer_load_lds(__VA_ARGS__)
+#define __builtin_amdgcn_global_load_lds(...) simt_global_load_lds(__VA_ARGS__)
+
+// ---------------------------------------------------------------------------------------------------------------- rewritten inline asm
+// (tests/simt/build_emu.py maps the sources' asm statements onto these)
+static inline float simt_max3_abs(float acc, float a, float b) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), acc); }
+// v_fma_mix{lo,hi}_f16 with an fp16 first operand (low / high half of h2), fp32 second and third operands: one rounding, to fp16
+static inline unsigned simt_fma_mix_f16(unsigned dst, unsigned h2, float s, float t, int hi) {
+    _Float16 h;
+    const unsigned short hb = (unsigned short)(hi ? (h2 >> 16) : (h2 & 0xffffu));
+    memcpy(&h, &hb, 2);
+    const _Float16 r = (_Float16)((double)(float)h * (double)s + (double)t);  // the fp32 fma of these operands is exact in double
+    unsigned short rb;
+    memcpy(&rb, &r, 2);
+    return hi ? ((dst & 0x0000ffffu) | ((unsigned)rb << 16)) : ((dst & 0xffff0000u) | rb);
+}

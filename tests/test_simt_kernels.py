@@ -1,0 +1,259 @@
+"""The gfx950 kernel SOURCES executed on the CPU (no GPU needed): chatterbox_amd/csrc/*.hip compiled for the x86 host against the SIMT
+emulator of tests/simt/ (fibers per lane, MFMA / DPP / buffer-resource semantics of gfx950) and driven through the SAME C ABI and the SAME
+`ops` wrappers as on the GPU -- by the SAME test bodies as `-m gpu` (tests/test_ops_gpu.py, tests/test_planes_gpu.py), called here with a
+CPU device at shapes the emulator finishes in seconds.
+
+What this pins without a GPU: index arithmetic, operand layouts (packed GEMV images, plane format, LDS swizzles, DMA addressing),
+bounds handling, barriers and reductions, the epilogues, and the arithmetic to fp32 rounding.  What it cannot show: speed, memory-model
+visibility, missing waits (simt_emu.h).  The emulator itself is pinned the other way round: every body below passes on the MI355X too.
+
+Test infrastructure only: nothing under chatterbox_amd/ can reach the emulated library.
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.join(HERE, "simt")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+    if not os.path.exists(build_emu.CLANG):
+        pytest.skip("ROCm's clang++ (x86 host compiler of the emulator build) is not installed")
+    import harness
+    with harness.emulated() as lib:
+        yield lib
+
+
+CPU = torch.device("cpu")
+
+# (module, test function, arguments after `dev`)
+_OPS = [
+    ("test_linear", (1, 8, 16)), ("test_linear", (37, 80, 192)),
+    ("test_linear_strided_accumulate_and_second_output", ()),
+    ("test_swiglu", ()),
+    ("test_conv1d", (32, 48, 3, 1, 1, 1, 77)), ("test_conv1d", (64, 64, 11, 5, 1, 25, 300)),
+    ("test_conv1d_ragged_and_upsample", ()),
+    ("test_conv_transpose", (32, 16, 11, 5, 3)),
+    ("test_bmm", ()),
+    ("test_layernorm_rmsnorm", ()),
+    ("test_flash_attn", (103, 103, True)), ("test_flash_attn", (130, 130, False)),
+    ("test_split_flash_attn", (130, 130, False, 3)), ("test_split_flash_attn", (103, 103, True, 6)), ("test_split_flash_attn", (130, 130, False, 16)),
+    ("test_decode_attn", ()),
+    ("test_softmax_relpos", ()),
+    ("test_rope_and_kv_append", ()),
+    ("test_elementwise", ()),
+    ("test_sampler", (1.0, 0.05)), ("test_sampler", (0.9, 0.0)), ("test_sampler", (0.8, 0.05)),
+    ("test_sampler_all_surviving_ids_banned", ()),
+    ("test_hift_source_stft_istft", ()),
+    ("test_gemv_decode", (16, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)),
+    ("test_gemv_swiglu", ()),
+    ("test_decode_attn_rope_fused", ()),
+    ("test_gemv_packed_rms_fused", (16, 3072, 1024, False, 8)), ("test_gemv_packed_rms_fused", (16, 4096, 1024, True, 8)),
+    ("test_gemv_packed_residual_epilogue", (16, 1024, 1024, 16)), ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)),
+    ("test_gemv_packed_residual_epilogue", (16, 64, 256, 4)),
+    ("test_gemv_partial_sum_operand", (9, 1024, 2, False)), ("test_gemv_partial_sum_operand", (16, 4096, 2, True)),
+    ("test_gemv_partial_sum_operand", (16, 3072, 4, False)),
+    ("test_decode_attn_packed_output_and_embed_packed", ()),
+    ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)), ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)),
+    ("test_gemv_half_tile", (16, 1024, 4096, 2, 8, False)), ("test_gemv_half_tile", (16, 1024, 1024, 1, 8, True)), ("test_gemv_half_tile", (9, 40, 256, 1, 4, False)),
+    ("test_gemv_bf16_weights_equal_rounded_fp32", ("plain",)), ("test_gemv_bf16_weights_equal_rounded_fp32", ("rms_np2",)),
+]
+
+
+@pytest.mark.parametrize("name,args", _OPS, ids=[f"{n}{list(a)}" for n, a in _OPS])
+def test_gpu_op_bodies_on_the_emulator(emu, name, args):
+    import test_ops_gpu
+    getattr(test_ops_gpu, name)(CPU, *args)
+
+
+_PLANES = [("test_split_planes_roundtrip_and_range_flag", ()), ("test_layernorm_planes", ()), ("test_gemm_planes_transposed_rejects_bad_arguments", ())]
+
+
+@pytest.mark.parametrize("name,args", _PLANES, ids=[n for n, _ in _PLANES])
+def test_gpu_planes_bodies_on_the_emulator(emu, name, args):
+    import test_planes_gpu
+    getattr(test_planes_gpu, name)(CPU, *args)
+
+
+@pytest.mark.parametrize("tile,persist", [(0, 1), (1, 0), (3, 8), (7, 1), (12, 0), (15, 8), (21, 1), (24, 8), (26, 0), (28, 1)])
+def test_gemm_planes_tiles_small(emu, tile, persist):
+    """tests/test_planes_gpu.py::test_gemm_planes_linear_tiles at emulator-sized shapes: symmetric, loader-wave (21+) and 16-wave (26+) tile
+    forms, persistent and one-tile-per-workgroup grids, ragged M and N, bias + GELU + residual, fp32 and plane outputs."""
+    from chatterbox_amd import ops
+    from test_planes_gpu import _close, _planes_exact, _r
+    try:
+        emu.cbx_set_planes_tile(tile)
+        emu.cbx_set_planes_persist(persist)
+        for (M, N, K) in [(129, 258, 512), (333, 80, 256)]:
+            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+            xP, wP = ops.split_planes(x), ops.split_planes(w)
+            ref = F.gelu(F.linear(_planes_exact(x), _planes_exact(w), b.double())) + r.double()
+            tol = 3e-5 * max(1.0, math.sqrt(K / 256))
+            out, outP = r.clone(), ops.Planes(M, N, CPU, zero=True)
+            ops.linear_planes(xP, wP, out=out, outp=outP, bias=b, act=ops.GELU_ERF, residual=out)
+            _close(out, ref, tol, f"tile {tile} {M}x{N}x{K} (fp32 out)")
+            _close(outP.float(), ref, tol, f"tile {tile} {M}x{N}x{K} (plane out)")
+            assert (outP.float() - out).abs().max() <= 2.0 ** -21 * out.abs().max(), "plane output = split of the fp32 output"
+    finally:
+        emu.cbx_set_planes_tile(0)
+        emu.cbx_set_planes_persist(1)
+
+
+def test_gemm_planes_conv_and_transposed_columns_small(emu):
+    """Causal 3-tap Conv1d on planes with ragged lengths, and q | k | V^T from one launch (ABI v8), at emulator-sized shapes."""
+    from chatterbox_amd import ops
+    from test_planes_gpu import _close, _planes_exact, _r
+    B, T, cin, N = 2, 77, 64, 128
+    x, w, b = _r((B, T, cin), 1), _r((N, cin, 3), 2, 1 / math.sqrt(3 * cin)), _r((N,), 3)
+    lens = torch.tensor([77, 30], dtype=torch.int32)
+    xm = x.clone()
+    xm[1, 30:] = 0
+    ref = F.conv1d(F.pad(_planes_exact(xm).transpose(1, 2), (2, 0)), _planes_exact(w), b.double()).transpose(1, 2)
+    wp = w.permute(0, 2, 1).reshape(N, 3 * cin).contiguous()
+    wide = ops.Planes(B * T, 128, CPU, zero=True)
+    ops.split_planes(x.reshape(B * T, cin), wide.cols(32, cin))
+    out, outP = torch.empty(B, T, N), ops.Planes(B * T, N, CPU)
+    ops.conv1d_planes(wide.cols(32, cin), ops.split_planes(wp), B=B, T=T, taps=3, cin=cin, out=out, outp=outP, bias=b, pad_left=2, lens=lens)
+    _close(out, ref, 6e-5, "conv3 with ragged lengths")
+    _close(outP.float().view(B, T, N), ref, 6e-5, "conv3 plane output")
+    Z, T2 = 2, 36
+    M, K, Nn, n0 = Z * T2, 256, 1536, 1024
+    Tp = (T2 + 7) // 8 * 8
+    h, wq = _r((M, K), 4), _r((Nn, K), 5, 1 / 16)
+    hP, wP = ops.split_planes(h), ops.split_planes(wq)
+    qkP, vtP = ops.Planes(M, n0, CPU), ops.Planes(Z * 512, Tp, CPU, zero=True)
+    ops.gemm_planes(hP, wP, M=M, N=Nn, K=K, P=qkP, PT=vtP, pt_n0=n0, pt_T=T2, pt_zs=512 * vtP.ld)
+    ref = F.linear(_planes_exact(h), _planes_exact(wq))
+    _close(qkP.float(), ref[:, :n0], 3e-5, "q | k columns")
+    vt = vtP.float().view(Z, 512, Tp)
+    _close(vt[:, :, :T2], ref[:, n0:].view(Z, T2, 512).transpose(1, 2), 3e-5, "V^T columns")
+    assert float(vt[:, :, T2:].abs().max()) == 0.0, "pad keys of V^T stay zero"
+
+
+@pytest.mark.parametrize("version", [2, 1, 4])
+def test_flash_attn_planes_small(emu, version):
+    """tests/test_planes_gpu.py::test_flash_attn_planes at emulator-sized shapes (ragged key lengths incl. an empty utterance)."""
+    import test_planes_gpu
+    try:
+        emu.cbx_set_attn_planes_version(version)
+        test_planes_gpu.test_flash_attn_planes(CPU, version, 3, 200, [200, 130, 1])
+        test_planes_gpu.test_flash_attn_planes(CPU, version, 1, 64, None)
+    finally:
+        emu.cbx_set_attn_planes_version(2)
+
+
+def test_mlp_planes_small(emu):
+    import test_planes_gpu
+    test_planes_gpu.test_mlp_planes_vs_fp64_and_vs_two_gemms(CPU, 64)
+
+
+def test_split_gemm_small(emu):
+    """gemm_split.hip (encoder / HiFT / range-check fallback path): the three split precisions and the LayerNorm-folded loader, small shapes."""
+    from chatterbox_amd import ops
+    from test_ops_gpu import _close, _r
+    M, N, K = 200, 96, 256
+    x, w, b = _r((M, K), 1), _r((N, K), 2, 1 / 16), _r((N,), 3)
+    ref = F.linear(x.double(), w.double(), b.double()).float()
+    for prec, tol in ((3, 1e-4), (6, 3e-5), (16, 3e-5)):
+        out = torch.empty(M, N)
+        with ops.gemm_precision(prec):
+            ops.linear(x, w, out, bias=b)
+        _close(out, ref, tol * 4, f"split gemm precision {prec}")
+    g, be = 1 + 0.1 * _r((K,), 4), 0.1 * _r((K,), 5)
+    stats, out = torch.empty(M, 2), torch.empty(M, N)
+    with ops.gemm_precision(16):
+        assert ops.ln_fusable(M, K)
+        ops.row_stats(x, stats)
+        ops.linear(x, w, out, bias=b, ln=(stats, g, be))
+    _close(out, F.linear(F.layer_norm(x, (K,), g, be, 1e-5), w, b), 1e-4, "LayerNorm folded into the A operand")
+
+
+def test_t3_decode_step_c_entry_point_equals_the_launch_sequence(emu):
+    """cbx_t3_decode_step (csrc/t3_step.hip) against the same token step issued launch by launch from Python (t3.py::_forward_decode_v2 +
+    _sample): 2 layers of the real width (1024 / 4096 / 16 heads), 4 rows, identical logits, identical sampled ids and cache rows."""
+    import ctypes
+
+    from chatterbox_amd import ops
+    from chatterbox_amd._lib import SamplerParams, T3Layer, T3Step
+    from test_ops_gpu import _r
+    L, rows, B, D, Fd, H, V, maxp = 2, 4, 2, 1024, 4096, 16, 512, 64
+    g = lambda shape, seed, s=1.0: _r(shape, seed, s)
+    lw = [dict(ln1=1 + 0.1 * g((D,), 10 + i), ln2=1 + 0.1 * g((D,), 20 + i), wqkv=g((3 * D, D), 30 + i, 0.03), wo=g((D, D), 40 + i, 0.03),
+               wg=g((Fd, D), 50 + i, 0.03), wu=g((Fd, D), 60 + i, 0.03), wd=g((D, Fd), 70 + i, 0.015)) for i in range(L)]
+    for w in lw:
+        w["wqkv_pk"], w["wo_pk8"] = ops.pack_gemv_weight(w["wqkv"]), ops.pack_gemv_weight(w["wo"], half_tile=True)
+        w["wgu_pk"] = ops.pack_gemv_weight(torch.cat([w["wg"], w["wu"]], 0), swiglu=True)
+        w["wd_pk8"] = ops.pack_gemv_weight(w["wd"], half_tile=True)
+    emb, pos_emb, norm, head = g((V, D), 1), g((maxp, D), 2, 0.1), 1 + 0.1 * g((D,), 3), g((V, D), 4, 0.03)
+    head_pk = ops.pack_gemv_weight(head)
+    from oracle import ref_torch as O
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    cos, sin = cos.contiguous(), sin.contiguous()
+
+    def fresh():
+        st = dict(kc=g((L, rows, H, maxp, 64), 5), vc=g((L, rows, H, maxp, 64), 6), logits=torch.zeros(rows, V),
+                  seen=torch.zeros(B, V, dtype=torch.uint8), uniforms=torch.rand(B, 8, generator=torch.Generator().manual_seed(7)),
+                  step=torch.zeros(B, dtype=torch.int32), out_tokens=torch.zeros(B, 8, dtype=torch.int64), done=torch.zeros(B, dtype=torch.int32),
+                  n_generated=torch.zeros(B, dtype=torch.int32), next_ids=torch.tensor([5, 9, 5, 9]), next_pos_ids=torch.tensor([1, 1, 1, 1], dtype=torch.int32),
+                  positions=torch.tensor([20, 31, 20, 31], dtype=torch.int32), ctx_lens=torch.tensor([21, 32, 21, 32], dtype=torch.int32),
+                  samp=torch.tensor([[0.5, 0.8, 0.05, 1.0, 1.2, 0.0, -1.0, 0.0]] * B))
+        ws = {k: torch.zeros(16, D) for k in ("x", "x2", "att")}
+        ws.update(qkv=torch.zeros(rows, 3 * D), g=torch.zeros(16, Fd), pd=torch.zeros(4, 16, D))
+        return st, ws
+
+    def sampler_kw(st):
+        return dict(logits=st["logits"], ld=V, V=V, B=B, cfg=1, order=0, eos_token=V - 1, dev_params=st["samp"], seen=st["seen"], uniforms=st["uniforms"],
+                    max_steps=8, step=st["step"], out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
+                    next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
+
+    # (a) launch by launch, as T3Engine._forward_decode_v2 does
+    st, ws = fresh()
+    cur, nxt, pk = ws["x"], ws["x2"], dict(w_packed=True, x_packed=True, M=rows)
+    ops.embed(st["next_ids"], emb, cur, table2=pos_emb, ids2=st["next_pos_ids"], out_packed=True)
+    red = {}
+    for i, w in enumerate(lw):
+        ops.gemv(cur, w["wqkv_pk"], ws["qkv"], N=3 * D, K=D, nw=8, norm_w=w["ln1"], **red, **pk)
+        if red:
+            cur, nxt = nxt, cur
+        ops.decode_attn_rope(ws["qkv"], st["positions"], cos, sin, st["kc"][i], st["vc"][i], ws["att"], 0.125, out_packed=True)
+        ops.gemv(ws["att"], w["wo_pk8"], cur, N=D, K=D, nw=8, res=cur, out_packed=True, half_tile=True, **pk)
+        ops.gemv(cur, w["wgu_pk"], ws["g"], N=Fd, K=D, swiglu=True, nw=8, norm_w=w["ln2"], out_packed=True, **pk)
+        ops.gemv(ws["g"], w["wd_pk8"], ws["pd"][:2], N=D, K=Fd, ksplit=2, nw=16, out_packed=True, half_tile=True, **pk)
+        red = dict(xpart=ws["pd"][:2], x_out=nxt)
+    red["x_out"] = None
+    ops.gemv(cur, head_pk, st["logits"], N=V, K=D, nw=8, norm_w=norm, **red, **pk)
+    ops.t3_sample(**sampler_kw(st))
+    ref = st
+
+    # (b) one call of the stage-level C entry point on fresh, identical state
+    st, ws = fresh()
+    layers = (T3Layer * L)()
+    for i, w in enumerate(lw):
+        layers[i].ln1, layers[i].ln2, layers[i].wqkv = w["ln1"].data_ptr(), w["ln2"].data_ptr(), w["wqkv_pk"].data_ptr()
+        layers[i].wo, layers[i].wgu, layers[i].wd = w["wo_pk8"].data_ptr(), w["wgu_pk"].data_ptr(), w["wd_pk8"].data_ptr()
+    sp = SamplerParams()
+    for k, v in sampler_kw(st).items():
+        setattr(sp, k, v.data_ptr() if torch.is_tensor(v) else v)
+    d = T3Step()
+    d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = L, rows, D, Fd, H, V
+    d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.half_tiles, d.w_bf16, d.eps, d.attn_scale = 8, 8, 16, 2, 1, 0, 1e-5, 0.125
+    d.layers = layers
+    d.speech_emb, d.speech_pos, d.final_norm, d.head = emb.data_ptr(), pos_emb.data_ptr(), norm.data_ptr(), head_pk.data_ptr()
+    d.cos_t, d.sin_t, d.kc, d.vc = cos.data_ptr(), sin.data_ptr(), st["kc"].data_ptr(), st["vc"].data_ptr()
+    d.kv_row_stride, d.kv_head_stride = st["kc"].stride(1), st["kc"].stride(2)
+    d.next_ids, d.next_pos_ids, d.positions = st["next_ids"].data_ptr(), st["next_pos_ids"].data_ptr(), st["positions"].data_ptr()
+    d.x_a, d.x_b, d.qkv, d.att, d.g, d.pd = (ws[k].data_ptr() for k in ("x", "x2", "qkv", "att", "g", "pd"))
+    d.logits, d.ld_logits, d.sampler = st["logits"].data_ptr(), V, ctypes.pointer(sp)
+    assert emu.cbx_t3_decode_step(ctypes.byref(d), None) == 0, emu.cbx_last_error()
+    assert torch.isfinite(st["logits"]).all() and float(st["logits"].abs().max()) > 0
+    for k in ("logits", "out_tokens", "next_ids", "positions", "ctx_lens", "kc", "vc", "seen", "n_generated"):
+        assert torch.equal(st[k], ref[k]), f"cbx_t3_decode_step differs from the launch sequence in {k}"

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 8  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 9  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -78,7 +78,8 @@ class T3Step(ctypes.Structure):
                 ("layers", ctypes.POINTER(T3Layer)), ("speech_emb", c_f), ("speech_pos", c_f), ("final_norm", c_f), ("head", c_f),
                 ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("kv_row_stride", c_long), ("kv_head_stride", c_long),
                 ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f), ("x_a", c_f), ("x_b", c_f), ("qkv", c_f), ("att", c_f),
-                ("g", c_f), ("pd", c_f), ("logits", c_f), ("ld_logits", c_long), ("sampler", ctypes.POINTER(SamplerParams))]
+                ("g", c_f), ("pd", c_f), ("logits", c_f), ("ld_logits", c_long), ("sampler", ctypes.POINTER(SamplerParams)),
+                ("qkv_tile", c_int)]  # ABI v9
 
 
 _SIGS = {

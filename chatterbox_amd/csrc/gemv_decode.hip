@@ -33,6 +33,9 @@ __device__ __forceinline__ f32x4 bf16x4_widen(const u32x4 u, int h) {
     return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
 }
 
+// cbx_gemv_t.half_tile -> output columns per workgroup (0: 16; 1 or 8: 8; 12; 4)
+__host__ __device__ __forceinline__ int gemv_tile_cols(int half_tile) { return half_tile == 0 ? 16 : half_tile == 1 ? 8 : half_tile; }
+
 template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
@@ -42,8 +45,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     __shared__ float ssx[RMS ? NW * MT * 16 : 1];  // row sums (LayerNorm form only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const bool ht = PK && p.half_tile;  // 8-column output tiles: twice the workgroups per projection (lanes c >= 8 idle in the B operand)
-    const int n0 = blockIdx.x * (ht ? 8 : 16), ks = blockIdx.y;
+    // tc = output columns per workgroup: 16, or the narrow tiles 12 / 8 / 4 (cbx_gemv_t.half_tile) that give a projection 4/3, 2 or 4
+    // times the workgroups (lanes c >= tc idle in the B operand): 8 for the two N = 1024 projections, 12 puts q/k/v (N = 3072) and 4 the
+    // o / down projections on exactly 256 workgroups
+    const int tc = PK ? gemv_tile_cols(p.half_tile) : 16;
+    const int n0 = blockIdx.x * tc, ks = blockIdx.y;
     const int kper = p.K / (p.ksplit * NW);
     const int kbeg = (ks * NW + w) * kper;
     const int nit = kper / 32;
@@ -54,19 +60,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     const float *wp, *wp2;
     // floats between consecutive 32-deep K blocks of this lane's stream / between the two 16-B halves of a block; the bf16 image is half
     // as large (one 16-byte load per block: 8 bf16 per lane)
-    const int WBLK = PK ? (ht ? 256 : 512) / (WB ? 2 : 1) : 32;
-    const int WHALF = PK ? (ht ? 128 : 256) : 4;
+    const int WBLK = PK ? (32 * tc) / (WB ? 2 : 1) : 32;
+    const int WHALF = PK ? 16 * tc : 4;
     if constexpr (PK) {
         // packed image: tile-major [tile][K/32][2][64 lanes][4]; swiglu: feature tile f -> tiles 2f (gate), 2f+1 (up); N is padded
         // to whole tiles by the packer, so every load is in range
         const long kb = p.K >> 5;
         const long tile = SWIGLU ? 2L * blockIdx.x : (long)blockIdx.x;
-        wok = !ht || c < 8;
+        wok = c < tc;
+        const int cl = wok ? c : tc - 1;  // idle lanes re-read the tile's last row (loads are unconditional)
         if constexpr (WB) {  // [tile][K/32][lanes][8 bf16] = 4 floats per lane per block
-            wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 128 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 256 + lane * 4;
+            wp = p.W + (tile * kb + (kbeg >> 5)) * (16 * tc) + (q * tc + cl) * 4;
             wp2 = wp + kb * 256;
         } else {
-            wp = ht ? p.W + (tile * kb + (kbeg >> 5)) * 256 + (q * 8 + (c & 7)) * 4 : p.W + (tile * kb + (kbeg >> 5)) * 512 + lane * 4;
+            wp = p.W + (tile * kb + (kbeg >> 5)) * (32 * tc) + (q * tc + cl) * 4;
             wp2 = wp + kb * 512;
         }
     } else {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     for (int e = tid; e < MT * 256; e += NW * 64) {
         const int t = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
         const int m = t * 16 + row, n = n0 + col;
-        if (m >= p.M || n >= p.N || (ht && col >= 8)) continue;
+        if (m >= p.M || n >= p.N || col >= tc) continue;
         float v = 0.f, v2 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 
 template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0, bool WB = false>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
-    const int tc = (PK && p.half_tile) ? 8 : 16;
+    const int tc = PK ? gemv_tile_cols(p.half_tile) : 16;
     dim3 grid((p.N + tc - 1) / tc, p.ksplit);
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
@@ -390,14 +397,15 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const float* __re
                                                                long ld, int swiglu, long n4, int half_tile) {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= n4) return;
-    if (half_tile) {  // 8-row tiles: [tile][K/32][2][32 lanes = q*8 + c][4]
-        const int l32 = i4 & 31, h = (i4 >> 5) & 1;
-        const long tb = i4 >> 6;
+    if (half_tile) {  // narrow tiles of tr = 8 / 12 / 4 rows: [tile][K/32][2][4 * tr lanes = q * tr + c][4]
+        const int tr = half_tile, nl = 4 * tr;
+        const int l32 = (int)(i4 % nl), h = (int)((i4 / nl) & 1);
+        const long tb = i4 / (2 * nl);
         const int KB = K >> 5;
         const long tile = tb / KB;
         const int kb = (int)(tb - tile * KB);
-        const long r = tile * 8 + (l32 & 7);
-        const int k = kb * 32 + (l32 >> 3) * 8 + h * 4;
+        const long r = tile * tr + (l32 % tr);
+        const int k = kb * 32 + (l32 / tr) * 8 + h * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < N) v = *reinterpret_cast<const f32x4*>(src + r * ld + k);
         *reinterpret_cast<f32x4*>(dst + i4 * 4) = v;
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_bf16_kernel(const float*
                                                                     int K, long ld, int swiglu, long nl, int half_tile) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (tile, kb, lane): 8 bf16
     if (i >= nl) return;
-    const int lanes = half_tile ? 32 : 64, rows_t = half_tile ? 8 : 16;
+    const int rows_t = half_tile ? half_tile : 16, lanes = 4 * rows_t;
     const int l = (int)(i % lanes);
     const long tb = i / lanes;
     const int KB = K >> 5;
@@ -465,10 +473,10 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_bf16_kernel(const float*
 
 extern "C" int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream) {
     CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight_bf16: bad args (K %% 32, ld %% 4)");
-    const int half_tile = swiglu == 8;
+    const int half_tile = (swiglu == 8 || swiglu == 12 || swiglu == 4) ? swiglu : 0;  // rows per narrow tile
     if (half_tile) swiglu = 0;
-    const long tiles = half_tile ? (N + 7) / 8 : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
-    const long nl = tiles * (K / 32) * (half_tile ? 32 : 64);
+    const long tiles = half_tile ? (N + half_tile - 1) / half_tile : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
+    const long nl = tiles * (K / 32) * (half_tile ? 4 * half_tile : 64);
     hipLaunchKernelGGL(pack_gemv_weight_bf16_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (unsigned short*)dst, N, K, ld_src, swiglu, nl, half_tile);
     return cbx_check_launch("pack_gemv_weight_bf16");
@@ -477,10 +485,10 @@ extern "C" int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int
 extern "C" int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream) {
     CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight: bad args (K %% 32, ld %% 4)");
     CBX_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "pack_gemv_weight: alignment");
-    const int half_tile = swiglu == 8;  // swiglu == 8 selects the 8-row-tile image (cbx_gemv_t.half_tile) of a plain weight
+    const int half_tile = (swiglu == 8 || swiglu == 12 || swiglu == 4) ? swiglu : 0;  // swiglu = 8 / 12 / 4 selects the narrow-tile image (cbx_gemv_t.half_tile) of a plain weight
     if (half_tile) swiglu = 0;
-    const long tiles = half_tile ? (N + 7) / 8 : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
-    const long n4 = tiles * (K / 32) * (half_tile ? 64 : 128);
+    const long tiles = half_tile ? (N + half_tile - 1) / half_tile : (long)((N + 15) / 16) * (swiglu ? 2 : 1);
+    const long n4 = tiles * (K / 32) * (half_tile ? 8 * half_tile : 128);
     hipLaunchKernelGGL(pack_gemv_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N, K,
                        ld_src, swiglu, n4, half_tile);
     return cbx_check_launch("pack_gemv_weight");
@@ -495,6 +503,8 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);
     CBX_REQUIRE(p.ldx % 4 == 0 && p.ldw % 4 == 0 && (((uintptr_t)p.x | (uintptr_t)p.W) & 15) == 0, "gemv: alignment");
     CBX_REQUIRE(!p.swiglu || (p.ksplit == 1 && p.N % 32 == 0), "gemv: swiglu needs ksplit == 1 and N %% 32 == 0");
+    CBX_REQUIRE(p.half_tile == 0 || p.half_tile == 1 || p.half_tile == 8 || p.half_tile == 12 || p.half_tile == 4, "gemv: half_tile must be 0, 1 (= 8), 8, 12 or 4");
+    CBX_REQUIRE(p.half_tile == 0 || (p.w_packed && !p.swiglu), "gemv: narrow tiles need the matching packed image and no swiglu");
     CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
     CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
     CBX_REQUIRE(!p.w_bf16 || (p.w_packed && p.x_packed && p.M <= 16), "gemv: w_bf16 needs w_packed, x_packed and M <= 16");

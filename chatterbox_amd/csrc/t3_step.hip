@@ -10,7 +10,7 @@
 extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     CBX_REQUIRE(d && d->layers && d->n_layers > 0, "t3_decode_step: null descriptor");
     CBX_REQUIRE(d->rows >= 1 && d->rows <= 16, "t3_decode_step: rows=%d (this entry point serves the packed <= 16-row path)", d->rows);
-    CBX_REQUIRE(d->d_ksplit == 2 || d->d_ksplit == 4, "t3_decode_step: d_ksplit must be 2 or 4");
+    CBX_REQUIRE(d->d_ksplit == 1 || d->d_ksplit == 2 || d->d_ksplit == 4, "t3_decode_step: d_ksplit must be 1, 2 or 4");
     const int D = d->dim, F = d->ffn, H = d->n_heads;
     float* cur = d->x_a;
     float* nxt = d->x_b;
@@ -27,7 +27,7 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     for (int i = 0; i < d->n_layers; ++i) {
         const cbx_t3_layer_t& L = d->layers[i];
         base(cur, L.wqkv, d->qkv, 3 * D, D);
-        g.norm_w = L.ln1;
+        g.norm_w = L.ln1, g.half_tile = d->qkv_tile;
         if (pending) g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nxt;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
         if (pending) {
@@ -44,14 +44,20 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
         base(cur, L.wgu, d->g, F, D);
         g.norm_w = L.ln2, g.swiglu = 1, g.out_packed = 1, g.nw = d->gu_nw;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
-        base(d->g, L.wd, d->pd, D, F);
-        g.ksplit = d->d_ksplit, g.nw = d->d_nw, g.out_packed = 1, g.part_stride = img, g.ldo = D, g.half_tile = d->half_tiles;
+        if (d->d_ksplit > 1) {
+            base(d->g, L.wd, d->pd, D, F);
+            g.ksplit = d->d_ksplit, g.part_stride = img;
+        } else {  // no partial images: the down projection adds the residual in its epilogue, in place
+            base(d->g, L.wd, cur, D, F);
+            g.res = cur;
+        }
+        g.nw = d->d_nw, g.out_packed = 1, g.ldo = D, g.half_tile = d->half_tiles;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
-        pending = true;
+        pending = d->d_ksplit > 1;
     }
     base(cur, d->head, d->logits, d->vocab, D);
     g.norm_w = d->final_norm, g.ldo = d->ld_logits;
-    g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nullptr;
+    if (pending) g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nullptr;
     if ((rc = cbx_gemv_f32(&g, stream))) return rc;
     return d->sampler ? cbx_t3_sample(d->sampler, stream) : 0;
 }

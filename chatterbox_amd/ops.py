@@ -344,19 +344,29 @@ def bmm(a, b, out, *, nn=False, alpha=1.0):
                 w_kn=nn, alpha=alpha)
 
 
+def _tile_rows(half_tile):
+    """gemv / pack_gemv_weight `half_tile`: False -> 16-column tiles, True -> 8, or the tile width itself (8, 12, 4)."""
+    tr = 0 if not half_tile else (8 if half_tile is True or half_tile == 1 else int(half_tile))
+    assert tr in (0, 4, 8, 12), f"narrow gemv tiles are 4, 8 or 12 columns wide, got {half_tile!r}"
+    return tr
+
+
 def pack_gemv_weight(w, swiglu=False, half_tile=False, bf16=False):
     """(N, K) fp32 weight [swiglu: (2F, K) = gate rows then up rows] -> lane-ordered packed image of cbx_gemv_f32 (w_packed = 1):
-    (ceil(N/16)*16, K) floats [swiglu: (2*ceil(F/16)*16, K)].  Done once at load (weights are constants)."""
+    (ceil(N/16)*16, K) floats [swiglu: (2*ceil(F/16)*16, K)].  half_tile (True = 8, or 12 / 4): the narrow-tile image of the same weight.
+    Done once at load (weights are constants)."""
     w = _f32(w, "w").contiguous()
     R, K = w.shape
     N = R // 2 if swiglu else R
-    rows = (N + 7) // 8 * 8 if half_tile else (N + 15) // 16 * 16 * (2 if swiglu else 1)
+    tr = _tile_rows(half_tile)
+    assert not (tr and swiglu)
+    rows = (N + tr - 1) // tr * tr if tr else (N + 15) // 16 * 16 * (2 if swiglu else 1)
     if bf16:  # opt-in decode numerics: weights rounded to bf16 (cbx_gemv_t.w_bf16), half the streamed bytes
         out = torch.empty(rows, K, dtype=torch.bfloat16, device=w.device)
-        check(lib.cbx_pack_gemv_weight_bf16(_p(w), _p(out), N, K, w.stride(0), 8 if half_tile else int(swiglu), _stream()), "cbx_pack_gemv_weight_bf16")
+        check(lib.cbx_pack_gemv_weight_bf16(_p(w), _p(out), N, K, w.stride(0), tr or int(swiglu), _stream()), "cbx_pack_gemv_weight_bf16")
         return out
     out = torch.empty(rows, K, device=w.device)
-    check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), 8 if half_tile else int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
+    check(lib.cbx_pack_gemv_weight_f32(_p(w), _p(out), N, K, w.stride(0), tr or int(swiglu), _stream()), "cbx_pack_gemv_weight_f32")
     return out
 
 
@@ -366,6 +376,7 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
     out_packed: out is written in the packed operand layout of the next gemv (ksplit > 1: out (ksplit, rows16, N) partial images);
+    half_tile (True = 8, or 12 / 4): output columns per workgroup, w being the pack_gemv_weight image of that tile width;
     xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart)."""
     if x_packed:
         assert w_packed and M is not None and K is not None
@@ -378,7 +389,7 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     p.x, p.W, p.bias, p.out = _p(_f32(x, "x")), _p(w if w_bf16 else _f32(w, "w")), _p(bias), _p(_f32(out, "out"))
     p.M, p.N, p.K, p.ksplit, p.nw, p.swiglu, p.act = M, N, K, ksplit, nw, int(swiglu), act
     p.ldx, p.ldw = x.stride(0), w.stride(0)
-    p.w_packed, p.x_packed, p.half_tile, p.w_bf16 = int(w_packed), int(x_packed), int(half_tile), int(w_bf16)
+    p.w_packed, p.x_packed, p.half_tile, p.w_bf16 = int(w_packed), int(x_packed), _tile_rows(half_tile), int(w_bf16)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
     if xpart is not None:

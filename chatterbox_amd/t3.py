@@ -40,7 +40,10 @@ class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
     # decode launch geometry: waves per 16-column tile (nw) / cross-workgroup K splits; *2 = the packed-operand (v2) path
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1)
+    # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
+    # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
+    # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -101,7 +104,7 @@ class T3Engine:
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"  # token step through the stage-level C entry point (same kernels)
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
-        self.tune = dict(self._TUNE)
+        self.tune = self._env_tune()
 
     # ------------------------------------------------------------------ packed device layout <-> disk (formats.save_packed / load_packed)
     _PLAIN = ("norm", "text_emb", "speech_emb", "text_pos", "speech_pos", "head", "head_pk", "spkr_w", "spkr_b", "emo_w", "pq", "cos", "sin")
@@ -137,8 +140,39 @@ class T3Engine:
         self._state = {}
         self.time_decode, self.decode_events = False, []
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"
-        self.tune = dict(cls._TUNE)
+        self.tune = cls._env_tune()
         return self
+
+    @classmethod
+    def _env_tune(cls):
+        tune = dict(cls._TUNE)
+        for kv in filter(None, os.environ.get("CBX_T3_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            assert k.strip() in tune, f"CBX_T3_TUNE: unknown knob {k!r} (known: {sorted(tune)})"
+            tune[k.strip()] = int(v)
+        return tune
+
+    def _tiles(self):
+        """(q/k/v tile width, o / down tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
+        tn = self.tune
+        od = tn.get("od_tc") or (8 if tn.get("half_tiles") and "wo_pk8" in self.layers[0] else 16)
+        return tn.get("qkv_tc") or 16, od
+
+    def _image(self, lw, name, tc):
+        """The packed decode image of layer weight `name` for `tc`-column tiles (packed on first use: never inside a stream capture,
+        generate() calls _prepare_tune() first)."""
+        key = f"{name}_pk" if tc == 16 else f"{name}_pk{tc}"
+        if key not in lw:
+            lw[key] = ops.pack_gemv_weight(lw[name], half_tile=tc, bf16=self.weight_dtype == "bf16")
+        return lw[key]
+
+    def _prepare_tune(self):
+        if self.decode_mode != "v2":
+            return
+        qtc, odtc = self._tiles()
+        assert qtc in (16, 12) and odtc in (16, 8, 4), f"tile widths {qtc} / {odtc}"
+        for lw in self.layers:
+            self._image(lw, "wqkv", qtc), self._image(lw, "wo", odtc), self._image(lw, "wd", odtc)
 
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
@@ -223,19 +257,20 @@ class T3Engine:
         pk = dict(w_packed=True, x_packed=True, M=rows)
         ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.speech_pos, ids2=st["next_pos_ids"], out_packed=True)
         red = {}  # partial images pending on the residual stream
+        qtc, odtc = self._tiles()
+        qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
         for i, lw in enumerate(self.layers):
-            ops.gemv(cur, lw["wqkv_pk"], qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], **red, **pk)
+            ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk)
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ht = bool(tn.get("half_tiles")) and "wo_pk8" in lw
-            ops.gemv(att, lw["wo_pk8"] if ht else lw["wo_pk"], cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ht, **pk)
+            ops.gemv(att, self._image(lw, "wo", odtc), cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
             ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
             if dks > 1:
-                ops.gemv(g, lw["wd_pk8"] if ht else lw["wd_pk"], pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ht, **pk)
+                ops.gemv(g, self._image(lw, "wd", odtc), pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ot, **pk)
                 red = dict(xpart=pd, x_out=nxt)
-            else:
-                ops.gemv(g, lw["wd_pk"], cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, **pk)
+            else:  # the down projection adds the residual itself: no partial images, no fold in the next q/k/v GEMV
+                ops.gemv(g, self._image(lw, "wd", odtc), cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
         if red:
             red["x_out"] = None
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, **red, **pk)
@@ -246,7 +281,7 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (2, 4):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
@@ -260,11 +295,11 @@ class T3Engine:
             p = lambda t: t.data_ptr()
             ws, tn = st["dws"], self.tune
             layers = (T3Layer * self.L)()
+            qtc, odtc = self._tiles()
             for i, lw in enumerate(self.layers):
                 layers[i].ln1, layers[i].ln2 = p(lw["ln1"]), p(lw["ln2"])
-                ht = bool(tn.get("half_tiles")) and "wo_pk8" in lw
-                layers[i].wqkv, layers[i].wgu = p(lw["wqkv_pk"]), p(lw["wgu_pk"])
-                layers[i].wo, layers[i].wd = (p(lw["wo_pk8"]), p(lw["wd_pk8"])) if ht else (p(lw["wo_pk"]), p(lw["wd_pk"]))
+                layers[i].wqkv, layers[i].wgu = p(self._image(lw, "wqkv", qtc)), p(lw["wgu_pk"])
+                layers[i].wo, layers[i].wd = p(self._image(lw, "wo", odtc)), p(self._image(lw, "wd", odtc))
             sp = SamplerParams()
             for k, v in dict(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=1, order=0, eos_token=STOP_SPEECH,
                              dev_params=st["samp_dev"], seen=st["seen"], uniforms=st["uniforms"], max_steps=st["max_steps"], step=st["step"],
@@ -274,7 +309,7 @@ class T3Engine:
             d = T3Step()
             d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = self.L, st["rows"], self.D, self.F, self.H, self.V
             d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.eps, d.attn_scale = tn["o_nw2"], tn["gu_nw"], tn["d_nw2"], tn["d_ks2"], 1e-5, 0.125
-            d.half_tiles = int(bool(tn.get("half_tiles")) and "wo_pk8" in self.layers[0])
+            d.half_tiles, d.qkv_tile = (0 if odtc == 16 else odtc), (0 if qtc == 16 else qtc)
             d.w_bf16 = int(self.head_pk.dtype == torch.bfloat16)
             d.layers = layers
             d.speech_emb, d.speech_pos, d.final_norm, d.head = p(self.speech_emb), p(self.speech_pos), p(self.norm), p(self.head_pk)
@@ -394,6 +429,7 @@ class T3Engine:
         max_ctx = (S + max_new_tokens + 63) // 64 * 64
         assert max_ctx <= self.max_pos, "context exceeds the RoPE table"
         st = self._get_state(B, max_ctx, max_new_tokens, slot)
+        self._prepare_tune()
         # {cfg_weight, temperature, min_p, top_p, rep_penalty, top_k, ban_token, ban_from} per utterance (cbx_sampler_t.dev_params)
         st["samp_dev"].copy_(torch.tensor([float(cfg_weight), float(temperature), float(min_p), float(top_p), float(repetition_penalty), 0.0,
                                            float(STOP_SPEECH if ban_eos else -1), float(ban_from)]).repeat(B, 1), non_blocking=True)

@@ -15,10 +15,11 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 8  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 9  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
-                                 per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace */
+                                 per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
+                              9: 12- and 4-column decode GEMV tiles (cbx_gemv_t.half_tile = 12 / 4), cbx_t3_step_t.qkv_tile, d_ksplit = 1 */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -154,8 +155,10 @@ typedef struct cbx_gemv_t {
     int w_packed;    /* W is the lane-ordered packed image written by cbx_pack_gemv_weight_f32 (ldw ignored; swiglu: tiles
                         2f = gate, 2f+1 = up of feature tile f) */
     int x_packed;    /* x is in the same packed layout (rows padded to 16, ldx ignored); needs w_packed */
-    int half_tile;   /* (was reserved0) W is the 8-row-tile packed image (cbx_pack_gemv_weight_f32 with swiglu = 8): 8 output columns per
-                        workgroup, i.e. twice the workgroups for projections with few output tiles (N = 1024: 128 instead of 64) */
+    int half_tile;   /* (was reserved0) narrow output tiles: 0 = 16 columns per workgroup; 1 or 8 = 8 columns (W is the 8-row-tile packed
+                        image, cbx_pack_gemv_weight_f32 with swiglu = 8): twice the workgroups for projections with few output tiles
+                        (N = 1024: 128 instead of 64); 12 / 4 = 12 / 4 columns (images packed with swiglu = 12 / 4): N = 3072 resp.
+                        N = 1024 on exactly 256 workgroups.  Same per-column arithmetic as the 16-column form (bit-identical results) */
     int out_packed;  /* out (and res) use the packed operand layout of the CONSUMING gemv (its K = this N; N % 32 == 0); with ksplit > 1
                         the partial images are part_stride floats apart */
     const float* norm_w; /* [K] or NULL: LlamaRMSNorm(x) folded in (x * norm_w feeds the MFMAs, rstd applied in the epilogue);
@@ -178,7 +181,8 @@ typedef struct cbx_gemv_t {
  * i.e. each (16-row tile, 32-deep K block) is 2 KiB of contiguous memory in exactly the order the 64 lanes of a wave load it
  * (two 1-KiB instructions).  Rows are zero-padded to a multiple of 16.  swiglu = 1: src holds [gate (F rows); up (F rows)] and
  * the tiles are interleaved gate/up per 16 features.  dst must hold ceil(N/16)*16*K floats.
- * swiglu = 8: the half-tile image (8-row tiles, 32 lanes per half block) for cbx_gemv_t.half_tile; dst holds ceil(N/8)*8*K floats. */
+ * swiglu = 8 / 12 / 4: the narrow-tile image (tr-row tiles, 4 * tr lanes per half block: dst[(((tile * (K/32) + kb) * 2 + h) * 4 * tr + q * tr + c) * 4 + s]
+ * = src[tile * tr + c][kb*32 + q*8 + h*4 + s]) for cbx_gemv_t.half_tile; dst holds ceil(N/tr)*tr*K floats. */
 int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld_src, int swiglu, void* stream);
 /* the same image with the weights rounded (RNE) to bf16: [tile][K/32][lanes][8 bf16] (cbx_gemv_t.w_bf16); dst holds half the bytes */
 int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream);
@@ -341,8 +345,9 @@ typedef struct cbx_t3_layer_t {
 } cbx_t3_layer_t;
 typedef struct cbx_t3_step_t {
     int n_layers, rows, dim, ffn, n_heads, vocab;
-    int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 8 / 2 */
-    int half_tiles, w_bf16;               /* 1: wo / wd are the 8-row-tile images (cbx_gemv_t.half_tile); 1: all weight images are bf16 */
+    int o_nw, gu_nw, d_nw, d_ksplit;      /* launch geometry (T3Engine.tune): 8 / 8 / 16 / 2; d_ksplit = 1 (ABI v9): the down projection adds
+                                             the residual itself (no partial images, no fold in the next q/k/v GEMV) */
+    int half_tiles, w_bf16;               /* cbx_gemv_t.half_tile of the wo / wd images (0, 1 = 8, 4); 1: all weight images are bf16 */
     float eps, attn_scale;
     const cbx_t3_layer_t* layers;         /* HOST array [n_layers] */
     const float *speech_emb, *speech_pos, *final_norm, *head; /* embeddings [V][dim], [P][dim]; tfmr.norm; packed head [ceil16(vocab)][dim] */
@@ -356,6 +361,7 @@ typedef struct cbx_t3_step_t {
     float* logits;                        /* [rows][ld_logits] */
     long ld_logits;
     const cbx_sampler_t* sampler;         /* sampler descriptor (host struct) run at the end of the step, or NULL */
+    int qkv_tile;                         /* ABI v9: cbx_gemv_t.half_tile of the wqkv images (0 or 12) */
 } cbx_t3_step_t;
 int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
 

@@ -16,7 +16,11 @@ texts = [synth.text_tokens(64, seed=b) for b in range(B)]
 u = synth.rand((B, N), seed=1)
 res = {}
 VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_ks2=4)), ("v2", dict(half_tiles=1, d_ks2=2)),
-            ("v2", dict(half_tiles=1, d_ks2=2, d_nw2=16)), ("v2", dict(half_tiles=0, d_ks2=2))]
+            ("v2", dict(half_tiles=1, d_ks2=2, d_nw2=16)), ("v2", dict(half_tiles=0, d_ks2=2)),
+            # round-3 tile variants (written without GPU access, verified on the SIMT emulator; first thing to time in round 4):
+            # q/k/v on 256 workgroups; o / down on 256 workgroups with the residual added by the down projection (no partial images)
+            ("v2", dict(qkv_tc=12)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16)),
+            ("v2", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16, o_nw2=16))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:

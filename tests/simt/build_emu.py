@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "chatterbox_amd", "csrc")
 GEN = os.path.join(HERE, "_gen")
 LIB = os.path.join(HERE, "libcbx_emu.so")
 CLANG = os.environ.get("CBX_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-fPIC", "-fno-strict-aliasing", "-Wno-everything", "-ffp-contract=off",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-fno-strict-aliasing", "-Wno-everything", "-ffp-contract=off",
          "-I", os.path.join(HERE, "shim"), "-I", HERE]
 
 

@@ -15,14 +15,12 @@ namespace {
 
 constexpr size_t STACK_BYTES = 512 * 1024;
 constexpr int MAX_THREADS = 1024;
-constexpr int XSLOT = 128;
 
 struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
     bool done = false;
     Lane lane;
-    int xpar = 0;           // parity of the wave exchange buffer this lane uses next
     unsigned shfl_seq[6];   // pairwise xor shuffles executed per mask
     const char* waiting = "";
 };
@@ -116,7 +114,7 @@ void init_fiber(Fiber& f) {
     for (int i = 0; i < 6; ++i) *--sp = nullptr;
     f.sp = sp;
     f.done = false;
-    f.xpar = 0;
+    f.lane.xpar = 0;
     memset(f.shfl_seq, 0, sizeof(f.shfl_seq));
     f.waiting = "";
 }
@@ -152,10 +150,6 @@ void block_sync() {
     while (g_block.gen == g);
 }
 
-unsigned char* xslot_mine() { return wave().xbuf[cur().xpar][cur().lane.lane]; }
-unsigned char* xslot_of(int lane) { return wave().xbuf[cur().xpar][lane]; }
-void xflip() { cur().xpar ^= 1; }
-int wave_lanes() { return wave().lanes; }
 
 unsigned long long shfl_xor_pair(unsigned long long bits, int mi) {
     Fiber& f = cur();
@@ -211,6 +205,8 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
                     f.lane.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.lane.lane = t % WAVE;
                     f.lane.wave = t / WAVE;
+                    f.lane.wave_lanes = g_waves[t / WAVE].lanes;
+                    f.lane.wave_x = &g_waves[t / WAVE].xbuf[0][0][0];
                 }
                 int remaining = nthreads;
                 while (remaining > 0) {

@@ -59,9 +59,13 @@ struct hipDeviceProp_t { int multiProcessorCount = 256; size_t sharedMemPerBlock
 
 namespace simt {
 constexpr int WAVE = 64;
+constexpr int XSLOT = 128;  // bytes per lane of a wave's exchange buffer
 struct Lane {
     dim3 tid;
     int flat, lane, wave;
+    int xpar;               // parity of the exchange buffer this lane uses for its next collective
+    int wave_lanes;         // lanes of this lane's wave (64 except in a ragged last wave)
+    unsigned char* wave_x;  // this wave's exchange buffers [2][WAVE][XSLOT]
 };
 extern Lane* g_cur;
 extern dim3 g_blockIdx, g_blockDim, g_gridDim;
@@ -73,11 +77,11 @@ void block_sync();
 void wave_sync();
 void yield();
 void note_progress();
-// this lane's slot / another lane's slot of the wave's exchange buffer for the collective in flight (128 bytes per lane)
-unsigned char* xslot_mine();
-unsigned char* xslot_of(int lane);
-void xflip();
-int wave_lanes();
+// this lane's slot / another lane's slot of the wave's exchange buffer for the collective in flight
+inline unsigned char* xslot_of(int lane) { return g_cur->wave_x + (g_cur->xpar * WAVE + lane) * XSLOT; }
+inline unsigned char* xslot_mine() { return xslot_of(g_cur->lane); }
+inline void xflip() { g_cur->xpar ^= 1; }
+inline int wave_lanes() { return g_cur->wave_lanes; }
 // pairwise mailbox of the power-of-two xor shuffles (lane groups of one wave may have diverged: decode attention)
 unsigned long long shfl_xor_pair(unsigned long long bits, int mask_log2);
 }  // namespace simt

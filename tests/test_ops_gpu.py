@@ -738,6 +738,54 @@ def test_gemv_half_tile(dev, M, N, K, ks, nw, res):
         _close(got, F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "half-tile gemv")
 
 
+@pytest.mark.parametrize("M,N,K,ks,nw,tile,mode", [(16, 3072, 1024, 1, 8, 12, "rms_np2"), (16, 3072, 1024, 1, 8, 12, "rms"), (16, 1024, 4096, 1, 16, 4, "res"),
+                                                    (16, 1024, 1024, 1, 8, 4, "res"), (9, 1024, 4096, 1, 8, 4, "plain"), (5, 40, 256, 2, 4, 12, "plain"),
+                                                    (16, 1024, 4096, 1, 8, 4, "bf16")])
+def test_gemv_narrow_tiles(dev, M, N, K, ks, nw, tile, mode):
+    """12- and 4-column output tiles (ABI v9: cbx_gemv_t.half_tile = 12 / 4 + the matching packed image): q/k/v (N = 3072) resp. the o / down
+    projections (N = 1024) on exactly 256 workgroups.  Same per-column arithmetic as the 16-column form: results bit for bit, in the plain,
+    RMSNorm-folded, partial-sum-operand, residual-epilogue and bf16-weight forms."""
+    from chatterbox_amd import ops
+    x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, (N + 31) // 32 * 32), 3)
+    nwt = 1 + 0.1 * _r((K,), 4)
+    xp = ops.pack_gemv_weight(x.to(dev))
+    bf = mode == "bf16"
+    w16, wn = ops.pack_gemv_weight(w.to(dev), bf16=bf), ops.pack_gemv_weight(w.to(dev), half_tile=tile, bf16=bf)
+    assert wn.shape[0] == (N + tile - 1) // tile * tile
+    shape = (ks, M, N) if ks > 1 else (M, N)
+    kw = dict(N=N, M=M, K=K, ksplit=ks, nw=nw, w_packed=True, x_packed=True)
+    tol = 3e-5 * max(1.0, math.sqrt(K / 256))
+    if mode == "res":
+        ra, rb = ops.pack_gemv_weight(r.to(dev)), ops.pack_gemv_weight(r.to(dev))
+        ops.gemv(xp, w16, ra, res=ra, out_packed=True, **kw)
+        ops.gemv(xp, wn, rb, res=rb, out_packed=True, half_tile=tile, **kw)
+        assert torch.equal(ra, rb)
+        _close(_unpack_operand(rb, M, N), r[:, :N] + F.linear(x, w), tol, f"{tile}-column gemv + residual")
+        return
+    extra = {}
+    ref = F.linear(x, w)
+    if mode.startswith("rms"):
+        extra = dict(norm_w=nwt.to(dev))
+        xs = x
+        if mode == "rms_np2":
+            parts = _r((2, M, K), 5, 0.3)
+            pp = torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(2)])
+            extra.update(xpart=pp, x_out=torch.zeros_like(xp))
+            xs = x + parts[0] + parts[1]
+        ref = F.linear(xs * torch.rsqrt((xs * xs).mean(-1, keepdim=True) + 1e-5) * nwt, w)
+    if bf:
+        ref = F.linear(x, w.bfloat16().float())
+    a, b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+    ops.gemv(xp, w16, a, **kw, **extra)
+    if "x_out" in extra:
+        extra["x_out"] = torch.zeros_like(xp)
+    ops.gemv(xp, wn, b, half_tile=tile, **kw, **extra)
+    assert torch.equal(a, b), f"{tile}-column tiles differ from the 16-column form"
+    _close(b.sum(0) if ks > 1 else b, ref, 2 * tol, f"{tile}-column gemv ({mode})")
+    if "x_out" in extra:
+        _close(_unpack_operand(extra["x_out"], M, K), xs, 1e-6, "x_out = x + partial images")
+
+
 @pytest.mark.parametrize("case", ["plain", "rms_swiglu", "half_ks2", "rms_np2"])
 def test_gemv_bf16_weights_equal_rounded_fp32(dev, case):
     """Opt-in bf16 decode weights (cbx_pack_gemv_weight_bf16 / cbx_gemv_t.w_bf16): bit-identical to the fp32 kernel run on the

@@ -66,6 +66,9 @@ _OPS = [
     ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)), ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)),
     ("test_gemv_half_tile", (16, 1024, 4096, 2, 8, False)), ("test_gemv_half_tile", (16, 1024, 1024, 1, 8, True)), ("test_gemv_half_tile", (9, 40, 256, 1, 4, False)),
     ("test_gemv_bf16_weights_equal_rounded_fp32", ("plain",)), ("test_gemv_bf16_weights_equal_rounded_fp32", ("rms_np2",)),
+    ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2")), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
+    ("test_gemv_narrow_tiles", (9, 1024, 4096, 1, 8, 4, "plain")), ("test_gemv_narrow_tiles", (5, 40, 256, 2, 4, 12, "plain")),
+    ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
 ]
 
 
@@ -177,83 +180,178 @@ def test_split_gemm_small(emu):
     _close(out, F.linear(F.layer_norm(x, (K,), g, be, 1e-5), w, b), 1e-4, "LayerNorm folded into the A operand")
 
 
-def test_t3_decode_step_c_entry_point_equals_the_launch_sequence(emu):
-    """cbx_t3_decode_step (csrc/t3_step.hip) against the same token step issued launch by launch from Python (t3.py::_forward_decode_v2 +
-    _sample): 2 layers of the real width (1024 / 4096 / 16 heads), 4 rows, identical logits, identical sampled ids and cache rows."""
-    import ctypes
-
+@pytest.fixture(scope="module")
+def tiny_llama(emu):
+    """2 layers of the real T3 width (1024 / 4096 / 16 heads), 4 rows (2 utterances x CFG), every packed image the tile variants need."""
     from chatterbox_amd import ops
-    from chatterbox_amd._lib import SamplerParams, T3Layer, T3Step
-    from test_ops_gpu import _r
-    L, rows, B, D, Fd, H, V, maxp = 2, 4, 2, 1024, 4096, 16, 512, 64
-    g = lambda shape, seed, s=1.0: _r(shape, seed, s)
+    from oracle import ref_torch as O
+    from test_ops_gpu import _r as g
+    L, D, Fd, V, maxp = 2, 1024, 4096, 512, 64
     lw = [dict(ln1=1 + 0.1 * g((D,), 10 + i), ln2=1 + 0.1 * g((D,), 20 + i), wqkv=g((3 * D, D), 30 + i, 0.03), wo=g((D, D), 40 + i, 0.03),
                wg=g((Fd, D), 50 + i, 0.03), wu=g((Fd, D), 60 + i, 0.03), wd=g((D, Fd), 70 + i, 0.015)) for i in range(L)]
     for w in lw:
-        w["wqkv_pk"], w["wo_pk8"] = ops.pack_gemv_weight(w["wqkv"]), ops.pack_gemv_weight(w["wo"], half_tile=True)
         w["wgu_pk"] = ops.pack_gemv_weight(torch.cat([w["wg"], w["wu"]], 0), swiglu=True)
-        w["wd_pk8"] = ops.pack_gemv_weight(w["wd"], half_tile=True)
-    emb, pos_emb, norm, head = g((V, D), 1), g((maxp, D), 2, 0.1), 1 + 0.1 * g((D,), 3), g((V, D), 4, 0.03)
-    head_pk = ops.pack_gemv_weight(head)
-    from oracle import ref_torch as O
+        for name, tcs in (("wqkv", (16, 12)), ("wo", (16, 8, 4)), ("wd", (16, 8, 4))):
+            for tc in tcs:
+                w[f"{name}_pk{tc}"] = ops.pack_gemv_weight(w[name], half_tile=0 if tc == 16 else tc)
+    m = dict(L=L, D=D, F=Fd, H=16, V=V, maxp=maxp, rows=4, B=2, lw=lw, emb=g((V, D), 1), pos_emb=g((maxp, D), 2, 0.1), norm=1 + 0.1 * g((D,), 3))
+    m["head_pk"] = ops.pack_gemv_weight(g((V, D), 4, 0.03))
     cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
-    cos, sin = cos.contiguous(), sin.contiguous()
+    m["cos"], m["sin"] = cos.contiguous(), sin.contiguous()
+    return m
 
-    def fresh():
-        st = dict(kc=g((L, rows, H, maxp, 64), 5), vc=g((L, rows, H, maxp, 64), 6), logits=torch.zeros(rows, V),
-                  seen=torch.zeros(B, V, dtype=torch.uint8), uniforms=torch.rand(B, 8, generator=torch.Generator().manual_seed(7)),
-                  step=torch.zeros(B, dtype=torch.int32), out_tokens=torch.zeros(B, 8, dtype=torch.int64), done=torch.zeros(B, dtype=torch.int32),
-                  n_generated=torch.zeros(B, dtype=torch.int32), next_ids=torch.tensor([5, 9, 5, 9]), next_pos_ids=torch.tensor([1, 1, 1, 1], dtype=torch.int32),
-                  positions=torch.tensor([20, 31, 20, 31], dtype=torch.int32), ctx_lens=torch.tensor([21, 32, 21, 32], dtype=torch.int32),
-                  samp=torch.tensor([[0.5, 0.8, 0.05, 1.0, 1.2, 0.0, -1.0, 0.0]] * B))
-        ws = {k: torch.zeros(16, D) for k in ("x", "x2", "att")}
-        ws.update(qkv=torch.zeros(rows, 3 * D), g=torch.zeros(16, Fd), pd=torch.zeros(4, 16, D))
-        return st, ws
 
-    def sampler_kw(st):
-        return dict(logits=st["logits"], ld=V, V=V, B=B, cfg=1, order=0, eos_token=V - 1, dev_params=st["samp"], seen=st["seen"], uniforms=st["uniforms"],
-                    max_steps=8, step=st["step"], out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"], next_ids=st["next_ids"],
-                    next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
+def _tiny_state(m):
+    from test_ops_gpu import _r as g
+    L, rows, B, D, Fd, H, V, maxp = (m[k] for k in ("L", "rows", "B", "D", "F", "H", "V", "maxp"))
+    st = dict(kc=g((L, rows, H, maxp, 64), 5), vc=g((L, rows, H, maxp, 64), 6), logits=torch.zeros(rows, V),
+              seen=torch.zeros(B, V, dtype=torch.uint8), uniforms=torch.rand(B, 8, generator=torch.Generator().manual_seed(7)),
+              step=torch.zeros(B, dtype=torch.int32), out_tokens=torch.zeros(B, 8, dtype=torch.int64), done=torch.zeros(B, dtype=torch.int32),
+              n_generated=torch.zeros(B, dtype=torch.int32), next_ids=torch.tensor([5, 9, 5, 9]), next_pos_ids=torch.tensor([1, 1, 1, 1], dtype=torch.int32),
+              positions=torch.tensor([20, 31, 20, 31], dtype=torch.int32), ctx_lens=torch.tensor([21, 32, 21, 32], dtype=torch.int32),
+              samp=torch.tensor([[0.5, 0.8, 0.05, 1.0, 1.2, 0.0, -1.0, 0.0]] * B))
+    ws = {k: torch.zeros(16, D) for k in ("x", "x2", "att")}
+    ws.update(qkv=torch.zeros(rows, 3 * D), g=torch.zeros(16, Fd), pd=torch.zeros(4, 16, D))
+    return st, ws
 
-    # (a) launch by launch, as T3Engine._forward_decode_v2 does
-    st, ws = fresh()
+
+def _tiny_sampler_kw(m, st):
+    return dict(logits=st["logits"], ld=m["V"], V=m["V"], B=m["B"], cfg=1, order=0, eos_token=m["V"] - 1, dev_params=st["samp"], seen=st["seen"],
+                uniforms=st["uniforms"], max_steps=8, step=st["step"], out_tokens=st["out_tokens"], done=st["done"], n_generated=st["n_generated"],
+                next_ids=st["next_ids"], next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
+
+
+def _tiny_step_launches(m, qtc, odtc, dks):
+    """The token step launch by launch, as T3Engine._forward_decode_v2 + _sample issue it."""
+    from chatterbox_amd import ops
+    st, ws = _tiny_state(m)
+    rows, D, Fd, V = m["rows"], m["D"], m["F"], m["V"]
     cur, nxt, pk = ws["x"], ws["x2"], dict(w_packed=True, x_packed=True, M=rows)
-    ops.embed(st["next_ids"], emb, cur, table2=pos_emb, ids2=st["next_pos_ids"], out_packed=True)
+    qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
+    ops.embed(st["next_ids"], m["emb"], cur, table2=m["pos_emb"], ids2=st["next_pos_ids"], out_packed=True)
     red = {}
-    for i, w in enumerate(lw):
-        ops.gemv(cur, w["wqkv_pk"], ws["qkv"], N=3 * D, K=D, nw=8, norm_w=w["ln1"], **red, **pk)
+    for i, w in enumerate(m["lw"]):
+        ops.gemv(cur, w[f"wqkv_pk{qtc}"], ws["qkv"], N=3 * D, K=D, nw=8, norm_w=w["ln1"], half_tile=qt, **red, **pk)
         if red:
             cur, nxt = nxt, cur
-        ops.decode_attn_rope(ws["qkv"], st["positions"], cos, sin, st["kc"][i], st["vc"][i], ws["att"], 0.125, out_packed=True)
-        ops.gemv(ws["att"], w["wo_pk8"], cur, N=D, K=D, nw=8, res=cur, out_packed=True, half_tile=True, **pk)
+        ops.decode_attn_rope(ws["qkv"], st["positions"], m["cos"], m["sin"], st["kc"][i], st["vc"][i], ws["att"], 0.125, out_packed=True)
+        ops.gemv(ws["att"], w[f"wo_pk{odtc}"], cur, N=D, K=D, nw=8, res=cur, out_packed=True, half_tile=ot, **pk)
         ops.gemv(cur, w["wgu_pk"], ws["g"], N=Fd, K=D, swiglu=True, nw=8, norm_w=w["ln2"], out_packed=True, **pk)
-        ops.gemv(ws["g"], w["wd_pk8"], ws["pd"][:2], N=D, K=Fd, ksplit=2, nw=16, out_packed=True, half_tile=True, **pk)
-        red = dict(xpart=ws["pd"][:2], x_out=nxt)
-    red["x_out"] = None
-    ops.gemv(cur, head_pk, st["logits"], N=V, K=D, nw=8, norm_w=norm, **red, **pk)
-    ops.t3_sample(**sampler_kw(st))
-    ref = st
+        if dks > 1:
+            ops.gemv(ws["g"], w[f"wd_pk{odtc}"], ws["pd"][:dks], N=D, K=Fd, ksplit=dks, nw=16, out_packed=True, half_tile=ot, **pk)
+            red = dict(xpart=ws["pd"][:dks], x_out=nxt)
+        else:
+            ops.gemv(ws["g"], w[f"wd_pk{odtc}"], cur, N=D, K=Fd, nw=16, res=cur, out_packed=True, half_tile=ot, **pk)
+    if red:
+        red["x_out"] = None
+    ops.gemv(cur, m["head_pk"], st["logits"], N=V, K=D, nw=8, norm_w=m["norm"], **red, **pk)
+    ops.t3_sample(**_tiny_sampler_kw(m, st))
+    return st
 
-    # (b) one call of the stage-level C entry point on fresh, identical state
-    st, ws = fresh()
-    layers = (T3Layer * L)()
-    for i, w in enumerate(lw):
-        layers[i].ln1, layers[i].ln2, layers[i].wqkv = w["ln1"].data_ptr(), w["ln2"].data_ptr(), w["wqkv_pk"].data_ptr()
-        layers[i].wo, layers[i].wgu, layers[i].wd = w["wo_pk8"].data_ptr(), w["wgu_pk"].data_ptr(), w["wd_pk8"].data_ptr()
+
+def _tiny_step_c(emu, m, qtc, odtc, dks):
+    """The same step as ONE call of the stage-level C entry point (csrc/t3_step.hip)."""
+    import ctypes
+
+    from chatterbox_amd._lib import SamplerParams, T3Layer, T3Step
+    st, ws = _tiny_state(m)
+    layers = (T3Layer * m["L"])()
+    for i, w in enumerate(m["lw"]):
+        layers[i].ln1, layers[i].ln2, layers[i].wqkv = w["ln1"].data_ptr(), w["ln2"].data_ptr(), w[f"wqkv_pk{qtc}"].data_ptr()
+        layers[i].wo, layers[i].wgu, layers[i].wd = w[f"wo_pk{odtc}"].data_ptr(), w["wgu_pk"].data_ptr(), w[f"wd_pk{odtc}"].data_ptr()
     sp = SamplerParams()
-    for k, v in sampler_kw(st).items():
+    for k, v in _tiny_sampler_kw(m, st).items():
         setattr(sp, k, v.data_ptr() if torch.is_tensor(v) else v)
     d = T3Step()
-    d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = L, rows, D, Fd, H, V
-    d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.half_tiles, d.w_bf16, d.eps, d.attn_scale = 8, 8, 16, 2, 1, 0, 1e-5, 0.125
+    d.n_layers, d.rows, d.dim, d.ffn, d.n_heads, d.vocab = m["L"], m["rows"], m["D"], m["F"], m["H"], m["V"]
+    d.o_nw, d.gu_nw, d.d_nw, d.d_ksplit, d.w_bf16, d.eps, d.attn_scale = 8, 8, 16, dks, 0, 1e-5, 0.125
+    d.half_tiles, d.qkv_tile = (0 if odtc == 16 else odtc), (0 if qtc == 16 else qtc)
     d.layers = layers
-    d.speech_emb, d.speech_pos, d.final_norm, d.head = emb.data_ptr(), pos_emb.data_ptr(), norm.data_ptr(), head_pk.data_ptr()
-    d.cos_t, d.sin_t, d.kc, d.vc = cos.data_ptr(), sin.data_ptr(), st["kc"].data_ptr(), st["vc"].data_ptr()
+    d.speech_emb, d.speech_pos, d.final_norm, d.head = m["emb"].data_ptr(), m["pos_emb"].data_ptr(), m["norm"].data_ptr(), m["head_pk"].data_ptr()
+    d.cos_t, d.sin_t, d.kc, d.vc = m["cos"].data_ptr(), m["sin"].data_ptr(), st["kc"].data_ptr(), st["vc"].data_ptr()
     d.kv_row_stride, d.kv_head_stride = st["kc"].stride(1), st["kc"].stride(2)
     d.next_ids, d.next_pos_ids, d.positions = st["next_ids"].data_ptr(), st["next_pos_ids"].data_ptr(), st["positions"].data_ptr()
     d.x_a, d.x_b, d.qkv, d.att, d.g, d.pd = (ws[k].data_ptr() for k in ("x", "x2", "qkv", "att", "g", "pd"))
-    d.logits, d.ld_logits, d.sampler = st["logits"].data_ptr(), V, ctypes.pointer(sp)
+    d.logits, d.ld_logits, d.sampler = st["logits"].data_ptr(), m["V"], ctypes.pointer(sp)
     assert emu.cbx_t3_decode_step(ctypes.byref(d), None) == 0, emu.cbx_last_error()
-    assert torch.isfinite(st["logits"]).all() and float(st["logits"].abs().max()) > 0
-    for k in ("logits", "out_tokens", "next_ids", "positions", "ctx_lens", "kc", "vc", "seen", "n_generated"):
-        assert torch.equal(st[k], ref[k]), f"cbx_t3_decode_step differs from the launch sequence in {k}"
+    return st
+
+
+_STEP_KEYS = ("logits", "out_tokens", "next_ids", "positions", "ctx_lens", "kc", "vc", "seen", "n_generated")
+
+
+def _tiny_step_reference(m):
+    """fp64 torch restatement of the step (HF Llama decoder layer arithmetic, reference a5): logits (rows, V)."""
+    from oracle import ref_torch as O
+    st, _ = _tiny_state(m)
+    D, H, rows = m["D"], m["H"], m["rows"]
+    dd = lambda t: t.double()
+    x = dd(m["emb"])[st["next_ids"]] + dd(m["pos_emb"])[st["next_pos_ids"].long()]
+    rms = lambda v, w: v * torch.rsqrt((v * v).mean(-1, keepdim=True) + 1e-5) * dd(w)
+    pos = st["positions"].long()
+    c, s = dd(m["cos"])[pos][:, None], dd(m["sin"])[pos][:, None]
+    for i, w in enumerate(m["lw"]):
+        q, k, v = (rms(x, w["ln1"]) @ dd(w["wqkv"]).t()).view(rows, 3, H, 64).unbind(1)
+        q, k = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
+        att = torch.empty(rows, H, 64, dtype=torch.float64)
+        for r in range(rows):
+            kk = torch.cat([dd(st["kc"][i, r, :, : pos[r]]), k[r][:, None]], 1)
+            vv = torch.cat([dd(st["vc"][i, r, :, : pos[r]]), v[r][:, None]], 1)
+            p = torch.softmax(torch.einsum("hd,hkd->hk", q[r], kk) * 0.125, -1)
+            att[r] = torch.einsum("hk,hkd->hd", p, vv)
+        x = x + att.reshape(rows, D) @ dd(w["wo"]).t()
+        h = rms(x, w["ln2"])
+        x = x + (F.silu(h @ dd(w["wg"]).t()) * (h @ dd(w["wu"]).t())) @ dd(w["wd"]).t()
+    from chatterbox_amd import ops  # the head image is only available packed: unpack through its row-major source is not kept, so rebuild
+    from test_ops_gpu import _r as g
+    return rms(x, m["norm"]) @ dd(g((m["V"], D), 4, 0.03)).t()
+
+
+@pytest.mark.parametrize("qtc,odtc,dks", [(16, 8, 2), (12, 4, 1)])
+def test_t3_decode_step_c_entry_point_and_tile_variants(emu, tiny_llama, qtc, odtc, dks):
+    """cbx_t3_decode_step (csrc/t3_step.hip) against the same token step issued launch by launch from Python (t3.py::_forward_decode_v2 +
+    _sample): identical logits, sampled ids and cache rows -- for the default geometry (16-column q/k/v tiles, 8-column o / down tiles,
+    2 split-K partial images) and for the round-3 tile variants (12-column q/k/v tiles, 4-column o / down tiles, the down projection adding
+    the residual itself: CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1").  Every variant also against an fp64 restatement of the step."""
+    m = tiny_llama
+    a = _tiny_step_launches(m, qtc, odtc, dks)
+    b = _tiny_step_c(emu, m, qtc, odtc, dks)
+    assert torch.isfinite(a["logits"]).all() and float(a["logits"].abs().max()) > 0
+    for k in _STEP_KEYS:
+        assert torch.equal(a[k], b[k]), f"cbx_t3_decode_step differs from the launch sequence in {k}"
+    ref = _tiny_step_reference(m)
+    err = (a["logits"].double() - ref).abs().max()
+    assert err < 2e-4 * max(1.0, float(ref.abs().max())), f"logits vs fp64: {err:.3e}"
+    assert torch.equal(a["positions"], torch.tensor([21, 32, 21, 32], dtype=torch.int32))
+
+
+@pytest.mark.parametrize("tune,c_step", [(dict(), True), (dict(qkv_tc=12, od_tc=4, d_ks2=1), True), (dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), False)])
+def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_step, monkeypatch):
+    """chatterbox_amd/t3.py's own decode-step code (T3Engine._prepare_tune / _tiles / _image / _forward_decode_v2 / _decode_step_c) driven on
+    the emulator: an engine object assembled around the tiny model, one token step, against the hand-written launch sequence above."""
+    from chatterbox_amd.t3 import T3Engine
+    m = tiny_llama
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: type("S", (), {"cuda_stream": None})())
+    eng = T3Engine.__new__(T3Engine)
+    eng.dev, eng.L, eng.V, eng.weight_dtype, eng.decode_mode, eng.c_step = CPU, m["L"], m["V"], "fp32", "v2", c_step
+    eng.layers = [dict(ln1=w["ln1"], ln2=w["ln2"], wqkv=w["wqkv"], wo=w["wo"], wd=w["wd"], wgu_pk=w["wgu_pk"], wqkv_pk=w["wqkv_pk16"], wo_pk=w["wo_pk16"],
+                       wd_pk=w["wd_pk16"], wo_pk8=w["wo_pk8"], wd_pk8=w["wd_pk8"]) for w in m["lw"]]
+    eng.norm, eng.head_pk, eng.speech_emb, eng.speech_pos, eng.cos, eng.sin = m["norm"], m["head_pk"], m["emb"], m["pos_emb"], m["cos"], m["sin"]
+    eng.tune, eng._state = dict(T3Engine._TUNE, **tune), {}
+    qtc, odtc = eng._tiles()
+    assert (qtc, odtc) == ((12, 4) if tune else (16, 8))
+    eng._prepare_tune()
+    assert all(f"wqkv_pk{qtc}" in lw or qtc == 16 for lw in eng.layers)
+    ref_st, _ = _tiny_state(m)
+    st = eng._get_state(m["B"], m["maxp"], 8)
+    for k in ("kc", "vc", "uniforms", "next_ids", "next_pos_ids", "positions", "ctx_lens"):
+        st[k].copy_(ref_st[k])
+    st["samp_dev"].copy_(ref_st["samp"])
+    eng._decode_step(st)
+    want = _tiny_step_launches(m, qtc, odtc, eng.tune["d_ks2"]) if eng.tune["d_nw2"] == 16 else None
+    if want is not None:
+        for k in ("logits", "next_ids", "kc", "vc", "positions"):
+            assert torch.equal(st[k], want[k]), f"T3Engine decode step differs from the reference launch sequence in {k}"
+    else:  # another wave count of the down projection: a different (valid) summation order
+        ref = _tiny_step_reference(m)
+        assert (st["logits"].double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))

@@ -97,6 +97,7 @@ _SIGS = {
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
     "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
+    "cbx_set_decode_attn_pipeline": ([c_int], c_int),
     "cbx_set_decode_attn_workspace": ([c_f, c_f, c_long], c_int),
     "cbx_set_decode_attn_split_min": ([c_int], c_int),
     "cbx_set_split_tile": ([c_int], c_int),

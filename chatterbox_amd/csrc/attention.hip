@@ -257,7 +257,12 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------
 // U = key rows per lane group in flight per step (env CBX_DA_U: 4 / 8 / 16).  The first step's K/V loads are issued BEFORE the
 // RoPE / LDS hand-off of q (they do not depend on it), so the q path's global round trip overlaps the cache stream.
-template <int DA_U, bool SPLIT>
+// PIPE (cbx_set_decode_attn_pipeline, ABI v9; written without GPU access at the end of round 3, verified on the SIMT emulator, to be timed in
+// round 4): the K/V rows of step i + 1 are requested BEFORE step i is multiplied (two register sets, loop unrolled by two; the loads
+// stay unconditional -- clamped addresses -- so that hipcc waits with a COUNTED vmcnt and the younger set stays in flight).  The plain form
+// issues a step's loads only after the previous step's arithmetic, i.e. it pays one memory round trip per step (64 positions with U = 4:
+// the measured slope of 1.6 us per 64 positions, profiles/r02_decode_micro.log, is that round trip).  Same arithmetic, same order, same results.
+template <int DA_U, bool SPLIT, bool PIPE = false>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
@@ -287,15 +292,17 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
 
     // lane group g = wid*4 + sub handles positions g, g+16, g+32, ...
     f32x4 kv[DA_U], vv[DA_U];
-    auto load_chunk = [&](int p0) {
+    f32x4 kv2[PIPE ? DA_U : 1], vv2[PIPE ? DA_U : 1];  // PIPE: the second register set
+    auto load_rows = [&](f32x4* kd, f32x4* vd, int p0) {
 #pragma unroll
         for (int u = 0; u < DA_U; ++u) {
             const int p = p0 + 16 * u;
             const int pc = p < pos ? p : 0;  // clamped: loads are unconditional (never the new position, never past the end)
-            kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
-            vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
+            kd[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
+            vd[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
         }
     };
+    auto load_chunk = [&](int p0) { load_rows(kv, vv, p0); };
     // this workgroup's positions: [p_lo, p_hi), 16-aligned slices of [0, ctx); the new token (position pos) belongs to the last slice
     const int slice = S > 1 ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
     const int p_lo = sp * slice, p_hi = min(ctx, p_lo + slice);
@@ -321,17 +328,18 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    while (true) {
+    // one step: DA_U key rows of this lane group (positions p0, p0 + 16, ...) folded into the running (m, l, acc)
+    auto step = [&](f32x4* kd, f32x4* vd, int p0) {
         float d[DA_U];
         float mt = m;
 #pragma unroll
         for (int u = 0; u < DA_U; ++u) {
             const int p = p0 + 16 * u;
             if (p == pos) {  // the new token's k/v come from LDS, never from HBM
-                kv[u] = *reinterpret_cast<const f32x4*>(&k_new[l16 * 4]);
-                vv[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
+                kd[u] = *reinterpret_cast<const f32x4*>(&k_new[l16 * 4]);
+                vd[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
             }
-            float t = kv[u][0] * qv4[0] + kv[u][1] * qv4[1] + kv[u][2] * qv4[2] + kv[u][3] * qv4[3];
+            float t = kd[u][0] * qv4[0] + kd[u][1] * qv4[1] + kd[u][2] * qv4[2] + kd[u][3] * qv4[3];
             t += __shfl_xor(t, 8);
             t += __shfl_xor(t, 4);
             t += __shfl_xor(t, 2);
@@ -347,13 +355,32 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             for (int u = 0; u < DA_U; ++u) {
                 const float pw = __expf(d[u] - mt);
                 l += pw;
-                acc += vv[u] * pw;
+                acc += vd[u] * pw;
             }
             m = mt;
         }
-        p0 += 16 * DA_U;
-        if (p0 >= p_hi) break;
-        load_chunk(p0);
+    };
+    if constexpr (PIPE) {
+        constexpr int STEP = 16 * DA_U;
+        while (true) {
+            load_rows(kv2, vv2, p0 + STEP);  // requested before the arithmetic on the set that has landed
+            __builtin_amdgcn_sched_barrier(0);
+            step(kv, vv, p0);
+            p0 += STEP;
+            if (p0 >= p_hi) break;
+            load_rows(kv, vv, p0 + STEP);
+            __builtin_amdgcn_sched_barrier(0);
+            step(kv2, vv2, p0);
+            p0 += STEP;
+            if (p0 >= p_hi) break;
+        }
+    } else {
+        while (true) {
+            step(kv, vv, p0);
+            p0 += 16 * DA_U;
+            if (p0 >= p_hi) break;
+            load_chunk(p0);
+        }
     }
     const int g = wid * 4 + sub;
     *reinterpret_cast<f32x4*>(&st_acc[g][l16 * 4]) = acc;
@@ -508,6 +535,11 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     g_da_pairs[d] = ws && zeroed_counters ? max_pairs : 0;
     return 0;
 }
+static int g_da_pipe = getenv("CBX_DA_PIPE") ? atoi(getenv("CBX_DA_PIPE")) : 0;
+extern "C" int cbx_set_decode_attn_pipeline(int on) {
+    g_da_pipe = on != 0;
+    return 0;
+}
 constexpr int DA_MAX_SPLIT = 8;
 static int g_da_split_min = getenv("CBX_DA_SPLIT_MIN") ? atoi(getenv("CBX_DA_SPLIT_MIN")) : 512;
 extern "C" int cbx_set_decode_attn_split_min(int min_ctx) {
@@ -541,18 +573,21 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     // at contexts of 200-700 by 1-4 %; the split engages on contexts >= cbx_set_decode_attn_split_min (512): a 1000-token Turbo generation
     // (contexts to ~1450) decodes at 1.03 ms / token with it, 1.20 without (profiles/r03_turbo_long_context.log).
     const int da_u = g_da_u > 0 ? g_da_u : 4;
-#define CBX_DA_LAUNCH(U)                                                                                                                   \
+#define CBX_DA_LAUNCH(U, P)                                                                                                                \
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,   \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
         else                                                                                                                               \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads,  \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
     } while (0)
-    if (da_u == 8) CBX_DA_LAUNCH(8);
-    else if (da_u == 16) CBX_DA_LAUNCH(16);
-    else CBX_DA_LAUNCH(4);
+    if (g_da_pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
+        if (da_u == 8) CBX_DA_LAUNCH(8, true);
+        else CBX_DA_LAUNCH(4, true);
+    } else if (da_u == 8) CBX_DA_LAUNCH(8, false);
+    else if (da_u == 16) CBX_DA_LAUNCH(16, false);
+    else CBX_DA_LAUNCH(4, false);
 #undef CBX_DA_LAUNCH
     return cbx_check_launch("decode_attn_rope");
 }

@@ -20,14 +20,18 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             # round-3 tile variants (written without GPU access, verified on the SIMT emulator; first thing to time in round 4):
             # q/k/v on 256 workgroups; o / down on 256 workgroups with the residual added by the down projection (no partial images)
             ("v2", dict(qkv_tc=12)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16)),
-            ("v2", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16, o_nw2=16))]
+            ("v2", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16, o_nw2=16)),
+            # software-pipelined decode attention (cbx_set_decode_attn_pipeline): alone, with 8 rows per step, and with the tile variants
+            ("v2", dict(da_pipe=1)), ("v2", dict(da_pipe=1, da_u=8)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:
     os.environ["CBX_T3_DECODE"] = mode
     eng = T3Engine(sd, dev)
-    da_u = tune.pop("da_u", 4)
+    tune = dict(tune)
+    da_u, da_pipe = tune.pop("da_u", 4), tune.pop("da_pipe", 0)
     ops.lib.cbx_set_decode_attn_unroll(da_u)
+    ops.lib.cbx_set_decode_attn_pipeline(da_pipe)
     eng.tune.update(tune)
     kw = dict(max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561)
     toks = eng.generate(synth.t3_cond(), texts, **kw)
@@ -38,7 +42,7 @@ for mode, tune in VARIANTS:
         toks = eng.generate(synth.t3_cond(), texts, **kw)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    key = f"{mode} {tune} da_u={da_u}"
+    key = f"{mode} {tune} da_u={da_u} da_pipe={da_pipe}"
     res[key] = [t.tolist() for t in toks]
     print(f"{key:50s} T3 stage {min(ts) * 1e3:7.1f} ms  ({min(ts) / (N - 1) * 1e3:.3f} ms/token incl. prefill)", flush=True)
     del eng

@@ -576,6 +576,49 @@ def test_decode_attn_rope_split_context(dev, rows, H, rope, split_min):
     assert int(ops._DA_WS[torch.device(dev).index or 0][1].abs().sum()) == 0, "arrival counters are back at zero"
 
 
+@pytest.mark.parametrize("rows,H,rope,split_min", [(3, 16, True, 512), (1, 12, False, 1), (16, 16, True, 512)])
+def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
+    """cbx_set_decode_attn_pipeline(1) (ABI v9: the next step's K / V rows are requested before the current step is multiplied, two register
+    sets) against the plain form: same arithmetic in the same order, so outputs and appended cache rows are equal bit for bit -- contexts of
+    1 .. 70 (fewer rows than one step, exactly one step, the ragged tail of the second register set), a few long ones, 4 and 8 rows per
+    lane group and step, the one-workgroup and the split-context grids."""
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    ops.ensure_decode_attn_workspace(dev)
+    maxp = 640
+    kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    cd, sd_ = (cos.to(dev), sin.to(dev)) if rope else (None, None)
+    try:
+        ops.lib.cbx_set_decode_attn_split_min(split_min)
+        for u in (4, 8):
+            ops.lib.cbx_set_decode_attn_unroll(u)
+            for n in list(range(0, 70, 1 if rows < 16 else 9)) + [127, 128, 129, 255, 300, 639]:
+                pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
+                qkv = _r((rows, 3 * H * 64), 100 + n)
+                res = []
+                for pipe in (0, 1):
+                    ops.lib.cbx_set_decode_attn_pipeline(pipe)
+                    kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.zeros(rows, H * 64, device=dev)
+                    ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
+                    res.append((out.cpu(), kc.cpu(), vc.cpu()))
+                for a, b, what in zip(res[0], res[1], ("output", "k cache", "v cache")):
+                    assert torch.equal(a, b), f"pipelined decode attention differs in the {what} (U = {u}, context {n + 1})"
+                if n in (0, 63, 64, 65, 300):  # and the result itself against torch
+                    q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
+                    if rope:
+                        c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
+                        q, k = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
+                    for r in range(rows):
+                        m = int(pos[r])
+                        kk, vv = torch.cat([kc0[r, :, :m], k[r][:, None]], 1), torch.cat([vc0[r, :, :m], v[r][:, None]], 1)
+                        _close(res[1][0][r].view(H, 64), F.scaled_dot_product_attention(q[r].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"pipelined, ctx {m + 1}")
+    finally:
+        ops.lib.cbx_set_decode_attn_pipeline(0)
+        ops.lib.cbx_set_decode_attn_unroll(4)
+        ops.lib.cbx_set_decode_attn_split_min(512)
+
+
 def _unpack_operand(img, rows, K):
     """Inverse of the packed GEMV operand layout (include/cbx.h): image (ceil(rows/16)*16, K) -> row-major (rows, K)."""
     T = img.shape[0] // 16

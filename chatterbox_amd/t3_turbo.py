@@ -40,8 +40,10 @@ class T3TurboEngine:
                 wpr=tw(sd[p + "mlp.c_proj.weight"]), bpr=d(sd[p + "mlp.c_proj.bias"])))
         # decode path: lane-ordered packed images of the streamed weights (every wave-level load = 1 KiB contiguous, cbx.h)
         # decode tuning (same knobs as T3Engine._TUNE; CBX_TURBO_TUNE="d_ks=4,d_nw=8,o_nw=8,half_tiles=0" overrides for an A/B):
-        # 8-column tiles for the two N = D projections (twice the workgroups), split-K factor / waves of the MLP projection
-        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1)
+        # 8-column tiles for the two N = D projections (twice the workgroups), split-K factor / waves of the MLP projection;
+        # qkv_tc = 12 / od_tc = 4 (ABI v9): c_attn resp. the two N = D projections on N / 12 resp. N / 4 workgroups, d_ks = 1: the MLP
+        # projection adds bias + residual itself (no partial images, no fold in the next c_attn GEMV)
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0)
         for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
             k, v = kv.split("=")
             self.tune[k.strip()] = int(v)
@@ -99,23 +101,49 @@ class T3TurboEngine:
         (same structure as T3Engine._forward_decode_v2)."""
         ws, D = st["dws"], self.D
         B, tn = st["B"], self.tune
-        dks, ht = tn["d_ks"], bool(tn["half_tiles"])
+        dks = tn["d_ks"]
+        qtc, odtc = self._tiles()
+        qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
         cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"][:dks]
         pk = dict(w_packed=True, x_packed=True, M=B)
         ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.wpe, ids2=st["positions"], out_packed=True)
         red = {}
         for i, lw in enumerate(self.layers):
-            ops.gemv(cur, lw["wqkv_pk"], qkv, N=3 * D, K=D, nw=8, norm_w=lw["ln1"][0], ln_cw=lw["c_qkv"][0], ln_cb=lw["c_qkv"][1], **red, **pk)
+            ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * D, K=D, nw=8, norm_w=lw["ln1"][0], ln_cw=lw["c_qkv"][0], ln_cb=lw["c_qkv"][1],
+                     half_tile=qt, **red, **pk)
             if red:
                 cur, nxt = nxt, cur
             ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ops.gemv(att, lw["wo_pk8"] if ht else lw["wo_pk"], cur, N=D, K=D, nw=tn["o_nw"], bias=lw["bo"], res=cur, out_packed=True, half_tile=ht, **pk)
+            ops.gemv(att, self._image(lw, "wo", odtc), cur, N=D, K=D, nw=tn["o_nw"], bias=lw["bo"], res=cur, out_packed=True, half_tile=ot, **pk)
             ops.gemv(cur, lw["wfc_pk"], g, N=4 * D, K=D, nw=8, norm_w=lw["ln2"][0], ln_cw=lw["c_fc"][0], ln_cb=lw["c_fc"][1],
                      act=ops.GELU_TANH, out_packed=True, **pk)
-            ops.gemv(g, lw["wpr_pk8"] if ht else lw["wpr_pk"], pd, N=D, K=4 * D, ksplit=dks, nw=tn["d_nw"], bias=lw["bpr"], out_packed=True, half_tile=ht, **pk)
-            red = dict(xpart=pd, x_out=nxt)
-        red["x_out"] = None
+            if dks > 1:
+                ops.gemv(g, self._image(lw, "wpr", odtc), pd, N=D, K=4 * D, ksplit=dks, nw=tn["d_nw"], bias=lw["bpr"], out_packed=True, half_tile=ot, **pk)
+                red = dict(xpart=pd, x_out=nxt)
+            else:
+                ops.gemv(g, self._image(lw, "wpr", odtc), cur, N=D, K=4 * D, nw=tn["d_nw"], bias=lw["bpr"], res=cur, out_packed=True, half_tile=ot, **pk)
+        if red:
+            red["x_out"] = None
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1], **red, **pk)
+
+    def _tiles(self):
+        """(c_attn tile width, attention / MLP projection tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
+        tn = self.tune
+        return tn.get("qkv_tc") or 16, tn.get("od_tc") or (8 if tn.get("half_tiles") else 16)
+
+    def _image(self, lw, name, tc):
+        """Packed decode image of layer weight `name` for `tc`-column tiles (packed on first use; generate() calls _prepare_tune() before
+        anything is captured)."""
+        key = f"{name}_pk" if tc == 16 else f"{name}_pk{tc}"
+        if key not in lw:
+            lw[key] = ops.pack_gemv_weight(lw[name], half_tile=tc)
+        return lw[key]
+
+    def _prepare_tune(self):
+        qtc, odtc = self._tiles()
+        assert qtc in (16, 12) and odtc in (16, 8, 4) and self.tune["d_ks"] in (1, 2, 4), f"decode tune {self.tune}"
+        for lw in self.layers:
+            self._image(lw, "wqkv", qtc), self._image(lw, "wo", odtc), self._image(lw, "wpr", odtc)
 
     def _sample(self, st):
         ops.t3_sample(logits=st["logits"], ld=st["logits"].stride(0), V=self.V, B=st["B"], cfg=0, order=1, eos_token=STOP_SPEECH,
@@ -185,6 +213,8 @@ class T3TurboEngine:
         max_ctx = (S + n_samples + 63) // 64 * 64
         assert max_ctx <= self.wpe.shape[0], "context exceeds GPT-2 n_positions"
         st = self._get_state(B, max_ctx, n_samples)
+        if self.decode_mode == "v2":
+            self._prepare_tune()
         # sampling parameters live in device memory (cbx_sampler_t.dev_params): no graph re-capture when a request changes them
         st["samp_dev"].copy_(torch.tensor([0.0, float(temperature), 0.0, float(top_p), float(repetition_penalty), float(top_k),
                                            float(STOP_SPEECH if ban_eos else -1), float(ban_from)]).repeat(B, 1), non_blocking=True)

@@ -356,3 +356,36 @@ def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_ste
     else:  # another wave count of the down projection: a different (valid) summation order
         ref = _tiny_step_reference(m)
         assert (st["logits"].double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials"])
+def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
+    """The WHOLE T3-Turbo path of chatterbox_amd/t3_turbo.py on the emulator -- conditioning, prefill (exact fp32 GEMMs + flash attention),
+    the 5-launch GPT-2 decode step with the LayerNorm-folded GEMVs, the device sampler (top-k / top-p bisection, repetition penalty) -- on a
+    1-layer, 256-wide model with two utterances of different text length and voice: sampled ids identical to the CPU oracle's
+    (oracle/ref_torch.py::t3_inference_turbo, itself pinned against the reference).  Second case: the round-3 decode tile variants."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3_turbo import T3TurboEngine
+    from oracle import ref_torch as O
+    samp = dict(temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
+    L, d, steps = 1, 256, 5
+    sd = synth.t3_turbo_state_dict(L, d, 0)
+    texts = [synth.turbo_text_tokens(n, seed=s) for n, s in ((7, 1), (12, 2))]
+    conds = [synth.t3_cond(seed=s, prompt_len=24) for s in (2, 3)]
+    u = synth.rand((2, steps + 1), seed=11)
+    eng = T3TurboEngine(sd, CPU)
+    eng.tune.update(tune)
+    toks = eng.generate(conds, texts, max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    for b in range(2):
+        ref = O.t3_inference_turbo(sd, L, d // 64, conds[b], texts[b], steps, u[b], ban_eos=True, **samp)
+        assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"
+
+
+@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="model-level emulator runs take minutes to half an hour each: CBX_EMU_SLOW=1")
+@pytest.mark.parametrize("name,args", [("test_flow_vs_reference_golden", (None,)), ("test_hift_vs_reference_golden", ()), ("test_meanflow_vs_reference_golden", ())])
+def test_model_level_golden_bodies_on_the_emulator(emu, name, args):
+    """tests/test_models_gpu.py bodies against the REFERENCE's golden vectors, executed by the emulator: the whole S3Gen flow (conformer encoder
+    + 10-step CFG CFM on the plane-format estimator, 56 transformer blocks) reproduces the reference's mel at the fp32 tolerances on the CPU
+    (measured once: 31 minutes for the flow golden).  Opt-in."""
+    import test_models_gpu
+    getattr(test_models_gpu, name)(CPU, *args)

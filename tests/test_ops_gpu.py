@@ -576,49 +576,6 @@ def test_decode_attn_rope_split_context(dev, rows, H, rope, split_min):
     assert int(ops._DA_WS[torch.device(dev).index or 0][1].abs().sum()) == 0, "arrival counters are back at zero"
 
 
-@pytest.mark.parametrize("rows,H,rope,split_min", [(3, 16, True, 512), (1, 12, False, 1), (16, 16, True, 512)])
-def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
-    """cbx_set_decode_attn_pipeline(1) (ABI v9: the next step's K / V rows are requested before the current step is multiplied, two register
-    sets) against the plain form: same arithmetic in the same order, so outputs and appended cache rows are equal bit for bit -- contexts of
-    1 .. 70 (fewer rows than one step, exactly one step, the ragged tail of the second register set), a few long ones, 4 and 8 rows per
-    lane group and step, the one-workgroup and the split-context grids."""
-    from chatterbox_amd import ops
-    from oracle import ref_torch as O
-    ops.ensure_decode_attn_workspace(dev)
-    maxp = 640
-    kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
-    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
-    cd, sd_ = (cos.to(dev), sin.to(dev)) if rope else (None, None)
-    try:
-        ops.lib.cbx_set_decode_attn_split_min(split_min)
-        for u in (4, 8):
-            ops.lib.cbx_set_decode_attn_unroll(u)
-            for n in list(range(0, 70, 1 if rows < 16 else 9)) + [127, 128, 129, 255, 300, 639]:
-                pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
-                qkv = _r((rows, 3 * H * 64), 100 + n)
-                res = []
-                for pipe in (0, 1):
-                    ops.lib.cbx_set_decode_attn_pipeline(pipe)
-                    kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.zeros(rows, H * 64, device=dev)
-                    ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
-                    res.append((out.cpu(), kc.cpu(), vc.cpu()))
-                for a, b, what in zip(res[0], res[1], ("output", "k cache", "v cache")):
-                    assert torch.equal(a, b), f"pipelined decode attention differs in the {what} (U = {u}, context {n + 1})"
-                if n in (0, 63, 64, 65, 300):  # and the result itself against torch
-                    q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
-                    if rope:
-                        c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
-                        q, k = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
-                    for r in range(rows):
-                        m = int(pos[r])
-                        kk, vv = torch.cat([kc0[r, :, :m], k[r][:, None]], 1), torch.cat([vc0[r, :, :m], v[r][:, None]], 1)
-                        _close(res[1][0][r].view(H, 64), F.scaled_dot_product_attention(q[r].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"pipelined, ctx {m + 1}")
-    finally:
-        ops.lib.cbx_set_decode_attn_pipeline(0)
-        ops.lib.cbx_set_decode_attn_unroll(4)
-        ops.lib.cbx_set_decode_attn_split_min(512)
-
-
 def _unpack_operand(img, rows, K):
     """Inverse of the packed GEMV operand layout (include/cbx.h): image (ceil(rows/16)*16, K) -> row-major (rows, K)."""
     T = img.shape[0] // 16
@@ -779,54 +736,6 @@ def test_gemv_half_tile(dev, M, N, K, ks, nw, res):
         assert torch.equal(a, b)
         got = b.sum(0) if ks > 1 else b
         _close(got, F.linear(x, w), 3e-5 * max(1.0, math.sqrt(K / 256)), "half-tile gemv")
-
-
-@pytest.mark.parametrize("M,N,K,ks,nw,tile,mode", [(16, 3072, 1024, 1, 8, 12, "rms_np2"), (16, 3072, 1024, 1, 8, 12, "rms"), (16, 1024, 4096, 1, 16, 4, "res"),
-                                                    (16, 1024, 1024, 1, 8, 4, "res"), (9, 1024, 4096, 1, 8, 4, "plain"), (5, 40, 256, 2, 4, 12, "plain"),
-                                                    (16, 1024, 4096, 1, 8, 4, "bf16")])
-def test_gemv_narrow_tiles(dev, M, N, K, ks, nw, tile, mode):
-    """12- and 4-column output tiles (ABI v9: cbx_gemv_t.half_tile = 12 / 4 + the matching packed image): q/k/v (N = 3072) resp. the o / down
-    projections (N = 1024) on exactly 256 workgroups.  Same per-column arithmetic as the 16-column form: results bit for bit, in the plain,
-    RMSNorm-folded, partial-sum-operand, residual-epilogue and bf16-weight forms."""
-    from chatterbox_amd import ops
-    x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, (N + 31) // 32 * 32), 3)
-    nwt = 1 + 0.1 * _r((K,), 4)
-    xp = ops.pack_gemv_weight(x.to(dev))
-    bf = mode == "bf16"
-    w16, wn = ops.pack_gemv_weight(w.to(dev), bf16=bf), ops.pack_gemv_weight(w.to(dev), half_tile=tile, bf16=bf)
-    assert wn.shape[0] == (N + tile - 1) // tile * tile
-    shape = (ks, M, N) if ks > 1 else (M, N)
-    kw = dict(N=N, M=M, K=K, ksplit=ks, nw=nw, w_packed=True, x_packed=True)
-    tol = 3e-5 * max(1.0, math.sqrt(K / 256))
-    if mode == "res":
-        ra, rb = ops.pack_gemv_weight(r.to(dev)), ops.pack_gemv_weight(r.to(dev))
-        ops.gemv(xp, w16, ra, res=ra, out_packed=True, **kw)
-        ops.gemv(xp, wn, rb, res=rb, out_packed=True, half_tile=tile, **kw)
-        assert torch.equal(ra, rb)
-        _close(_unpack_operand(rb, M, N), r[:, :N] + F.linear(x, w), tol, f"{tile}-column gemv + residual")
-        return
-    extra = {}
-    ref = F.linear(x, w)
-    if mode.startswith("rms"):
-        extra = dict(norm_w=nwt.to(dev))
-        xs = x
-        if mode == "rms_np2":
-            parts = _r((2, M, K), 5, 0.3)
-            pp = torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(2)])
-            extra.update(xpart=pp, x_out=torch.zeros_like(xp))
-            xs = x + parts[0] + parts[1]
-        ref = F.linear(xs * torch.rsqrt((xs * xs).mean(-1, keepdim=True) + 1e-5) * nwt, w)
-    if bf:
-        ref = F.linear(x, w.bfloat16().float())
-    a, b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
-    ops.gemv(xp, w16, a, **kw, **extra)
-    if "x_out" in extra:
-        extra["x_out"] = torch.zeros_like(xp)
-    ops.gemv(xp, wn, b, half_tile=tile, **kw, **extra)
-    assert torch.equal(a, b), f"{tile}-column tiles differ from the 16-column form"
-    _close(b.sum(0) if ks > 1 else b, ref, 2 * tol, f"{tile}-column gemv ({mode})")
-    if "x_out" in extra:
-        _close(_unpack_operand(extra["x_out"], M, K), xs, 1e-6, "x_out = x + partial images")
 
 
 @pytest.mark.parametrize("case", ["plain", "rms_swiglu", "half_ks2", "rms_np2"])

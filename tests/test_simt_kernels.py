@@ -76,7 +76,8 @@ _OPS = [
 @pytest.mark.parametrize("name,args", _OPS, ids=[f"{n}{list(a)}" for n, a in _OPS])
 def test_gpu_op_bodies_on_the_emulator(emu, name, args):
     import test_ops_gpu
-    getattr(test_ops_gpu, name)(CPU, *args)
+    import test_zz_abi_v9_gpu
+    getattr(test_ops_gpu if hasattr(test_ops_gpu, name) else test_zz_abi_v9_gpu, name)(CPU, *args)
 
 
 _PLANES = [("test_split_planes_roundtrip_and_range_flag", ()), ("test_layernorm_planes", ()), ("test_gemm_planes_transposed_rejects_bad_arguments", ())]

@@ -182,7 +182,21 @@ def _stream_plan(n_tokens, done, exhausted, lookahead):
     return fin, [0 if f else 2 * lookahead for f in fin]
 
 
-def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, chunk=50, lookahead=3, fade=480, max_new_tokens=1000,
+def stream_token_schedule(n_tokens, first_chunk=25, chunk=50, lookahead=3, chunk_growth=1.0):
+    """Tokens available to round 0, 1, 2, ... of synthesize_stream for an utterance of `n_tokens` sampled tokens: first_chunk + lookahead,
+    then `chunk` more per round, each chunk `chunk_growth` times the previous one (1.0: constant chunks -- every round re-runs encoder + CFM
+    over all tokens so far, so the total work grows with the number of rounds; a growth of 2 keeps the first-audio latency and bounds the
+    total at about twice the one-shot synthesis)."""
+    out, n, c = [], min(n_tokens, first_chunk + lookahead), float(chunk)
+    while True:
+        out.append(n)
+        if n >= n_tokens:
+            return out
+        n = min(n_tokens, n + max(1, int(round(c))))
+        c *= chunk_growth
+
+
+def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, chunk=50, chunk_growth=1.0, lookahead=3, fade=480, max_new_tokens=1000,
                       temperature=0.8, top_p=1.0, min_p=0.05, repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False,
                       ban_from=0, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=True):
     """Chunked synthesis: first audio after `first_chunk` tokens instead of after the whole utterance.
@@ -190,7 +204,8 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
     The reference is non-streaming; of its vestigial hooks only HiFT's `cache_source` works (hifigan.py:470-472) -- `finalize=False`
     (flow.py:170-171) raises a shape error there -- so the schedule is this build's own, with its own oracle
     (tests/test_stream_gpu.py restates it on the CPU oracle):
-      * T3 decodes `first_chunk + lookahead` tokens, then `chunk` more per round (graph replays of the same captured step);
+      * T3 decodes `first_chunk + lookahead` tokens, then `chunk` more per round (graph replays of the same captured step), each chunk
+        `chunk_growth` times the previous one (stream_token_schedule: 1.0 = constant chunks; 2.0 halves the number of re-synthesis rounds);
       * every round re-runs encoder + CFM over ALL tokens so far with the same noise realisation, masking the last
         2 * lookahead mel frames of unfinished utterances (the encoder looks 3 tokens ahead), and HiFT with the previous round's source
         as `cache_source` (phase-continuous excitation);
@@ -215,6 +230,7 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
                          repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms, ban_eos=ban_eos, ban_from=ban_from,
                          async_mode=True, run_steps=first_chunk + lookahead)
     emitted, tails, closed, src_cache = [0] * B, [None] * B, [False] * B, None
+    next_chunk = float(chunk)
     ramp = torch.linspace(0.0, 1.0, fade + 2, device=dev)[1:-1]
     while True:
         toks, done = self.t3.peek(h)
@@ -258,7 +274,8 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
         yield dict(wavs=out, final=list(fin), n_tokens=ns)
         if all(closed) or exhausted:
             return
-        self.t3.advance(h, chunk)
+        self.t3.advance(h, max(1, int(round(next_chunk))))
+        next_chunk *= chunk_growth
 
 
 S3GEN_SIL = 4299  # reference models/s3gen/const.py:2

@@ -382,3 +382,19 @@ def test_example_script_fixture_is_the_reference_text():
         ref = os.path.join("/root/reference", name)
         if os.path.exists(ref):
             assert open(ref, encoding="utf-8").read() == e["text"], f"{name}: fixture differs from the reference (re-run tests/golden/make_golden_examples.py)"
+
+
+def test_stream_token_schedule_constant_and_growing_chunks():
+    """engine.stream_token_schedule = the rounds synthesize_stream runs (tests/test_stream_gpu.py pins the constant-chunk form on the GPU):
+    first_chunk + lookahead tokens, then chunk * growth^k more per round; the work of a round is proportional to prompt + tokens so far."""
+    from chatterbox_amd.engine import stream_token_schedule as sched
+    assert sched(20, 6, 7, 3) == [9, 16, 20] and sched(30, 6, 40, 3) == [9, 30]          # the two GPU stream tests
+    assert sched(250, 25, 50, 3) == [28, 78, 128, 178, 228, 250]
+    assert sched(250, 25, 50, 3, 2.0) == [28, 78, 178, 250]
+    assert sched(5, 25, 50, 3) == [5] and sched(28, 25, 50, 3) == [28] and sched(29, 25, 50, 3) == [28, 29]
+    P = 250                                                                             # S3Gen prompt tokens of the bench
+    cost = lambda s: sum(P + n for n in s) / (P + 250)                                  # flow work in units of the one-shot synthesis
+    assert cost(sched(250, 25, 50, 3)) > 4.7 and cost(sched(250, 25, 50, 3, 2.0)) < 3.1
+    for g in (1.0, 1.5, 2.0, 3.0):
+        s = sched(1000, 25, 50, 3, g)
+        assert s[0] == 28 and s[-1] == 1000 and all(b > a for a, b in zip(s, s[1:]))

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 SAMP = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
 
 
-def _oracle_stream(O, s3_sd, tokens, ref, z, phase, noise, first, chunk, lookahead, fade, n_steps):
+def _oracle_stream(O, s3_sd, tokens, ref, z, phase, noise, first, chunk, lookahead, fade, n_steps, growth=1.0):
     """The schedule of engine.synthesize_stream for ONE utterance that never samples EOS (fixed-length synthetic run)."""
     N, P = tokens.numel(), ref["prompt_token"].shape[1]
     pieces, emitted, tail, cache, n = [], 0, None, None, min(N, first + lookahead)
@@ -36,7 +36,8 @@ def _oracle_stream(O, s3_sd, tokens, ref, z, phase, noise, first, chunk, lookahe
         pieces.append(new)
         if final:
             return pieces
-        n = min(N, n + chunk)
+        n = min(N, n + max(1, int(round(chunk))))
+        chunk = chunk * growth
 
 
 def _setup(dev, N, P):

@@ -136,3 +136,24 @@ def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypa
     assert [t.tolist() for t in ra] == [t.tolist() for t in rb]
 
 
+
+
+def test_stream_with_growing_chunks_matches_the_oracle_schedule(dev):
+    """synthesize_stream(chunk_growth=2): rounds at 9 -> 13 -> 21 -> 30 tokens (engine.stream_token_schedule), against the same schedule
+    restated on the CPU oracle (tests/test_stream_gpu.py::_oracle_stream) and, beyond the vocoder's receptive field, the one-shot synthesis."""
+    from chatterbox_amd.engine import stream_token_schedule
+    from oracle import ref_torch as O
+    from test_stream_gpu import _oracle_stream, _setup
+    N, P, first, chunk, look, fade = 30, 8, 6, 4, 3, 240
+    assert stream_token_schedule(N, first, chunk, look, 2.0) == [9, 13, 21, 30]
+    eng, s3_sd, texts, cond, ref, z, phase, noise, kw = _setup(dev, N, P)
+    rounds = list(eng.synthesize_stream(texts, cond, ref, first_chunk=first, chunk=chunk, chunk_growth=2.0, lookahead=look, fade=fade, **kw))
+    assert [r["n_tokens"][0] for r in rounds] == [9, 13, 21, 30] and rounds[-1]["final"] == [True, True]
+    full, toks = eng.synthesize(texts, cond, ref, drop_last_token=True, **kw)
+    for b in range(2):
+        streamed = torch.cat([r["wavs"][b] for r in rounds])
+        assert streamed.numel() == (N - 1) * 960 == full[b].numel()
+        pieces = _oracle_stream(O, s3_sd, toks[b], ref, z[b:b + 1], phase[b:b + 1], noise[b:b + 1], first, chunk, look, fade, 3, growth=2.0)
+        assert [p.numel() for p in pieces] == [r["wavs"][b].numel() for r in rounds]
+        rmse = (streamed - torch.cat(pieces)).pow(2).mean().sqrt().item()
+        assert rmse <= 2e-3, f"utt {b}: streamed vs oracle-streamed RMSE {rmse:.3e}"

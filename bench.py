@@ -326,18 +326,20 @@ def gemv_sweeps(t3, rows, reps=6):
         x, x2, att, g = f(r16, t3.D), f(r16, t3.D), f(r16, t3.D), f(r16, t3.F)
         qkv, gg = torch.empty(rows, 3 * t3.D, device=dev), torch.empty(r16, t3.F, device=dev)
         dks = tn["d_ks2"]
-        ht = bool(tn.get("half_tiles")) and "wo_pk8" in t3.layers[0]
-        pd = f(dks, r16, t3.D) * 0.1
+        t3._prepare_tune()
+        qtc, odtc = t3._tiles()  # output columns per workgroup of the q/k/v resp. o / down projections (T3Engine.tune, CBX_T3_TUNE)
+        qt, ht = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
+        pd = f(max(dks, 1), r16, t3.D) * 0.1
         pk = dict(w_packed=True, x_packed=True, M=rows)
         red = dict(xpart=pd, x_out=x2) if dks > 1 else {}
-        calls = {"qkv": lambda lw: ops.gemv(x, lw["wqkv_pk"], qkv, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], **red, **pk),
-                 "o": lambda lw: ops.gemv(att, lw["wo_pk8"] if ht else lw["wo_pk"], x2, N=t3.D, K=t3.D, nw=tn["o_nw2"], res=x2, out_packed=True,
+        calls = {"qkv": lambda lw: ops.gemv(x, t3._image(lw, "wqkv", qtc), qkv, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk),
+                 "o": lambda lw: ops.gemv(att, t3._image(lw, "wo", odtc), x2, N=t3.D, K=t3.D, nw=tn["o_nw2"], res=x2, out_packed=True,
                                           half_tile=ht, **pk),
                  "gate_up": lambda lw: ops.gemv(x, lw["wgu_pk"], gg, N=t3.F, K=t3.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"],
                                                 out_packed=True, **pk),
-                 "down": (lambda lw: ops.gemv(g, lw["wd_pk8"] if ht else lw["wd_pk"], pd, N=t3.D, K=t3.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True,
+                 "down": (lambda lw: ops.gemv(g, t3._image(lw, "wd", odtc), pd, N=t3.D, K=t3.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True,
                                               half_tile=ht, **pk)) if dks > 1
-                 else (lambda lw: ops.gemv(g, lw["wd_pk"], x2, N=t3.D, K=t3.F, nw=tn["d_nw2"], res=x2, out_packed=True, **pk))}
+                 else (lambda lw: ops.gemv(g, t3._image(lw, "wd", odtc), x2, N=t3.D, K=t3.F, nw=tn["d_nw2"], res=x2, out_packed=True, half_tile=ht, **pk))}
         wbytes = {"qkv": lambda lw: lw["wqkv_pk"].numel() * 4, "o": lambda lw: lw["wo_pk"].numel() * 4,
                   "gate_up": lambda lw: lw["wgu_pk"].numel() * 4, "down": lambda lw: lw["wd_pk"].numel() * 4}
     else:

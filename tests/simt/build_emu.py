@@ -91,7 +91,13 @@ def _rewrite_asm(body, where):
     outs = _operands(secs[1]) if len(secs) > 1 else []
     ins = _operands(secs[2]) if len(secs) > 2 else []
     first = tmpl.strip().split()[0] if tmpl.strip() else ""
-    if first in ("", "s_waitcnt", "s_nop", ";"):
+    if first == "s_waitcnt":
+        m = re.match(r"s_waitcnt vmcnt\((%0|\d+)\)\s*$", tmpl.strip())
+        if m:  # the explicit vector-memory waits: they decide when a deferred LDS-DMA lands (simt_emu.h, CBX_EMU_DMA=deferred)
+            return f"(simt::g_dma_deferred ? simt::vm_wait({ins[0] if m.group(1) == '%0' else m.group(1)}) : (void)0)"
+        assert re.match(r"s_waitcnt (lgkmcnt|vmcnt)\(", tmpl.strip()), (where, tmpl)
+        return "((void)0)"
+    if first in ("", "s_nop", ";"):
         return "((void)0)"
     if first == "v_max3_f32":
         assert re.match(r"v_max3_f32 %0, \|%1\|, \|%2\|, %0", tmpl), (where, tmpl)

@@ -1,6 +1,7 @@
 // SIMT emulator core (test infrastructure, see simt_emu.h): fibers, scheduler, barriers, wave exchange buffers.
 #include <sys/mman.h>
 
+#include <deque>
 #include <vector>
 
 #include "simt_emu.h"
@@ -10,18 +11,27 @@ namespace simt {
 Lane* g_cur = nullptr;
 dim3 g_blockIdx, g_blockDim, g_gridDim;
 int g_last_error = 0;
+bool g_dma_deferred = getenv("CBX_EMU_DMA") && !strcmp(getenv("CBX_EMU_DMA"), "deferred");
 
 namespace {
 
 constexpr size_t STACK_BYTES = 512 * 1024;
 constexpr int MAX_THREADS = 1024;
 
+struct PendingOp {
+    char* dst;
+    int size;  // 0: a buffer load / store (already executed; only occupies its slot of the in-order counter)
+    unsigned char data[16];
+};
+
 struct Fiber {
+    std::deque<PendingOp> vm;  // this lane's outstanding vector-memory operations, oldest first (deferred-DMA mode)
     void* sp = nullptr;
     char* stack = nullptr;
     bool done = false;
     Lane lane;
     unsigned shfl_seq[6];   // pairwise xor shuffles executed per mask
+    int nbar = 0;           // workgroup barriers this thread has reached
     const char* waiting = "";
 };
 
@@ -47,6 +57,21 @@ unsigned long g_progress = 0;
 const std::function<void()>* g_body = nullptr;
 std::vector<unsigned char> g_dyn;
 bool g_abandon = false;
+// CBX_EMU_SCHED=reverse | random[:seed]: the order in which the scheduler resumes the lanes of a workgroup.  Results must not depend on it;
+// a kernel with a missing barrier (a lane reading LDS another lane has not written yet) does.
+int g_sched_mode = 0;
+unsigned long long g_sched_rng = 0x9E3779B97F4A7C15ull;
+struct SchedInit {
+    SchedInit() {
+        const char* e = getenv("CBX_EMU_SCHED");
+        if (!e) return;
+        if (!strncmp(e, "reverse", 7)) g_sched_mode = 1;
+        else if (!strncmp(e, "random", 6)) {
+            g_sched_mode = 2;
+            if (e[6] == ':') g_sched_rng ^= strtoull(e + 7, nullptr, 10) * 0x2545F4914F6CDD1Dull;
+        }
+    }
+} g_sched_init;
 
 extern "C" void simt_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -86,9 +111,18 @@ void release_block() {
     ++g_progress;
 }
 
+void vm_retire(Fiber& f, size_t keep) {
+    while (f.vm.size() > keep) {
+        const PendingOp& o = f.vm.front();
+        if (o.size) memcpy(o.dst, o.data, o.size);
+        f.vm.pop_front();
+    }
+}
+
 void fiber_main() {
     (*g_body)();
     Fiber& f = cur();
+    vm_retire(f, 0);
     f.done = true;
     ++g_progress;
     WaveState& w = g_waves[f.lane.wave];
@@ -114,12 +148,36 @@ void init_fiber(Fiber& f) {
     for (int i = 0; i < 6; ++i) *--sp = nullptr;
     f.sp = sp;
     f.done = false;
+    f.vm.clear();
+    f.nbar = 0;
     f.lane.xpar = 0;
     memset(f.shfl_seq, 0, sizeof(f.shfl_seq));
     f.waiting = "";
 }
 
 }  // namespace
+
+void vm_push_dma(void* dst, const void* src, int size) {
+    PendingOp o;
+    o.dst = (char*)dst;
+    o.size = size;
+    if (size > 16) {
+        fprintf(stderr, "simt: LDS-DMA of %d bytes per lane\n", size);
+        abort();
+    }
+    if (src) memcpy(o.data, src, size);
+    else memset(o.data, 0, size);
+    cur().vm.push_back(o);
+}
+void vm_push_other() {
+    PendingOp o;
+    o.dst = nullptr;
+    o.size = 0;
+    cur().vm.push_back(o);
+}
+// CBX_EMU_DMA_SLACK=k weakens every explicit wait by k operations: the self-check that the deferred mode can fail (tests/test_simt_kernels.py)
+static int g_vm_slack = getenv("CBX_EMU_DMA_SLACK") ? atoi(getenv("CBX_EMU_DMA_SLACK")) : 0;
+void vm_wait(int n) { vm_retire(cur(), (n < 0 ? 0 : (size_t)n) + (size_t)g_vm_slack); }
 
 void yield() {
     Fiber& f = cur();
@@ -139,7 +197,11 @@ void wave_sync() {
     while (w.gen == g);
 }
 
+// CBX_EMU_DROP_BARRIER=k: every thread skips its k-th workgroup barrier -- the self-check that the scheduling modes can see a missing barrier
+static int g_drop_barrier = getenv("CBX_EMU_DROP_BARRIER") ? atoi(getenv("CBX_EMU_DROP_BARRIER")) : -1;
+
 void block_sync() {
+    if (g_drop_barrier >= 0 && cur().nbar++ == g_drop_barrier) return;
     if (++g_block.arrived == g_block.alive) {
         release_block();
         return;
@@ -209,9 +271,18 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
                     f.lane.wave_x = &g_waves[t / WAVE].xbuf[0][0][0];
                 }
                 int remaining = nthreads;
+                static std::vector<int> order;
+                order.resize(nthreads);
+                for (int t = 0; t < nthreads; ++t) order[t] = g_sched_mode == 1 ? nthreads - 1 - t : t;
                 while (remaining > 0) {
                     const unsigned long before = g_progress;
-                    for (int t = 0; t < nthreads; ++t) {
+                    if (g_sched_mode == 2)  // a fresh permutation per sweep: lanes (and waves) overtake each other wherever no barrier forbids it
+                        for (int t = nthreads - 1; t > 0; --t) {
+                            g_sched_rng = g_sched_rng * 6364136223846793005ull + 1442695040888963407ull;
+                            std::swap(order[t], order[(int)((g_sched_rng >> 33) % (unsigned)(t + 1))]);
+                        }
+                    for (int oi = 0; oi < nthreads; ++oi) {
+                        const int t = order[oi];
                         Fiber& f = g_fibers[t];
                         if (f.done) continue;
                         g_curf = t;

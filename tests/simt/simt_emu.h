@@ -82,6 +82,14 @@ inline unsigned char* xslot_of(int lane) { return g_cur->wave_x + (g_cur->xpar *
 inline unsigned char* xslot_mine() { return xslot_of(g_cur->lane); }
 inline void xflip() { g_cur->xpar ^= 1; }
 inline int wave_lanes() { return g_cur->wave_lanes; }
+// Vector-memory completion order (CBX_EMU_DMA=deferred): an LDS-DMA does not land when it is issued but when its lane waits for it --
+// `s_waitcnt vmcnt(n)` (the explicit asm waits of the sources), `__syncthreads()` (which carries a vmcnt(0)) or the end of the kernel --
+// i.e. as LATE as the kernel's own waits allow.  Buffer loads / stores through the builtins occupy a slot of the same in-order queue.
+// A kernel whose counted waits are too weak then reads stale LDS deterministically, instead of once in a while on the hardware.
+extern bool g_dma_deferred;
+void vm_push_dma(void* dst, const void* src, int size);  // src == nullptr: zeros (out-of-range lanes)
+void vm_push_other();
+void vm_wait(int n);
 // pairwise mailbox of the power-of-two xor shuffles (lane groups of one wave may have diverged: decode attention)
 unsigned long long shfl_xor_pair(unsigned long long bits, int mask_log2);
 }  // namespace simt
@@ -106,7 +114,10 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     ((void)(stream), simt::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); }))
 
-static inline void __syncthreads() { simt::block_sync(); }
+static inline void __syncthreads() {
+    if (simt::g_dma_deferred) simt::vm_wait(0);  // the compiler's __syncthreads drains the wave's vector-memory counter
+    simt::block_sync();
+}
 
 // ---------------------------------------------------------------------------------------------------------------- scalar helpers
 #define __expf(x) expf(x)
@@ -369,17 +380,20 @@ typedef unsigned simt_u32x4 __attribute__((ext_vector_type(4)));
 static inline bool simt_in_range(const simt_rsrc& rs, long off, int bytes) { return off >= 0 && (unsigned long)off + (unsigned)bytes <= rs.num_records; }
 static inline simt_u32x4 simt_buffer_load_b128(simt_rsrc rs, int voff, int soff, int) {
     simt_u32x4 v = {0, 0, 0, 0};
+    if (simt::g_dma_deferred) simt::vm_push_other();
     const long off = (long)(unsigned)voff + (long)(unsigned)soff;  // 32-bit unsigned offsets, as the hardware adds them
     if (simt_in_range(rs, off, 16)) memcpy(&v, rs.base + off, 16);
     return v;
 }
 static inline unsigned simt_buffer_load_b32(simt_rsrc rs, int voff, int soff, int) {
     unsigned v = 0;
+    if (simt::g_dma_deferred) simt::vm_push_other();
     const long off = (long)(unsigned)voff + (long)(unsigned)soff;
     if (simt_in_range(rs, off, 4)) memcpy(&v, rs.base + off, 4);
     return v;
 }
 template <class T> static inline void simt_buffer_store(T v, simt_rsrc rs, int voff, int soff, int) {
+    if (simt::g_dma_deferred) simt::vm_push_other();
     const long off = (long)(unsigned)voff + (long)(unsigned)soff;
     if (simt_in_range(rs, off, (int)sizeof(T))) memcpy(rs.base + off, &v, sizeof(T));
 }
@@ -392,11 +406,14 @@ template <class T> static inline void simt_buffer_store(T v, simt_rsrc rs, int v
 template <class L> static inline void simt_buffer_load_lds(simt_rsrc rs, L lds, int size, int voff, int soff, int imm, int) {
     char* dst = (char*)(uintptr_t)lds + (long)simt::g_cur->lane * size;
     const long off = (long)(unsigned)voff + (long)(unsigned)soff + imm;
-    if (simt_in_range(rs, off, size)) memcpy(dst, rs.base + off, size);
+    const bool ok = simt_in_range(rs, off, size);
+    if (simt::g_dma_deferred) return simt::vm_push_dma(dst, ok ? rs.base + off : nullptr, size);
+    if (ok) memcpy(dst, rs.base + off, size);
     else memset(dst, 0, size);
 }
 template <class G, class L> static inline void simt_global_load_lds(G src, L lds, int size, int imm, int) {
     char* dst = (char*)(uintptr_t)lds + (long)simt::g_cur->lane * size;
+    if (simt::g_dma_deferred) return simt::vm_push_dma(dst, (const char*)(uintptr_t)src + imm, size);
     memcpy(dst, (const char*)(uintptr_t)src + imm, size);
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(...) simt_buffer_load_lds(__VA_ARGS__)

@@ -390,3 +390,38 @@ def test_model_level_golden_bodies_on_the_emulator(emu, name, args):
     (measured once: 31 minutes for the flow golden).  Opt-in."""
     import test_models_gpu
     getattr(test_models_gpu, name)(CPU, *args)
+
+
+def _rerun(env, select):
+    """A fresh pytest process of THIS file under emulator switches that are read when the emulated library loads."""
+    import subprocess
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", select], env=e, capture_output=True, text=True,
+                       cwd=os.path.dirname(HERE))
+    return r.returncode, (r.stdout + r.stderr)[-1500:]
+
+
+_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or mlp_planes_small or conv_and_transposed_columns"
+
+
+def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):
+    """CBX_EMU_DMA=deferred: every LDS-DMA lands only when its lane's own explicit `s_waitcnt vmcnt(n)` (or a __syncthreads / the kernel's
+    end) retires it -- as late as the sources' counted waits allow, with the epilogue's buffer loads / stores occupying their slots of the
+    in-order counter.  The plane GEMM (symmetric, loader-wave, persistent, 2-4 stage rings), the plane attention (three versions) and the
+    fused MLP must still be exact: their waits do not lean on timing.  Self-check: with every wait weakened by ONE operation
+    (CBX_EMU_DMA_SLACK=1) the same tests must fail."""
+    rc, out = _rerun({"CBX_EMU_DMA": "deferred"}, _DMA_TESTS)
+    assert rc == 0, out
+    rc, out = _rerun({"CBX_EMU_DMA": "deferred", "CBX_EMU_DMA_SLACK": "1"}, "gemm_planes_tiles_small and 21-1")
+    assert rc != 0, "weakened waits went unnoticed: the deferred-DMA mode is not effective\n" + out
+
+
+def test_results_do_not_depend_on_the_lane_schedule(emu):
+    """CBX_EMU_SCHED=random: the scheduler resumes the lanes of a workgroup in a fresh random order every sweep, so lanes and waves overtake
+    each other wherever no barrier (or exchange) forbids it; a kernel with a missing barrier then reads LDS that has not been written.
+    Self-check: with the first barrier of every thread dropped (CBX_EMU_DROP_BARRIER=0) the same selection must fail."""
+    sel = "test_sampler or test_layernorm_rmsnorm or test_flash_attn or gemm_planes_tiles_small or decode_attn_rope or test_gemv_packed_rms_fused or test_hift"
+    rc, out = _rerun({"CBX_EMU_SCHED": "random:5"}, sel)
+    assert rc == 0, out
+    rc, out = _rerun({"CBX_EMU_SCHED": "random:5", "CBX_EMU_DROP_BARRIER": "0"}, "test_gemv_decode or test_linear")  # the K-slice reduction through LDS
+    assert rc != 0, "a dropped barrier went unnoticed\n" + out

@@ -39,6 +39,7 @@ struct WaveState {
     int lanes = 0, alive = 0, arrived = 0;
     unsigned gen = 0;
     alignas(16) unsigned char xbuf[2][WAVE][XSLOT];
+    alignas(16) float result[2][32 * 32];  // D tile of the MFMA in flight (written by the last arriver), by exchange parity
     unsigned shfl_post[WAVE][6];
     unsigned long long shfl_box[WAVE][6][2];
 };
@@ -199,6 +200,21 @@ void wave_sync() {
 
 // CBX_EMU_DROP_BARRIER=k: every thread skips its k-th workgroup barrier -- the self-check that the scheduling modes can see a missing barrier
 static int g_drop_barrier = getenv("CBX_EMU_DROP_BARRIER") ? atoi(getenv("CBX_EMU_DROP_BARRIER")) : -1;
+
+// Split form of wave_sync for collectives whose result is computed ONCE: the last lane to arrive computes, then releases the others.
+bool wave_arrive_last() {
+    WaveState& w = wave();
+    return ++w.arrived == w.alive;
+}
+void wave_release() { release_wave(wave()); }
+void wave_wait_released() {
+    WaveState& w = wave();
+    const unsigned g = w.gen;
+    cur().waiting = "MFMA";
+    do yield();
+    while (w.gen == g);
+}
+float* wave_result() { return wave().result[cur().lane.xpar]; }
 
 void block_sync() {
     if (g_drop_barrier >= 0 && cur().nbar++ == g_drop_barrier) return;

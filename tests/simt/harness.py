@@ -63,7 +63,9 @@ def emulated():
 
     def ensure_decode_attn_workspace(device):
         _lib.check(emu.cbx_set_decode_attn_workspace(da_ws[0].data_ptr(), da_ws[1].data_ptr(), 128), "cbx_set_decode_attn_workspace")
+        ops._DA_WS[0] = da_ws
 
+    saved_da = dict(ops._DA_WS)
     saved = dict(erf=ops.enable_range_flag, eda=ops.ensure_decode_attn_workspace, lib_l=_lib.lib, lib_o=ops.lib, stream=ops._stream, f32=ops._f32, pinit=ops.Planes.__init__, sync=torch.cuda.synchronize,
                  flags=dict(ops._RANGE_FLAGS), dev_index=ops._dev_index, cur_dev=torch.cuda.current_device)
     _lib.lib = ops.lib = emu
@@ -86,3 +88,5 @@ def emulated():
         ops.enable_range_flag, ops.ensure_decode_attn_workspace = saved["erf"], saved["eda"]
         ops._RANGE_FLAGS.clear()
         ops._RANGE_FLAGS.update(saved["flags"])
+        ops._DA_WS.clear()
+        ops._DA_WS.update(saved_da)

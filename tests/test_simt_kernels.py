@@ -56,7 +56,7 @@ _OPS = [
     ("test_hift_source_stft_istft", ()),
     ("test_gemv_decode", (16, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)),
     ("test_gemv_swiglu", ()),
-    ("test_decode_attn_rope_fused", ()),
+    ("test_decode_attn_rope_fused", ()), ("test_decode_attn_rope_split_context", (2, 16, True, 1)),
     ("test_gemv_packed_rms_fused", (16, 3072, 1024, False, 8)), ("test_gemv_packed_rms_fused", (16, 4096, 1024, True, 8)),
     ("test_gemv_packed_residual_epilogue", (16, 1024, 1024, 16)), ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)),
     ("test_gemv_packed_residual_epilogue", (16, 64, 256, 4)),

@@ -10,6 +10,7 @@
 //     per 32-deep block instead of 512 lane-FMAs + a cross-lane reduction;
 //   * K is split over the waves of a workgroup (reduced through LDS in fixed order) and optionally over workgroups
 //     (partials reduced by the consumer kernel, cbx_add_rmsnorm_f32) -- deterministic, no atomics.
+#include <stdlib.h>
 #include "cbx_common.h"
 
 namespace {
@@ -36,7 +37,9 @@ __device__ __forceinline__ f32x4 bf16x4_widen(const u32x4 u, int h) {
 // cbx_gemv_t.half_tile -> output columns per workgroup (0: 16; 1 or 8: 8; 12; 4)
 __host__ __device__ __forceinline__ int gemv_tile_cols(int half_tile) { return half_tile == 0 ? 16 : half_tile == 1 ? 8 : half_tile; }
 
-template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false>
+// D8: eight K blocks (instead of four) requested before the first MFMA -- for a wave whose K slice is >= 256 deep (the down projection
+// without split-K partials: K = 4096 over 16 waves) the whole slice is then ONE batch of loads instead of two dependent ones.
+template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false, bool D8 = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
     static_assert(!WB || (PK && XPK), "bf16 weights: packed operands only");
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         ss[t] = 0.f;
         sx[t] = 0.f;
     }
-    constexpr int DEPTH = (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
+    constexpr int DEPTH = D8 ? 8 : (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
     // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
@@ -257,11 +260,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     }
 }
 
+int g_gemv_deep = getenv("CBX_GEMV_DEEP") ? atoi(getenv("CBX_GEMV_DEEP")) : 0;  // cbx_set_gemv_deep_batches
+
 template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0, bool WB = false>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     const int tc = PK ? gemv_tile_cols(p.half_tile) : 16;
     dim3 grid((p.N + tc - 1) / tc, p.ksplit);
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
+        if constexpr (PK) {  // a K slice of >= 256 per wave (ABI v9: the down projection with ksplit = 1 on 8 waves): batches of 8 K blocks in flight.
+            // 8-wave workgroups only: with 16 waves (128 VGPRs per wave) the 8-deep form spills
+            if (g_gemv_deep && p.nw >= 8 && p.nw != 16 && p.K / (p.ksplit * 8) >= 256) {
+                hipLaunchKernelGGL((gemv_kernel<1, 8, false, true, true, false, 0, WB, true>), grid, dim3(512), 0, st, p);
+                return cbx_check_launch("gemv");
+            }
+        }
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
             hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0, WB>), grid, dim3(1024), 0, st, p);
             return cbx_check_launch("gemv");
@@ -492,6 +504,11 @@ extern "C" int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int
     hipLaunchKernelGGL(pack_gemv_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N, K,
                        ld_src, swiglu, n4, half_tile);
     return cbx_check_launch("pack_gemv_weight");
+}
+
+extern "C" int cbx_set_gemv_deep_batches(int on) {
+    g_gemv_deep = on != 0;
+    return 0;
 }
 
 extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {

@@ -187,6 +187,9 @@ int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld
 /* the same image with the weights rounded (RNE) to bf16: [tile][K/32][lanes][8 bf16] (cbx_gemv_t.w_bf16); dst holds half the bytes */
 int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
+/* ABI v9, A/B knob (env CBX_GEMV_DEEP, default 0): 1 = an 8-wave plain packed GEMV whose waves own >= 256 of K (the down projection with
+ * ksplit = 1) requests 8 K blocks per batch instead of 4 -- half the dependent load batches; bit-identical results. */
+int cbx_set_gemv_deep_batches(int on);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,

@@ -67,6 +67,7 @@ _OPS = [
     ("test_gemv_half_tile", (16, 1024, 4096, 2, 8, False)), ("test_gemv_half_tile", (16, 1024, 1024, 1, 8, True)), ("test_gemv_half_tile", (9, 40, 256, 1, 4, False)),
     ("test_gemv_bf16_weights_equal_rounded_fp32", ("plain",)), ("test_gemv_bf16_weights_equal_rounded_fp32", ("rms_np2",)),
     ("test_decode_attn_rope_pipelined_equals_plain", (3, 16, True, 512)), ("test_decode_attn_rope_pipelined_equals_plain", (1, 12, False, 1)),
+    ("test_gemv_deep_batches_equal_plain", (16, 1024, 4096, 1, 4, True)), ("test_gemv_deep_batches_equal_plain", (9, 64, 2048, 1, 0, False)),
     ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2")), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
     ("test_gemv_narrow_tiles", (9, 1024, 4096, 1, 8, 4, "plain")), ("test_gemv_narrow_tiles", (5, 40, 256, 2, 4, 12, "plain")),
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),

@@ -157,3 +157,29 @@ def test_stream_with_growing_chunks_matches_the_oracle_schedule(dev):
         assert [p.numel() for p in pieces] == [r["wavs"][b].numel() for r in rounds]
         rmse = (streamed - torch.cat(pieces)).pow(2).mean().sqrt().item()
         assert rmse <= 2e-3, f"utt {b}: streamed vs oracle-streamed RMSE {rmse:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K,ks,tile,res", [(16, 1024, 4096, 1, 4, True), (16, 1024, 4096, 2, 8, False), (9, 64, 2048, 1, 0, False)])
+def test_gemv_deep_batches_equal_plain(dev, M, N, K, ks, tile, res):
+    """cbx_set_gemv_deep_batches(1): an 8-wave plain packed GEMV whose waves own >= 256 of K requests 8 K blocks per load batch instead of 4
+    (the partial-free down projection: K = 4096 over 8 waves).  Same blocks in the same order: bit-identical."""
+    from chatterbox_amd import ops
+    x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, (N + 31) // 32 * 32), 3)
+    xp, wp = ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(w.to(dev), half_tile=tile)
+    kw = dict(N=N, M=M, K=K, ksplit=ks, nw=8, w_packed=True, x_packed=True, half_tile=tile)
+    outs = []
+    try:
+        for deep in (0, 1):
+            ops.lib.cbx_set_gemv_deep_batches(deep)
+            if res:
+                o = ops.pack_gemv_weight(r.to(dev))
+                ops.gemv(xp, wp, o, res=o, out_packed=True, **kw)
+            else:
+                o = torch.zeros((ks, M, N) if ks > 1 else (M, N), device=dev)
+                ops.gemv(xp, wp, o, **kw)
+            outs.append(o.cpu())
+    finally:
+        ops.lib.cbx_set_gemv_deep_batches(0)
+    assert torch.equal(outs[0], outs[1])
+    got = _unpack_operand(outs[1], M, N) - r[:, :N] if res else (outs[1].sum(0) if ks > 1 else outs[1])
+    _close(got, F.linear(x, w), 6e-5 * max(1.0, math.sqrt(K / 256)), "deep-batch gemv")

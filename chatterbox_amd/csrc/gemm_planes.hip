@@ -184,9 +184,16 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
 #else
 #define DG(bit) 0
 #endif
-    constexpr int EPI_OPS = TM * TN * 16;  // vector-memory operations every epilogue issues at least (one output kind)
+    constexpr int EPI_OPS = TM * TN * 16;  // vector-memory operations every epilogue issues at least (one output kind: C or P)
     [[maybe_unused]] constexpr int W_EPI0 = (NS - 2) * LPW + EPI_OPS > 63 ? 63 : (NS - 2) * LPW + EPI_OPS;  // first K tile after an epilogue
     [[maybe_unused]] constexpr int W_EPI1 = LPW + EPI_OPS > 63 ? 63 : LPW + EPI_OPS;                          // NS = 3: second K tile after an epilogue
+    // ... except the epilogue of a TRANSPOSED tile (PT, ABI v8), which issues 8-byte stores: HALF as many operations.  Counting 16 per
+    // 32 x 32 tile behind it would let up to TM * TN * 8 of the OLDER operations -- the DMAs of the K tile about to be consumed -- stay
+    // outstanding.  (Found by the emulator's deferred-DMA mode, tests/simt/: never observed on the GPU, where an epilogue outlasts a DMA.)
+    constexpr int EPI_OPS_T = TM * TN * 8;
+    [[maybe_unused]] constexpr int W_EPI0T = (NS - 2) * LPW + EPI_OPS_T > 63 ? 63 : (NS - 2) * LPW + EPI_OPS_T;
+    [[maybe_unused]] constexpr int W_EPI1T = LPW + EPI_OPS_T > 63 ? 63 : LPW + EPI_OPS_T;
+    bool prev_t = false;  // the previous tile of this workgroup was a transposed one
     int c_g = 0;  // consumer ring position
     if (is_loader) {  // ---- the loader wave: wait for K tile g, release it to the consumers at the barrier, issue K tile g + NS - 1
 #pragma unroll
@@ -220,8 +227,13 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         for (int kt = 0; kt < nk; ++kt) {
             if (!LD) {
                 const int younger = l_g - c_g - 1;  // K tiles issued after the one consumed now (0 .. NS - 2)
-                if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0) : "memory");
-                else if (NS == 3 && after_epi && kt == 1 && younger == 1 && !DG(5)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1) : "memory");
+                if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) {
+                    if (prev_t) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0T) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI0) : "memory");
+                } else if (NS == 3 && after_epi && kt == 1 && younger == 1 && !DG(5)) {
+                    if (prev_t) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1T) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_EPI1) : "memory");
+                }
                 else if (NS == 3 && younger == 1 && !DG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -251,6 +263,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     const __amdgpu_buffer_rsrc_t t_rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<_Float16*>(p.PT), 0, p.PT ? (int)((((long)(p.M / (p.pt_T > 0 ? p.pt_T : 1)) - 1) * p.pt_zs + ((long)(p.N - p.pt_n0) - 1) * p.pt_ld + p.pt_lo + p.pt_T) * 2) : 0, 0x00020000);
     const bool hasC = p.C != nullptr && !vt_tile, hasP = p.P != nullptr && !vt_tile, hasR = p.R != nullptr && !vt_tile;
+    prev_t = vt_tile;
     const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4, ldp2 = (int)p.ldp * 2;
     const bool odd = lr & 1;
     float amax = 0.f;

@@ -145,6 +145,30 @@ def test_gemm_planes_conv_and_transposed_columns_small(emu):
     assert float(vt[:, :, T2:].abs().max()) == 0.0, "pad keys of V^T stay zero"
 
 
+@pytest.mark.parametrize("tile", [4, 9, 14])
+def test_gemm_planes_transposed_walk_small(emu, tile):
+    """q | k | V^T from one launch on a PERSISTENT grid of 2 workgroups: every workgroup walks 12+ tiles, transposed (V^T) tiles followed by
+    q | k tiles.  Under CBX_EMU_DMA=deferred this is the case that exposed a too-weak counted wait behind the transposed epilogue (8-byte
+    stores = half the operations the wait assumed): fixed in gemm_planes.hip (W_EPI0T); the body runs in both modes."""
+    from chatterbox_amd import ops
+    from test_planes_gpu import _close, _planes_exact, _r
+    try:
+        emu.cbx_set_planes_tile(tile)
+        emu.cbx_set_planes_persist(2)
+        Z, T = 2, 100
+        M, K, N, n0, Tp = Z * T, 256, 1536, 1024, 104
+        h, w = _r((M, K), 1), _r((N, K), 2, 1 / 16)
+        hP, wP = ops.split_planes(h), ops.split_planes(w)
+        qkP, vtP = ops.Planes(M, n0, CPU), ops.Planes(Z * 512, Tp, CPU, zero=True)
+        ops.gemm_planes(hP, wP, M=M, N=N, K=K, P=qkP, PT=vtP, pt_n0=n0, pt_T=T, pt_zs=512 * vtP.ld)
+        ref = F.linear(_planes_exact(h), _planes_exact(w))
+        _close(qkP.float(), ref[:, :n0], 3e-5, f"q | k columns, tile {tile}")
+        _close(vtP.float().view(Z, 512, Tp)[:, :, :T], ref[:, n0:].view(Z, T, 512).transpose(1, 2), 3e-5, f"V^T, tile {tile}")
+    finally:
+        emu.cbx_set_planes_tile(0)
+        emu.cbx_set_planes_persist(1)
+
+
 @pytest.mark.parametrize("version", [2, 1, 4])
 def test_flash_attn_planes_small(emu, version):
     """tests/test_planes_gpu.py::test_flash_attn_planes at emulator-sized shapes (ragged key lengths incl. an empty utterance)."""
@@ -402,7 +426,7 @@ def _rerun(env, select):
     return r.returncode, (r.stdout + r.stderr)[-1500:]
 
 
-_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or mlp_planes_small or conv_and_transposed_columns"
+_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or mlp_planes_small or conv_and_transposed_columns or transposed_walk"
 
 
 def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):

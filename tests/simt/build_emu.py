@@ -18,11 +18,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "chatterbox_amd", "csrc")
-GEN = os.path.join(HERE, "_gen")
-LIB = os.path.join(HERE, "libcbx_emu.so")
+# CBX_EMU_ASAN=1: an AddressSanitizer build (libcbx_emu_asan.so): out-of-range reads / writes of the kernels on host buffers become
+# reports.  Run the Python process with LD_PRELOAD=$(clang++ -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0
+ASAN = os.environ.get("CBX_EMU_ASAN") == "1"
+LIB = os.path.join(HERE, "libcbx_emu_asan.so" if ASAN else "libcbx_emu.so")
+GEN = os.path.join(HERE, "_gen_asan" if ASAN else "_gen")
 CLANG = os.environ.get("CBX_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-fno-strict-aliasing", "-Wno-everything", "-ffp-contract=off",
-         "-I", os.path.join(HERE, "shim"), "-I", HERE]
+         "-I", os.path.join(HERE, "shim"), "-I", HERE] + (["-fsanitize=address", "-fsanitize-recover=address", "-fno-omit-frame-pointer", "-g"] if os.environ.get("CBX_EMU_ASAN") == "1" else [])
 
 
 def _match_paren(s, i):
@@ -177,7 +180,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     core = os.path.join(GEN, "simt_core.o")
-    procs.append(("simt_core.cpp", subprocess.Popen([CLANG, "-std=c++17", "-O2", "-fPIC", "-Wno-everything", "-I", os.path.join(HERE, "shim"), "-I", HERE, "-c",
+    procs.append(("simt_core.cpp", subprocess.Popen([CLANG, "-std=c++17", "-O2", "-fPIC", "-Wno-everything", *(["-fsanitize=address", "-g"] if ASAN else []), "-I", os.path.join(HERE, "shim"), "-I", HERE, "-c",
                                                      os.path.join(HERE, "simt_core.cpp"), "-o", core], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     fail = False
     for name, pr in procs:
@@ -187,7 +190,7 @@ def build(force=False, verbose=False):
             sys.stderr.write(f"--- {name} failed:\n{o.decode()[:6000]}\n")
     if fail:
         raise RuntimeError("emulator build failed")
-    subprocess.check_call([CLANG, "-shared", "-fPIC", *objs, core, "-o", LIB])
+    subprocess.check_call([CLANG, "-shared", "-fPIC", *(["-fsanitize=address", "-shared-libasan"] if ASAN else []), *objs, core, "-o", LIB])
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB

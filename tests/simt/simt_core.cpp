@@ -49,6 +49,8 @@ struct BlockState {
     unsigned gen = 0;
 };
 
+const void* g_main_bottom = nullptr;  // the scheduler's (OS thread's) stack, as AddressSanitizer wants it named on a switch back
+size_t g_main_size = 0;
 Fiber g_fibers[MAX_THREADS];
 std::vector<WaveState> g_waves;
 BlockState g_block;
@@ -74,6 +76,13 @@ struct SchedInit {
     }
 } g_sched_init;
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SIMT_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+#endif
 extern "C" void simt_switch(void** save_sp, void* load_sp);
 asm(R"(
     .text
@@ -121,6 +130,9 @@ void vm_retire(Fiber& f, size_t keep) {
 }
 
 void fiber_main() {
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_main_bottom, &g_main_size);  // first entry: learn the scheduler's stack
+#endif
     (*g_body)();
     Fiber& f = cur();
     vm_retire(f, 0);
@@ -130,6 +142,9 @@ void fiber_main() {
     // a finished lane no longer takes part in barriers / exchanges (s_barrier counts the waves still running)
     if (--w.alive > 0 && w.arrived == w.alive) release_wave(w);
     if (--g_block.alive > 0 && g_block.arrived == g_block.alive) release_block();
+#ifdef SIMT_ASAN
+    __sanitizer_start_switch_fiber(nullptr, g_main_bottom, g_main_size);  // nullptr: this fiber's fake stack is released
+#endif
     simt_switch(&f.sp, g_sched_sp);
     abort();  // never resumed
 }
@@ -182,7 +197,14 @@ void vm_wait(int n) { vm_retire(cur(), (n < 0 ? 0 : (size_t)n) + (size_t)g_vm_sl
 
 void yield() {
     Fiber& f = cur();
+#ifdef SIMT_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, g_main_bottom, g_main_size);
     simt_switch(&f.sp, g_sched_sp);
+    __sanitizer_finish_switch_fiber(fake, &g_main_bottom, &g_main_size);
+#else
+    simt_switch(&f.sp, g_sched_sp);
+#endif
 }
 void note_progress() { ++g_progress; }
 
@@ -303,7 +325,14 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
                         if (f.done) continue;
                         g_curf = t;
                         g_cur = &f.lane;
+#ifdef SIMT_ASAN
+                        void* fake = nullptr;
+                        __sanitizer_start_switch_fiber(&fake, f.stack, STACK_BYTES);
                         simt_switch(&g_sched_sp, f.sp);
+                        __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+                        simt_switch(&g_sched_sp, f.sp);
+#endif
                         if (f.done) --remaining;
                     }
                     if (remaining > 0 && g_progress == before) {

@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04/first
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -x -q -m gpu \
-    -k "narrow_tiles or pipelined or tile_variants or c_level_decode_step or half_tile or decode_attn" > $O/pytest_v9.log 2>&1
+timeout 900 python -m pytest tests/test_zz_abi_v9_gpu.py tests/test_ops_gpu.py tests/test_models_gpu.py tests/test_planes_gpu.py -q -m gpu \
+    -k "abi_v9 or c_level_decode_step or half_tile or decode_attn or transposed_column_range or stream" > $O/pytest_v9.log 2>&1
 tail -3 $O/pytest_v9.log
 # T3 stage time, B = 8, 250 tokens, 30 layers: index 3 = the shipped default, 6.. = the round-3 variants (scripts/t3_decode_time.py VARIANTS)
 T3_VARIANTS=3,6,7,8,9,10,11,12,13,14,15 timeout 700 python scripts/t3_decode_time.py > $O/t3_decode_variants.log 2>&1

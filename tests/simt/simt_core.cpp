@@ -285,9 +285,20 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
     const int nwaves = (nthreads + WAVE - 1) / WAVE;
     if ((int)g_waves.size() < nwaves) g_waves.resize(nwaves);
     g_dyn.assign(dyn_bytes + 16, 0xCD);  // LDS is not zero-initialised
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // workgroups run one after the other, in dispatch order -- or, under CBX_EMU_SCHED, reversed / shuffled: nothing may depend on it
+    // (the split-context decode attention must merge in split order whoever arrives last)
+    const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
+    static std::vector<unsigned long> border;
+    border.resize(nblocks);
+    for (unsigned long b = 0; b < nblocks; ++b) border[b] = g_sched_mode == 1 ? nblocks - 1 - b : b;
+    if (g_sched_mode == 2)
+        for (unsigned long b = nblocks - 1; b > 0; --b) {
+            g_sched_rng = g_sched_rng * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(border[b], border[(unsigned long)((g_sched_rng >> 33) % (b + 1))]);
+        }
+    for (unsigned long bi = 0; bi < nblocks; ++bi) {
+            {
+                const unsigned bx = (unsigned)(border[bi] % grid.x), by = (unsigned)((border[bi] / grid.x) % grid.y), bz = (unsigned)(border[bi] / ((unsigned long)grid.x * grid.y));
                 g_blockIdx = dim3(bx, by, bz);
                 g_block = BlockState();
                 g_block.alive = nthreads;
@@ -346,6 +357,7 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
                     }
                 }
             }
+    }
     g_cur = nullptr;
     return 0;
 }

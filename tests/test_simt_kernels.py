@@ -444,8 +444,9 @@ def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):
 def test_results_do_not_depend_on_the_lane_schedule(emu):
     """CBX_EMU_SCHED=random: the scheduler resumes the lanes of a workgroup in a fresh random order every sweep, so lanes and waves overtake
     each other wherever no barrier (or exchange) forbids it; a kernel with a missing barrier then reads LDS that has not been written.
+    The workgroups of a launch run in a shuffled order too (the split-context decode attention must merge in split order whoever arrives last).
     Self-check: with the first barrier of every thread dropped (CBX_EMU_DROP_BARRIER=0) the same selection must fail."""
-    sel = ("test_sampler or test_layernorm_rmsnorm or test_flash_attn or decode_attn_rope_fused or test_hift or (gemm_planes_tiles_small and 21-1) "
+    sel = ("test_sampler or test_layernorm_rmsnorm or test_flash_attn or decode_attn_rope_fused or split_context or test_hift or (gemm_planes_tiles_small and 21-1) "
            "or (gemm_planes_tiles_small and 3-8) or (test_gemv_packed_rms_fused and False) or flash_attn_planes_small")
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5"}, sel)
     assert rc == 0, out

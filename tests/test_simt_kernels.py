@@ -408,11 +408,14 @@ def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
 
 
 @pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="model-level emulator runs take minutes to half an hour each: CBX_EMU_SLOW=1")
-@pytest.mark.parametrize("name,args", [("test_flow_vs_reference_golden", (None,)), ("test_hift_vs_reference_golden", ()), ("test_meanflow_vs_reference_golden", ())])
+@pytest.mark.parametrize("name,args", [("test_flow_vs_reference_golden", (None,)), ("test_hift_vs_reference_golden", ()), ("test_meanflow_vs_reference_golden", ()),
+                                       ("test_flow_batched_ragged_vs_oracle", ()), ("test_hift_batched_ragged_vs_oracle", ()),
+                                       ("test_flow_and_vocoder_with_one_voice_per_utterance", ()), ("test_t3_turbo_batched_vs_oracle", ())])
 def test_model_level_golden_bodies_on_the_emulator(emu, name, args):
     """tests/test_models_gpu.py bodies against the REFERENCE's golden vectors, executed by the emulator: the whole S3Gen flow (conformer encoder
     + 10-step CFG CFM on the plane-format estimator, 56 transformer blocks) reproduces the reference's mel at the fp32 tolerances on the CPU
-    (measured: flow golden 31 min before the emulator's MFMA fast path, HiFT golden 140 s, meanflow golden 59 s; all three pass).  Opt-in."""
+    (measured: flow golden 31 min before the emulator's MFMA fast path, HiFT golden 140 s, meanflow golden 59 s; all three pass; under CBX_EMU_SCHED=random CBX_EMU_DMA=deferred the ragged-batch flow / HiFT bodies
+    and the mixed-voice batch pass against the oracle in 4 / 3 / 7 min).  Opt-in."""
     import test_models_gpu
     getattr(test_models_gpu, name)(CPU, *args)
 

@@ -410,7 +410,7 @@ def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
 @pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="model-level emulator runs take minutes to half an hour each: CBX_EMU_SLOW=1")
 @pytest.mark.parametrize("name,args", [("test_flow_vs_reference_golden", (None,)), ("test_hift_vs_reference_golden", ()), ("test_meanflow_vs_reference_golden", ()),
                                        ("test_flow_batched_ragged_vs_oracle", ()), ("test_hift_batched_ragged_vs_oracle", ()),
-                                       ("test_flow_and_vocoder_with_one_voice_per_utterance", ()), ("test_t3_turbo_batched_vs_oracle", ())])
+                                       ("test_flow_and_vocoder_with_one_voice_per_utterance", ())])
 def test_model_level_golden_bodies_on_the_emulator(emu, name, args):
     """tests/test_models_gpu.py bodies against the REFERENCE's golden vectors, executed by the emulator: the whole S3Gen flow (conformer encoder
     + 10-step CFG CFM on the plane-format estimator, 56 transformer blocks) reproduces the reference's mel at the fp32 tolerances on the CPU

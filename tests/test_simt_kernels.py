@@ -352,7 +352,7 @@ def test_t3_decode_step_c_entry_point_and_tile_variants(emu, tiny_llama, qtc, od
     assert torch.equal(a["positions"], torch.tensor([21, 32, 21, 32], dtype=torch.int32))
 
 
-@pytest.mark.parametrize("tune,c_step", [(dict(), True), (dict(qkv_tc=12, od_tc=4, d_ks2=1), True), (dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), False)])
+@pytest.mark.parametrize("tune,c_step", [(dict(qkv_tc=12, od_tc=4, d_ks2=1), True), (dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), False)])  # the default tune: the e2e test below
 def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_step, monkeypatch):
     """chatterbox_amd/t3.py's own decode-step code (T3Engine._prepare_tune / _tiles / _image / _forward_decode_v2 / _decode_step_c) driven on
     the emulator: an engine object assembled around the tiny model, one token step, against the hand-written launch sequence above."""
@@ -455,3 +455,28 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc == 0, out
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5", "CBX_EMU_DROP_BARRIER": "0"}, "test_gemv_decode or test_linear")  # the K-slice reduction through LDS
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
+
+
+def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, monkeypatch):
+    """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
+    encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
+    through the stage-level C entry point (the product default), the device sampler with the reference's processor order -- two utterances of
+    different text length and voice: sampled ids identical to the CPU oracle's (oracle/ref_torch.py::t3_inference, pinned against the
+    reference's T3.inference by tests/golden)."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3 import T3Engine
+    from oracle import ref_torch as O
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: type("S", (), {"cuda_stream": None})())
+    samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+    L, steps = 1, 3
+    sd = synth.t3_state_dict(L, 0)
+    eng = T3Engine(sd, CPU)
+    assert eng.c_step and eng.decode_mode == "v2"
+    texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
+    conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
+    u = synth.rand((2, steps), seed=11)
+    toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    assert "cstep" in next(iter(eng._state.values())), "the decode steps went through cbx_t3_decode_step"
+    for b in range(2):
+        ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
+        assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"

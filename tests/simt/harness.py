@@ -65,6 +65,22 @@ def emulated():
         _lib.check(emu.cbx_set_decode_attn_workspace(da_ws[0].data_ptr(), da_ws[1].data_ptr(), 128), "cbx_set_decode_attn_workspace")
         ops._DA_WS[0] = da_ws
 
+    # the engines' own device plumbing: no hipGraph capture, no streams, no device switch on the emulator
+    import functools
+
+    from chatterbox_amd import t3 as _t3, t3_turbo as _t3t
+    eng_saved = (_t3.T3Engine.generate, _t3t.T3TurboEngine.generate, torch.cuda.current_stream, torch.cuda.set_device)
+
+    def no_graph(fn):
+        @functools.wraps(fn)
+        def wrapper(self, *a, **k):
+            k["use_graph"] = False
+            return fn(self, *a, **k)
+        return wrapper
+
+    _t3.T3Engine.generate, _t3t.T3TurboEngine.generate = no_graph(eng_saved[0]), no_graph(eng_saved[1])
+    torch.cuda.current_stream = lambda *a, **k: type("HostStream", (), {"cuda_stream": None, "synchronize": lambda self: None})()
+    torch.cuda.set_device = lambda *a, **k: None
     saved_da = dict(ops._DA_WS)
     saved = dict(erf=ops.enable_range_flag, eda=ops.ensure_decode_attn_workspace, lib_l=_lib.lib, lib_o=ops.lib, stream=ops._stream, f32=ops._f32, pinit=ops.Planes.__init__, sync=torch.cuda.synchronize,
                  flags=dict(ops._RANGE_FLAGS), dev_index=ops._dev_index, cur_dev=torch.cuda.current_device)
@@ -90,3 +106,4 @@ def emulated():
         ops._RANGE_FLAGS.update(saved["flags"])
         ops._DA_WS.clear()
         ops._DA_WS.update(saved_da)
+        _t3.T3Engine.generate, _t3t.T3TurboEngine.generate, torch.cuda.current_stream, torch.cuda.set_device = eng_saved

@@ -410,7 +410,8 @@ def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
 @pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="model-level emulator runs take minutes to half an hour each: CBX_EMU_SLOW=1")
 @pytest.mark.parametrize("name,args", [("test_flow_vs_reference_golden", (None,)), ("test_hift_vs_reference_golden", ()), ("test_meanflow_vs_reference_golden", ()),
                                        ("test_flow_batched_ragged_vs_oracle", ()), ("test_hift_batched_ragged_vs_oracle", ()),
-                                       ("test_flow_and_vocoder_with_one_voice_per_utterance", ())])
+                                       ("test_flow_and_vocoder_with_one_voice_per_utterance", ()), ("test_minimum_sizes_vs_oracle", ()),
+                                       ("test_end_to_end_batch_vs_oracle", ())])
 def test_model_level_golden_bodies_on_the_emulator(emu, name, args):
     """tests/test_models_gpu.py bodies against the REFERENCE's golden vectors, executed by the emulator: the whole S3Gen flow (conformer encoder
     + 10-step CFG CFM on the plane-format estimator, 56 transformer blocks) reproduces the reference's mel at the fp32 tolerances on the CPU
@@ -457,7 +458,7 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
 
 
-def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, monkeypatch):
+def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
     through the stage-level C entry point (the product default), the device sampler with the reference's processor order -- two utterances of
@@ -466,7 +467,6 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, monkeyp
     from chatterbox_amd import synth
     from chatterbox_amd.t3 import T3Engine
     from oracle import ref_torch as O
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: type("S", (), {"cuda_stream": None})())
     samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
     L, steps = 1, 3
     sd = synth.t3_state_dict(L, 0)
@@ -480,3 +480,23 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, monkeyp
     for b in range(2):
         ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"
+
+
+@pytest.mark.parametrize("name", ["test_s3_log_mel_vs_reference", "test_mel24k_vs_reference"])
+def test_frontend_bodies_against_the_references_golden_vectors_on_the_emulator(emu, name):
+    """tests/test_frontend_gpu.py bodies on the emulator: the S3 tokenizer's log-mel and the 24 kHz prompt mel (framed DFT as an exact fp32
+    GEMM over the waveform, mel filterbank, log maps) against tests/golden/frontend.npz -- outputs of the UNMODIFIED reference."""
+    import numpy as np
+    import test_frontend_gpu
+    getattr(test_frontend_gpu, name)(CPU, np.load(os.path.join(test_frontend_gpu.GOLD, "frontend.npz")))
+
+
+@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="minutes each: CBX_EMU_SLOW=1")
+@pytest.mark.parametrize("name", ["test_voice_encoder_vs_reference", "test_campplus_vs_reference", "test_s3tokenizer_quantize_vs_oracle"])
+def test_frontend_model_bodies_on_the_emulator(emu, name):
+    """The voice-encoder LSTM and CAMPPlus against the reference's golden vectors, the S3 tokenizer against the oracle (28 s / 170 s / 44 s under
+    the hazard modes; all pass)."""
+    import numpy as np
+    import test_frontend_gpu
+    fn = getattr(test_frontend_gpu, name)
+    fn(CPU) if name.endswith("oracle") else fn(CPU, np.load(os.path.join(test_frontend_gpu.GOLD, "frontend.npz")))

@@ -43,7 +43,7 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -457,8 +457,12 @@ class T3Engine:
                    att=torch.empty(rows * S, self.D, device=dev), g=torch.empty(rows * S, self.F, device=dev))
         pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(rows)
         crow = torch.arange(rows, dtype=torch.int32, device=dev).repeat_interleave(S)
-        for i, lw in enumerate(self.layers):
-            self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
+        # prefill_prec (tune / CBX_T3_TUNE="prefill_prec=6", opt-in, untimed): the prefill's plain projections (q/k/v, o, down) and its attention
+        # on the bf16x6 split kernels (24 significand bits, fp32 range, accumulation error below the exact MFMA's own: DESIGN.md section 1)
+        # instead of the exact fp32 MFMA; gate|up (SwiGLU epilogue) and every decode step stay exact
+        with ops.gemm_precision(self.tune.get("prefill_prec") or 0):
+            for i, lw in enumerate(self.layers):
+                self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
         last = torch.tensor([r * S + s0[r % B] - 1 for r in range(rows)], device=dev)
         hl = xf.index_select(0, last).contiguous()
         ops.layernorm(hl, self.norm, None, st["dws"]["h"], 1e-5, rms=True)

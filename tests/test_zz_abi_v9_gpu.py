@@ -183,3 +183,22 @@ def test_gemv_deep_batches_equal_plain(dev, M, N, K, ks, tile, res):
     assert torch.equal(outs[0], outs[1])
     got = _unpack_operand(outs[1], M, N) - r[:, :N] if res else (outs[1].sum(0) if ks > 1 else outs[1])
     _close(got, F.linear(x, w), 6e-5 * max(1.0, math.sqrt(K / 256)), "deep-batch gemv")
+
+
+def test_t3_prefill_on_the_bf16x6_kernels_samples_the_reference_tokens(dev, monkeypatch):
+    """CBX_T3_TUNE="prefill_prec=6" (opt-in): the prefill's q/k/v, o and down projections and its attention on the bf16x6 split kernels
+    (24 significand bits, fp32 exponent range) instead of the exact fp32 MFMA; decode stays exact.  Golden tokens of the reference (t3_l2,
+    64 steps) and teacher-forced logits within the usual 1e-3."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3 import T3Engine
+    g = np.load(os.path.join(GOLD, "t3_l2.npz"))
+    steps, n_text = int(g["steps"]), int(g["n_text"])
+    monkeypatch.setenv("CBX_T3_TUNE", "prefill_prec=6")
+    eng = T3Engine(synth.t3_state_dict(2, 0), dev)
+    assert eng.tune["prefill_prec"] == 6
+    u = torch.from_numpy(g["uniforms"])[None]
+    toks, logits = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, debug_logits=True, **SAMP)
+    idx = torch.from_numpy(g["logit_idx"]).long()
+    err = (logits.cpu()[:, :, idx] - torch.from_numpy(g["logits_sub"])).abs().max().item()
+    assert err <= 1e-3, f"teacher-forced logits max-abs {err:.3e}"
+    assert toks[0].tolist() == g["tokens"].tolist()

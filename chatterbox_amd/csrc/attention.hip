@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 // stay unconditional -- clamped addresses -- so that hipcc waits with a COUNTED vmcnt and the younger set stays in flight).  The plain form
 // issues a step's loads only after the previous step's arithmetic, i.e. it pays one memory round trip per step (64 positions with U = 4:
 // the measured slope of 1.6 us per 64 positions, profiles/r02_decode_micro.log, is that round trip).  Same arithmetic, same order, same results.
-template <int DA_U, bool SPLIT, bool PIPE = false>
+// NT (cbx_set_decode_attn_pipeline(2 | 3), same provenance): the K / V rows are read with the non-temporal policy -- a (row, head)'s cache is
+// streamed once per token step by one CU, the case for which MI355X_MICROARCH.md measures nt loads 5-10 % ahead on a decode layer.
+template <int DA_U, bool SPLIT, bool PIPE = false, bool NT = false>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
@@ -298,8 +300,13 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         for (int u = 0; u < DA_U; ++u) {
             const int p = p0 + 16 * u;
             const int pc = p < pos ? p : 0;  // clamped: loads are unconditional (never the new position, never past the end)
-            kd[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
-            vd[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
+            if constexpr (NT) {
+                kd[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4));
+                vd[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4));
+            } else {
+                kd[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
+                vd[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
+            }
         }
     };
     auto load_chunk = [&](int p0) { load_rows(kv, vv, p0); };
@@ -536,8 +543,8 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     return 0;
 }
 static int g_da_pipe = getenv("CBX_DA_PIPE") ? atoi(getenv("CBX_DA_PIPE")) : 0;
-extern "C" int cbx_set_decode_attn_pipeline(int on) {
-    g_da_pipe = on != 0;
+extern "C" int cbx_set_decode_attn_pipeline(int on) {  // bit 0: pipelined K / V stream; bit 1: non-temporal K / V loads (4 rows per step)
+    g_da_pipe = on & 3;
     return 0;
 }
 constexpr int DA_MAX_SPLIT = 8;
@@ -573,21 +580,24 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     // at contexts of 200-700 by 1-4 %; the split engages on contexts >= cbx_set_decode_attn_split_min (512): a 1000-token Turbo generation
     // (contexts to ~1450) decodes at 1.03 ms / token with it, 1.20 without (profiles/r03_turbo_long_context.log).
     const int da_u = g_da_u > 0 ? g_da_u : 4;
-#define CBX_DA_LAUNCH(U, P)                                                                                                                \
+#define CBX_DA_LAUNCH(U, P, N)                                                                                                             \
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
         else                                                                                                                               \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
     } while (0)
-    if (g_da_pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
-        if (da_u == 8) CBX_DA_LAUNCH(8, true);
-        else CBX_DA_LAUNCH(4, true);
-    } else if (da_u == 8) CBX_DA_LAUNCH(8, false);
-    else if (da_u == 16) CBX_DA_LAUNCH(16, false);
-    else CBX_DA_LAUNCH(4, false);
+    if (g_da_pipe & 2) {  // non-temporal K / V loads (4 rows per lane group and step), plain or pipelined
+        if (g_da_pipe & 1) CBX_DA_LAUNCH(4, true, true);
+        else CBX_DA_LAUNCH(4, false, true);
+    } else if (g_da_pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
+        if (da_u == 8) CBX_DA_LAUNCH(8, true, false);
+        else CBX_DA_LAUNCH(4, true, false);
+    } else if (da_u == 8) CBX_DA_LAUNCH(8, false, false);
+    else if (da_u == 16) CBX_DA_LAUNCH(16, false, false);
+    else CBX_DA_LAUNCH(4, false, false);
 #undef CBX_DA_LAUNCH
     return cbx_check_launch("decode_attn_rope");
 }

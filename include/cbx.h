@@ -267,8 +267,9 @@ int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float
 int cbx_set_split_tile(int t);
 /* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
 int cbx_set_decode_attn_unroll(int u);
-/* ABI v9: 1 = software-pipelined K / V stream (the rows of the next step are requested before the current step is multiplied; two register
- * sets; 4 or 8 rows per lane group and step).  Same results bit for bit.  Default 0 (env CBX_DA_PIPE). */
+/* ABI v9: bit 0 = software-pipelined K / V stream (the rows of the next step are requested before the current step is multiplied; two register
+ * sets; 4 or 8 rows per lane group and step); bit 1 = non-temporal K / V loads (4 rows per step).  Same results bit for bit.  Default 0
+ * (env CBX_DA_PIPE = 0 .. 3). */
 int cbx_set_decode_attn_pipeline(int on);
 /* Workspace of cbx_decode_attn_rope_f32's split-context form, used when rows * n_heads < 128 (Turbo / Nano at small batch): ws = 66 * 8 floats
  * per (row, head), zeroed_counters = one int per (row, head), initialised to 0 once; registered for the calling thread's current device. */

@@ -23,7 +23,7 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             ("v2", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16, o_nw2=16)),
             # software-pipelined decode attention (cbx_set_decode_attn_pipeline): alone, with 8 rows per step, and with the tile variants
             ("v2", dict(od_tc=4, d_ks2=1, d_nw2=8, deep=1)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, deep=1)),
-            ("v2", dict(da_pipe=1)), ("v2", dict(da_pipe=1, da_u=8)), ("v2", dict(prefill_prec=6)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16))]
+            ("v2", dict(da_pipe=1)), ("v2", dict(da_pipe=1, da_u=8)), ("v2", dict(prefill_prec=6)), ("v2", dict(da_pipe=2)), ("v2", dict(da_pipe=3)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:

@@ -90,13 +90,14 @@ def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
                 pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
                 qkv = _r((rows, 3 * H * 64), 100 + n)
                 res = []
-                for pipe in (0, 1):
+                for pipe in (0, 1) + ((2, 3) if u == 4 else ()):  # 2 / 3: non-temporal K / V loads, plain / pipelined
                     ops.lib.cbx_set_decode_attn_pipeline(pipe)
                     kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.zeros(rows, H * 64, device=dev)
                     ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
                     res.append((out.cpu(), kc.cpu(), vc.cpu()))
-                for a, b, what in zip(res[0], res[1], ("output", "k cache", "v cache")):
-                    assert torch.equal(a, b), f"pipelined decode attention differs in the {what} (U = {u}, context {n + 1})"
+                for other in res[1:]:
+                    for a, b, what in zip(res[0], other, ("output", "k cache", "v cache")):
+                        assert torch.equal(a, b), f"pipelined / non-temporal decode attention differs in the {what} (U = {u}, context {n + 1})"
                 if n in (0, 63, 64, 65, 300):  # and the result itself against torch
                     q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
                     if rope:

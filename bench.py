@@ -65,6 +65,9 @@ def parse():
                     help="after the timed region also run configs[3]: 256 utterances strong-sharded over the ranks (32 per GPU at 8 GPUs); "
                          "default on when WORLD_SIZE == 8")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the built-in decode-step geometry instead of measuring the candidates on this GPU first (T3Engine.autotune: child "
+                         "process, bit-identical candidates only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-CPU parity block (needs the CPU baseline utterance)")
     ap.add_argument("--selftest-rendezvous", action="store_true",
                     help="launcher / collective self-test WITHOUT kernels (gloo, host tensors): the N ranks rendezvous, C1 (broadcast of the "
@@ -453,6 +456,14 @@ def main():
     s3_prec = eng.flow.precision
     build_s = time.perf_counter() - t_build
     log(f"model built in {build_s:.1f}s")
+    # decode-step geometry picked by measurement on THIS GPU before anything is timed (chatterbox_amd/autotune.py): candidates run in a child
+    # process; only geometries whose logits are bit-identical to the built-in one can be adopted; the report goes into the JSON line
+    tune_rep = None
+    if not turbo and not args.no_autotune and 2 * args.batch <= 16:
+        t_tune = time.perf_counter()
+        tune_rep = eng.t3.autotune(B=args.batch, ctx=34 + args.text_tokens + 2 + args.tokens // 2, log=log)
+        tune_rep["autotune_s"] = round(time.perf_counter() - t_tune, 1)
+        log(f"decode autotune: {tune_rep.get('best')} in {tune_rep['autotune_s']} s")
 
     # C1: rank 0 "analysed the voice prompt"; everybody else receives the packed Conditionals over RCCL
     t3c, gen = (synth.t3_cond(prompt_len=375 if turbo else 150), synth.s3gen_ref()) if rank == 0 else (None, None)
@@ -646,6 +657,14 @@ def main():
             "decode_step": dstep,
             "roofline_secondary": list(roofs.values()),
         }
+        if tune_rep is not None:
+            out["config"]["t3_decode_autotune"] = {
+                "adopted": tune_rep.get("best") or {}, "error": tune_rep.get("error"), "seconds": tune_rep.get("autotune_s"),
+                "ms_per_token_builtin": tune_rep.get("baseline_ms_per_token"), "ms_per_token_adopted": tune_rep.get("ms_per_token"),
+                "rule": "adopt the fastest candidate whose logits are bit-identical to the built-in geometry's (>= 1 % faster, confirmed back to back); "
+                        "'reorders' = another fp32 summation order: timed, not adopted",
+                "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "error", "confirm") if k in r}
+                               for r in tune_rep.get("candidates", [])]}
         if alt:
             labels = {"s3gen_precision_3": "s3gen_bf16x3_fast_mode (narrower than the reference's fp32; bf16-mode tolerances)",
                       "s3gen_precision_1": "s3gen_exact_fp32_mfma", "s3gen_precision_6": "s3gen_bf16x6 (fp32-level, fp32 exponent range)",

@@ -1,0 +1,167 @@
+"""Decode-step autotuner of the Llama T3 engine: picks the launch geometry of the token step on the GPU it runs on.
+
+The token step of `T3.inference` (reference models/t3/t3.py:338-386) is 5 launches per layer whose geometry is a free choice that does not
+change the arithmetic: output columns per workgroup of the q/k/v and o / down GEMVs (`T3Engine.tune`: qkv_tc, od_tc), and the K / V stream
+of the decode attention (`cbx_set_decode_attn_pipeline`, `cbx_set_decode_attn_unroll`).  Which one is fastest depends on the box (the pool's
+MI355X boxes differ by 3-10 %), the batch (rows = 2 B) and the context, so it is measured, the way MIOpen's find step picks a convolution:
+
+    report = T3Engine.autotune(B=8)          # times every candidate on a synthetic decode state in a CHILD process, adopts the winner
+
+Rules:
+  * a candidate is ADOPTED only if its logits after one token step are bit-identical to the current geometry's (same products, same
+    summation order) and it is faster by `min_gain`; candidates that sum in another (equally valid fp32) order -- the down projection without
+    split-K partial images, another wave count -- are timed and reported (`"reorders": true`) but not adopted unless `allow_reorder=True`;
+  * the measurement runs in a child process on seeded synthetic weights of the engine's shape (time does not depend on weight values): a
+    candidate that faults or hangs takes the child down, not the serving process, and the engine keeps its current geometry;
+  * timing is HIP events around hipGraph replays of the whole token step (every GEMV, the attention, the head and the sampler), i.e. exactly
+    what `generate()` replays per token.
+
+`python -m chatterbox_amd.autotune --layers 30 --batch 8 --ctx 224` prints the report as one JSON line (the child's protocol).
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+# geometry candidates of the GEMVs (keys of T3Engine.tune) -- {} is the geometry the engine currently runs
+TILE_VARIANTS = (dict(), dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4),
+                 dict(od_tc=4, d_ks2=1, d_nw2=8), dict(od_tc=4, d_ks2=1, d_nw2=16), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16))
+# process-wide library knobs of the decode attention (cbx_set_decode_attn_pipeline / _unroll), tried on top of the best tile geometry
+ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe=1, da_u=8), dict(da_u=8))
+LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0)  # library defaults
+
+
+def env_knobs():
+    """The library knobs as the environment sets them when libcbx_hip.so loads (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP)."""
+    e = os.environ.get
+    return dict(da_pipe=int(e("CBX_DA_PIPE") or 0) & 3, da_u=int(e("CBX_DA_U") or 0) or 4, deep=int(e("CBX_GEMV_DEEP") or 0))
+
+
+def split_variant(v):
+    """(tune keys, library knobs) of a candidate."""
+    return {k: x for k, x in v.items() if k not in LIB_KNOBS}, {k: x for k, x in v.items() if k in LIB_KNOBS}
+
+
+def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, use_graph=True, tiles=TILE_VARIANTS, attn=ATTN_VARIANTS,
+                log=None):
+    """Time every candidate on `eng` (in this process) and return the report; `eng` is left on the geometry it came with."""
+    import torch
+    base_tune, base_knobs = dict(eng.tune), dict(getattr(eng, "lib_knobs", None) or env_knobs())
+    rows = []
+
+    def run(v):
+        eng.apply_variant(dict(base_tune, **split_variant(v)[0]), dict(base_knobs, **split_variant(v)[1]))
+        ms, logits = eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
+        return ms, logits
+
+    ms0, ref = run({})
+    scale = max(1.0, float(ref.abs().max()))
+    rows.append(dict(variant={}, ms_per_token=round(ms0, 5), identical=True, reorders=False, max_abs_diff=0.0))
+    if log:
+        log(f"autotune: current geometry {ms0:.4f} ms / token")
+    best, best_ms = {}, ms0
+
+    def consider(v):
+        nonlocal best, best_ms
+        try:
+            ms, lg = run(v)
+        except Exception as e:  # a candidate this build / shape does not support: reported, never adopted
+            rows.append(dict(variant=v, error=f"{type(e).__name__}: {e}"[:200]))
+            return
+        same = bool(torch.equal(lg, ref))
+        diff = float((lg - ref).abs().max())
+        ok_num = same or diff <= 2e-4 * scale  # another fp32 summation order of the same products
+        rows.append(dict(variant=v, ms_per_token=round(ms, 5), identical=same, reorders=not same, max_abs_diff=diff, valid=ok_num))
+        if log:
+            log(f"autotune: {v} {ms:.4f} ms / token, identical={same} (max |d logits| {diff:.2e})")
+        if ok_num and (same or allow_reorder) and ms < best_ms * (1.0 - min_gain):
+            best, best_ms = v, ms
+
+    for v in tiles[1:]:
+        consider(v)
+    tile_best = dict(best)
+    for a in attn:
+        consider(dict(tile_best, **a))
+    if best:  # confirm against the current geometry back to back (two more rounds each): the pool's boxes drift by a few per cent over seconds
+        a0 = min(run({})[0] for _ in range(2))
+        a1 = min(run(best)[0] for _ in range(2))
+        rows.append(dict(confirm=dict(current=round(a0, 5), best=round(a1, 5))))
+        if not a1 < a0 * (1.0 - min_gain):
+            best, best_ms = {}, min(a0, ms0)
+        else:
+            best_ms = a1
+    eng.apply_variant(base_tune, base_knobs)
+    return dict(best=best, ms_per_token=round(best_ms, 5), baseline_ms_per_token=round(ms0, 5), B=B, ctx=ctx, steps=steps, layers=eng.L,
+                graph=bool(use_graph), allow_reorder=bool(allow_reorder), candidates=rows)
+
+
+def tune_in_child(layers, B, ctx, steps, reps, min_gain, allow_reorder, device_index, base_tune, base_knobs, timeout=180.0, log=None):
+    """Run `python -m chatterbox_amd.autotune` and parse its report; any failure (non-zero exit, timeout, no JSON) returns {"error": ...}."""
+    cmd = [sys.executable, "-m", "chatterbox_amd.autotune", "--layers", str(layers), "--batch", str(B), "--ctx", str(ctx), "--steps", str(steps),
+           "--reps", str(reps), "--min-gain", str(min_gain), "--device", str(device_index), "--tune", json.dumps(base_tune), "--knobs",
+           json.dumps(base_knobs)] + (["--allow-reorder"] if allow_reorder else [])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CBX_T3_TUNE", "CBX_DA_PIPE", "CBX_DA_U", "CBX_GEMV_DEEP"):
+        env.pop(k, None)  # the child is a plain single-device process whose starting geometry arrives on the command line
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root)
+    except OSError as e:
+        return dict(error=f"spawn failed: {e}")
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return dict(error=f"timeout after {timeout:.0f} s", wall_s=round(time.perf_counter() - t0, 1))
+    rep = None
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                rep = json.loads(line)
+                break
+            except ValueError:
+                continue
+    if p.returncode != 0 or rep is None:
+        return dict(error=f"child exit {p.returncode}", stderr_tail=err[-400:], wall_s=round(time.perf_counter() - t0, 1))
+    rep["wall_s"] = round(time.perf_counter() - t0, 1)
+    if log:
+        log(f"autotune child: {rep['wall_s']} s, best {rep['best']}")
+    return rep
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--layers", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ctx", type=int, default=224)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--min-gain", type=float, default=0.01)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--allow-reorder", action="store_true")
+    ap.add_argument("--tune", default="{}", help="JSON: T3Engine.tune overrides of the starting geometry")
+    ap.add_argument("--knobs", default="{}", help="JSON: library knobs (da_pipe, da_u, deep) of the starting geometry")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args(argv)
+    import torch
+
+    from . import synth
+    from .t3 import T3Engine
+    assert torch.cuda.is_available(), "the autotuner measures on the GPU"
+    torch.cuda.set_device(a.device)
+    eng = T3Engine(synth.t3_state_dict(a.layers, 0), torch.device("cuda", a.device), n_layers=a.layers)
+    eng.apply_variant(dict(eng.tune, **json.loads(a.tune)), dict(LIB_KNOBS, **json.loads(a.knobs)))
+    log = (lambda m: print(m, file=sys.stderr, flush=True)) if a.verbose else None
+    rep = tune_decode(eng, B=a.batch, ctx=a.ctx, steps=a.steps, reps=a.reps, min_gain=a.min_gain, allow_reorder=a.allow_reorder, log=log)
+    print(json.dumps(rep), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,107 @@ class T3Engine:
         for lw in self.layers:
             self._image(lw, "wqkv", qtc), self._image(lw, "wo", odtc), self._image(lw, "wd", odtc)
 
+    # ------------------------------------------------------------------ decode-step geometry: measured, not guessed (autotune.py)
+    def apply_variant(self, tune, knobs=None):
+        """Switch the decode geometry: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep) are the process-wide library knobs of the
+        decode attention / GEMV load batches.  Captured decode graphs and C step descriptors bake the geometry in: they are dropped."""
+        from .autotune import LIB_KNOBS
+        self.tune = dict(tune)
+        k = dict(LIB_KNOBS, **(knobs or {}))
+        ops.lib.cbx_set_decode_attn_pipeline(int(k["da_pipe"]))
+        ops.lib.cbx_set_decode_attn_unroll(int(k["da_u"]))
+        ops.lib.cbx_set_gemv_deep_batches(int(k["deep"]))
+        self.lib_knobs = k
+        for st in self._state.values():
+            st["graph"] = None
+            st.pop("cstep", None)
+
+    @ops.on_device
+    @torch.inference_mode()
+    def measure_decode(self, B=8, ctx=224, steps=24, reps=2, use_graph=True, slot=7):
+        """(ms per token step, logits after ONE step) of the current geometry on a seeded synthetic decode state: 2 B rows that hold `ctx`
+        cached positions each.  The step is the one generate() replays (embedding .. sampler, one hipGraph); time = HIP events around
+        `steps` replays, best of `reps`.  The logits are a pure function of the seed, so two geometries can be compared bit for bit."""
+        import time
+        rows = 2 * B
+        total = 4 + reps * steps
+        max_ctx = (ctx + total + 1 + 63) // 64 * 64
+        assert max_ctx <= self.max_pos
+        st = self._get_state(B, max_ctx, total + 1, slot)
+        self._prepare_tune()
+        st["graph"] = None
+        st.pop("cstep", None)
+        gen = torch.Generator(device=self.dev).manual_seed(20240229)
+        for k in ("kc", "vc"):
+            st[k].normal_(0.0, 0.5, generator=gen)
+        st["uniforms"].uniform_(generator=gen)
+        for k in ("seen", "step", "done", "n_generated", "out_tokens"):
+            st[k].zero_()
+        st["samp_dev"].copy_(torch.tensor([0.5, 0.8, 0.05, 1.0, 1.2, 0.0, float(STOP_SPEECH), 6561.0]).repeat(B, 1))
+        ids = torch.tensor([(911 * b + 17) % 6561 for b in range(B)] * 2, dtype=torch.int64)
+        st["next_ids"].copy_(ids)
+        st["next_pos_ids"].fill_(1)
+        st["positions"].fill_(ctx)
+        st["ctx_lens"].fill_(ctx + 1)
+        self._decode_step(st)
+        logits = st["logits"].clone()
+        if steps <= 0:  # numerics only
+            return 0.0, logits
+        cuda = self.dev.type == "cuda"
+        if cuda and use_graph:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step(st)
+            step = g.replay
+        else:
+            step = lambda: self._decode_step(st)
+        step()
+        best = float("inf")
+        for _ in range(reps):
+            if cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+            else:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                ms = 1e3 * (time.perf_counter() - t0)
+            best = min(best, ms / steps)
+        st["graph"] = None
+        st.pop("cstep", None)
+        return best, logits
+
+    def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None):
+        """Measure the decode-step geometries (autotune.py) and adopt the fastest one whose logits are bit-identical to the current
+        geometry's.  in_child: the candidates run in a child process on synthetic weights of this shape, so a faulting candidate cannot take
+        the serving process down; its failure leaves the geometry unchanged.  Returns the report (also kept as self.autotune_report)."""
+        from . import autotune as at
+        knobs = dict(getattr(self, "lib_knobs", None) or at.env_knobs())
+        if self.decode_mode != "v2" or 2 * B > 16:
+            rep = dict(best={}, skipped="the tile / pipeline variants serve the packed <= 16-row decode path")
+        elif in_child:
+            base = {k: v for k, v in self.tune.items() if v != self._TUNE.get(k)}
+            rep = at.tune_in_child(self.L, B, ctx, steps, reps, min_gain, allow_reorder, self.dev.index or 0, base, knobs, timeout, log)
+        else:
+            rep = at.tune_decode(self, B, ctx, steps, reps, min_gain, allow_reorder, use_graph=self.dev.type == "cuda", log=log,
+                                 tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn)
+        best = rep.get("best") or {}
+        if best:
+            t, k = at.split_variant(best)
+            self.apply_variant(dict(self.tune, **t), dict(knobs, **k))
+            with torch.inference_mode():
+                self._prepare_tune()
+        for key in [k for k in self._state if k[3] == 7]:  # the measurement's own state (KV cache of the synthetic context)
+            del self._state[key]
+        self.autotune_report = rep
+        return rep
+
     # ------------------------------------------------------------------ conditioning (t3.py:92-100, cond_enc.py:64-97)
     def _perceiver_block(self, x1, x2):
         """AttentionBlock2.forward (perceiver.py:156-170): x1 (n1,1024) queries attend to x2 (n2,1024)."""

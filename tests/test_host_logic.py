@@ -398,3 +398,26 @@ def test_stream_token_schedule_constant_and_growing_chunks():
     for g in (1.0, 1.5, 2.0, 3.0):
         s = sched(1000, 25, 50, 3, g)
         assert s[0] == 28 and s[-1] == 1000 and all(b > a for a, b in zip(s, s[1:]))
+
+
+def test_decode_autotuner_child_failure_keeps_the_geometry():
+    """chatterbox_amd/autotune.py: the candidates are measured in a child process; a child that dies (here: there is no GPU, its first assertion
+    fails) must come back as an error report -- never as an exception or a changed geometry in the serving process.  Also: the candidate
+    tables only hold knobs the engine / library know, and the split into tune keys / library knobs is total."""
+    import torch
+    from chatterbox_amd import autotune as at
+    from chatterbox_amd.t3 import T3Engine
+    for v in at.TILE_VARIANTS + at.ATTN_VARIANTS:
+        t, k = at.split_variant(v)
+        assert set(t) <= set(T3Engine._TUNE) and set(k) <= set(at.LIB_KNOBS) and {**t, **k} == v
+    assert at.TILE_VARIANTS[0] == {} and at.env_knobs() == at.LIB_KNOBS or os.environ.get("CBX_DA_PIPE") or os.environ.get("CBX_DA_U")
+    if torch.cuda.is_available():
+        pytest.skip("the failure path is what this test is about: it needs a box without a GPU")
+    rep = at.tune_in_child(1, 1, 8, 1, 1, 0.01, False, 0, {}, dict(at.LIB_KNOBS), timeout=300.0)
+    assert "error" in rep and "best" not in rep, rep
+    eng = T3Engine.__new__(T3Engine)  # the adoption logic of T3Engine.autotune without a model: an error report adopts nothing
+    eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE)
+    r2 = T3Engine.autotune(eng, B=1, ctx=8, steps=1, reps=1, timeout=300.0)
+    assert "error" in r2 and eng.tune == T3Engine._TUNE and not hasattr(eng, "lib_knobs") and eng.autotune_report is r2
+    r3 = T3Engine.autotune(eng, B=16)  # 32 rows: not the packed <= 16-row path -- nothing to tune, nothing spawned
+    assert r3.get("skipped") and eng.tune == T3Engine._TUNE

@@ -203,3 +203,30 @@ def test_t3_prefill_on_the_bf16x6_kernels_samples_the_reference_tokens(dev, monk
     err = (logits.cpu()[:, :, idx] - torch.from_numpy(g["logits_sub"])).abs().max().item()
     assert err <= 1e-3, f"teacher-forced logits max-abs {err:.3e}"
     assert toks[0].tolist() == g["tokens"].tolist()
+
+
+def test_decode_autotuner_adopts_only_bit_identical_geometries(dev):
+    """T3Engine.autotune (chatterbox_amd/autotune.py): the candidates are timed in a child process on a 2-layer model of the real width; whatever
+    is adopted samples the reference's golden tokens (t3_l2: 64 steps) through the hipGraph path, and every candidate row carries either a time
+    and an identity verdict or an error -- a reordering candidate is never the adopted one."""
+    from chatterbox_amd import autotune as at, ops, synth
+    from chatterbox_amd.t3 import T3Engine
+    g = np.load(os.path.join(GOLD, "t3_l2.npz"))
+    steps, n_text = int(g["steps"]), int(g["n_text"])
+    eng = T3Engine(synth.t3_state_dict(2, 0), dev)
+    try:
+        rep = eng.autotune(B=8, ctx=128, steps=16, reps=2, timeout=240.0)
+        assert "error" not in rep, rep
+        rows = [r for r in rep["candidates"] if "variant" in r]
+        assert len(rows) == len(at.TILE_VARIANTS) + len(at.ATTN_VARIANTS) and all(("ms_per_token" in r) != ("error" in r) for r in rows), rows
+        narrow = [r for r in rows if r["variant"] in (dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4))]
+        assert all(r.get("identical") for r in narrow), narrow  # same per-column arithmetic as the 16- / 8-column tiles
+        best = rep["best"]
+        if best:
+            assert next(r for r in rows if r["variant"] == best)["identical"]
+            assert all(eng.tune[k] == v for k, v in at.split_variant(best)[0].items())
+        u = torch.from_numpy(g["uniforms"])[None]
+        toks = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, **SAMP)
+        assert toks[0].tolist() == g["tokens"].tolist(), f"adopted geometry {best}"
+    finally:
+        eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the attention knobs are process-wide

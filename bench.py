@@ -456,15 +456,7 @@ def main():
     s3_prec = eng.flow.precision
     build_s = time.perf_counter() - t_build
     log(f"model built in {build_s:.1f}s")
-    # decode-step geometry picked by measurement on THIS GPU before anything is timed (chatterbox_amd/autotune.py): candidates run in a child
-    # process; only geometries whose logits are bit-identical to the built-in one can be adopted; the report goes into the JSON line
-    tune_rep = None
-    if not turbo and not args.no_autotune and 2 * args.batch <= 16:
-        t_tune = time.perf_counter()
-        tune_rep = eng.t3.autotune(B=args.batch, ctx=34 + args.text_tokens + 2 + args.tokens // 2, log=log)
-        tune_rep["autotune_s"] = round(time.perf_counter() - t_tune, 1)
-        log(f"decode autotune: {tune_rep.get('best')} in {tune_rep['autotune_s']} s")
-
+    tune_rep = None  # T3 decode-step geometry picked by measurement on THIS GPU before anything is timed (below, once the workload exists)
     # C1: rank 0 "analysed the voice prompt"; everybody else receives the packed Conditionals over RCCL
     t3c, gen = (synth.t3_cond(prompt_len=375 if turbo else 150), synth.s3gen_ref()) if rank == 0 else (None, None)
     t3c, gen = cdist.broadcast_conditionals(t3c, gen, src=0, device=dev)
@@ -472,6 +464,20 @@ def main():
     B, N = args.batch, args.tokens
     texts = [(synth.turbo_text_tokens if turbo else synth.text_tokens)(args.text_tokens, seed=100 * rank + b) for b in range(B)]
     T = 2 * (gen["prompt_token"].shape[1] + N)
+
+    if not turbo and not args.no_autotune and 2 * B <= 16:
+        # chatterbox_amd/autotune.py: the candidates run in a child process (a faulting one cannot take the bench down); a geometry whose logits
+        # are bit-identical to the built-in one's is adopted as is; the report goes into the JSON line (config.t3_decode_autotune).
+        # the fastest candidate overall may sum the down projection in another (valid fp32) order: it is kept only if ALL B x N tokens of the
+        # benched workload come out as the built-in geometry samples them (whose utterance 0 the parity block checks against the CPU reference)
+        t_tune = time.perf_counter()
+        gv = torch.Generator(device=dev).manual_seed(777 + rank)
+        kwv = dict(max_new_tokens=N, uniforms=torch.rand(B, N, generator=gv, device=dev), ban_eos=True, ban_from=6561)
+        want = [t.tolist() for t in eng.t3.generate(t3c, texts, **kwv)]
+        tune_rep = eng.t3.autotune(B=B, ctx=34 + args.text_tokens + 2 + N // 2, log=log,
+                                   validate=lambda: [t.tolist() for t in eng.t3.generate(t3c, texts, **kwv)] == want)
+        tune_rep["autotune_s"] = round(time.perf_counter() - t_tune, 1)
+        log(f"decode autotune: adopted {tune_rep.get('adopted')} in {tune_rep['autotune_s']} s")
 
     def one_step(seed):
         g = torch.Generator(device=dev).manual_seed(1234 + 1000 * rank + seed)
@@ -659,10 +665,14 @@ def main():
         }
         if tune_rep is not None:
             out["config"]["t3_decode_autotune"] = {
-                "adopted": tune_rep.get("best") or {}, "error": tune_rep.get("error"), "seconds": tune_rep.get("autotune_s"),
-                "ms_per_token_builtin": tune_rep.get("baseline_ms_per_token"), "ms_per_token_adopted": tune_rep.get("ms_per_token"),
-                "rule": "adopt the fastest candidate whose logits are bit-identical to the built-in geometry's (>= 1 % faster, confirmed back to back); "
-                        "'reorders' = another fp32 summation order: timed, not adopted",
+                "adopted": tune_rep.get("adopted") or {}, "error": tune_rep.get("error"), "seconds": tune_rep.get("autotune_s"),
+                "best_bit_identical": tune_rep.get("best"), "best_overall": tune_rep.get("best_any"),
+                "best_overall_tokens_equal_builtin": tune_rep.get("best_any_validated"),
+                "ms_per_token": {"builtin": tune_rep.get("baseline_ms_per_token"), "best_bit_identical": tune_rep.get("ms_per_token"),
+                                 "best_overall": tune_rep.get("ms_per_token_any")},
+                "rule": "candidates timed in a child process (hipGraph replays of the whole token step, synthetic state, >= 1 % faster, confirmed back "
+                        f"to back); a bit-identical one is adopted as is; one that 'reorders' (another fp32 summation order) only if all {B} x {N} "
+                        "tokens of the benched batch equal the built-in geometry's",
                 "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "error", "confirm") if k in r}
                                for r in tune_rep.get("candidates", [])]}
         if alt:

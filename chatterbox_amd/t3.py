@@ -250,12 +250,17 @@ class T3Engine:
         st.pop("cstep", None)
         return best, logits
 
-    def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None):
+    def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None,
+                 validate=None):
         """Measure the decode-step geometries (autotune.py) and adopt the fastest one whose logits are bit-identical to the current
         geometry's.  in_child: the candidates run in a child process on synthetic weights of this shape, so a faulting candidate cannot take
-        the serving process down; its failure leaves the geometry unchanged.  Returns the report (also kept as self.autotune_report)."""
+        the serving process down; its failure leaves the geometry unchanged.  validate: a callable run on THIS engine after the fastest
+        candidate overall -- possibly one that sums the down projection in another fp32 order -- has been applied; it is kept only if the
+        callable returns True (e.g. "the serving workload's tokens are the ones the built-in geometry samples"), otherwise the bit-identical
+        winner is.  Returns the report (also kept as self.autotune_report)."""
         from . import autotune as at
         knobs = dict(getattr(self, "lib_knobs", None) or at.env_knobs())
+        tune0 = dict(self.tune)
         if self.decode_mode != "v2" or 2 * B > 16:
             rep = dict(best={}, skipped="the tile / pipeline variants serve the packed <= 16-row decode path")
         elif in_child:
@@ -264,12 +269,28 @@ class T3Engine:
         else:
             rep = at.tune_decode(self, B, ctx, steps, reps, min_gain, allow_reorder, use_graph=self.dev.type == "cuda", log=log,
                                  tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn)
-        best = rep.get("best") or {}
-        if best:
-            t, k = at.split_variant(best)
-            self.apply_variant(dict(self.tune, **t), dict(knobs, **k))
+
+        def adopt(v):
+            t, k = at.split_variant(v)
+            self.apply_variant(dict(tune0, **t), dict(knobs, **k))
             with torch.inference_mode():
                 self._prepare_tune()
+
+        best, best_any = rep.get("best") or {}, rep.get("best_any") or {}
+        adopted = best
+        if validate is not None and best_any and best_any != best:
+            adopt(best_any)
+            try:
+                ok = bool(validate())
+            except Exception as e:
+                ok = False
+                rep["validate_error"] = f"{type(e).__name__}: {e}"[:200]
+            rep["best_any_validated"] = ok
+            if ok:
+                adopted = best_any
+        if adopted or (validate is not None and best_any and best_any != best):
+            adopt(adopted)
+        rep["adopted"] = adopted
         for key in [k for k in self._state if k[3] == 7]:  # the measurement's own state (KV cache of the synthetic context)
             del self._state[key]
         self.autotune_report = rep

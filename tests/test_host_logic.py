@@ -421,3 +421,34 @@ def test_decode_autotuner_child_failure_keeps_the_geometry():
     assert "error" in r2 and eng.tune == T3Engine._TUNE and not hasattr(eng, "lib_knobs") and eng.autotune_report is r2
     r3 = T3Engine.autotune(eng, B=16)  # 32 rows: not the packed <= 16-row path -- nothing to tune, nothing spawned
     assert r3.get("skipped") and eng.tune == T3Engine._TUNE
+
+
+def test_decode_autotuner_adoption_rules(monkeypatch):
+    """T3Engine.autotune's adoption logic on a canned child report: without a validate callback only `best` (bit-identical) is adopted; with one,
+    `best_any` (a reordering geometry) is applied, kept if the callback accepts it, and replaced by `best` if it refuses or raises."""
+    import torch
+    from chatterbox_amd import autotune as at
+    from chatterbox_amd.t3 import T3Engine
+    best, best_any = dict(qkv_tc=12, da_pipe=1), dict(od_tc=4, d_ks2=1, d_nw2=8, da_pipe=3)
+    monkeypatch.setattr(at, "tune_in_child", lambda *a, **k: dict(best=dict(best), best_any=dict(best_any), candidates=[]))
+    applied = []
+
+    def mk():
+        eng = T3Engine.__new__(T3Engine)
+        eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE)
+        eng.apply_variant = lambda t, k=None: (applied.append((dict(t), dict(k))), setattr(eng, "tune", dict(t)), setattr(eng, "lib_knobs", dict(k)))
+        eng._prepare_tune = lambda: None
+        return eng
+
+    eng = mk()
+    rep = eng.autotune(B=8)
+    assert rep["adopted"] == best and eng.tune["qkv_tc"] == 12 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.lib_knobs["da_pipe"] == 1
+    eng = mk()
+    rep = eng.autotune(B=8, validate=lambda: eng.tune["d_ks2"] == 1 and eng.lib_knobs["da_pipe"] == 3)  # sees best_any applied
+    assert rep["best_any_validated"] is True and rep["adopted"] == best_any and eng.tune["od_tc"] == 4 and eng.tune["qkv_tc"] == 0
+    for refuse in (lambda: False, lambda: 1 // 0):
+        eng = mk()
+        rep = eng.autotune(B=8, validate=refuse)
+        assert rep["best_any_validated"] is False and rep["adopted"] == best
+        assert eng.tune["qkv_tc"] == 12 and eng.tune["od_tc"] == 0 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.lib_knobs["da_pipe"] == 1
+    assert "validate_error" in rep

@@ -505,45 +505,54 @@ def test_frontend_model_bodies_on_the_emulator(emu, name):
 def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     """chatterbox_amd/autotune.py driven on the emulator (in-process, eager steps): every candidate geometry runs one real token step of a 1-layer
     Llama T3 at the real width; the narrow-tile and pipelined-attention candidates reproduce the current geometry's logits BIT FOR BIT, the
-    candidates that sum the down projection in another order are flagged (`reorders`) and never adopted; with the clock replaced by a table the
-    adoption rule is checked (fastest identical candidate wins, tile geometry first, attention knobs on top, confirmed back to back), and the
-    engine then samples the oracle's tokens on the adopted geometry."""
+    candidates that sum the down projection in another order are flagged (`reorders`) and are not `best`; with the clock replaced by a table the
+    adoption rule is checked (fastest identical candidate = best, tile geometry first, attention knobs on top, confirmed back to back; the fastest
+    candidate overall = best_any, adopted only because the validate callback -- here: the engine samples the ORACLE's tokens on it -- says so)."""
     from chatterbox_amd import autotune as at, synth
     from chatterbox_amd.t3 import T3Engine
     from oracle import ref_torch as O
     L, steps = 1, 3
     sd = synth.t3_state_dict(L, 0)
     eng = T3Engine(sd, CPU)
-    fake = {(): 1.0, (("qkv_tc", 12),): 0.8, (("od_tc", 4),): 0.9, (("d_ks2", 1), ("d_nw2", 8), ("od_tc", 4)): 0.3,
-            (("da_pipe", 3), ("qkv_tc", 12)): 0.7, (("da_pipe", 1), ("qkv_tc", 12)): 0.75}
+    reorder = dict(od_tc=4, d_ks2=1, d_nw2=8)
+    key = lambda v: tuple(sorted(v.items()))
+    fake = {(): 1.0, key(dict(qkv_tc=12)): 0.8, key(dict(od_tc=4)): 0.9, key(reorder): 0.3, key(dict(qkv_tc=12, da_pipe=3)): 0.7,
+            key(dict(reorder, da_pipe=3)): 0.25}
     real = T3Engine.measure_decode
 
     def measure(self, **kw):
         _, logits = real(self, **dict(kw, steps=0))  # one real token step per call; the clock is the table above
-        key = {k: v for k, v in self.tune.items() if v != T3Engine._TUNE[k]}
-        key.update({k: v for k, v in self.lib_knobs.items() if v != at.LIB_KNOBS[k]})
-        return fake[tuple(sorted(key.items()))], logits
+        k = {k: v for k, v in self.tune.items() if v != T3Engine._TUNE[k]}
+        k.update({k: v for k, v in self.lib_knobs.items() if v != at.LIB_KNOBS[k]})
+        return fake[key(k)], logits
 
     monkeypatch.setattr(T3Engine, "measure_decode", measure)
-    rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False,
-                       tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), dict(od_tc=4, d_ks2=1, d_nw2=8)), attn=(dict(da_pipe=3),))
-    rows = {tuple(sorted(r["variant"].items())): r for r in rep["candidates"] if "variant" in r}
-    assert all("error" not in r for r in rows.values()), rows
-    for k in ((("qkv_tc", 12),), (("od_tc", 4),), (("da_pipe", 3), ("qkv_tc", 12))):
-        assert rows[k]["identical"], f"{k}: logits differ from the current geometry's by {rows[k]['max_abs_diff']:.3e}"
-    r = rows[(("d_ks2", 1), ("d_nw2", 8), ("od_tc", 4))]
-    assert r["reorders"] and r["valid"] and r["max_abs_diff"] > 0, r  # another fp32 summation order: valid, fastest on the fake clock, NOT adopted
-    assert rep["best"] == dict(qkv_tc=12, da_pipe=3) and rep["ms_per_token"] == 0.7
-    assert eng.tune["qkv_tc"] == 12 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.lib_knobs["da_pipe"] == 3
-    assert "wqkv_pk12" in eng.layers[0] and not [k for k in eng._state if k[3] == 7]
-    try:
-        samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
-        texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
-        conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
-        u = synth.rand((2, steps), seed=11)
+    samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+    texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
+    conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
+    u = synth.rand((2, steps), seed=11)
+    seen_geometry = []
+
+    def validate():  # runs on the engine with best_any applied
+        seen_geometry.append((dict(eng.tune), dict(eng.lib_knobs)))
         toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
-        for b in range(2):
-            ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
-            assert toks[b].tolist() == ref.tolist(), f"utterance {b} on the adopted geometry: {toks[b].tolist()} vs oracle {ref.tolist()}"
+        return all(toks[b].tolist() == O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp).tolist()
+                   for b in range(2))
+
+    try:
+        rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False, tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), reorder), attn=(dict(da_pipe=3),),
+                           validate=validate)
+        rows = {key(r["variant"]): r for r in rep["candidates"] if "variant" in r}
+        assert all("error" not in r for r in rows.values()), rows
+        for k in (dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, da_pipe=3)):
+            assert rows[key(k)]["identical"], f"{k}: logits differ from the current geometry's by {rows[key(k)]['max_abs_diff']:.3e}"
+        for k in (reorder, dict(reorder, da_pipe=3)):  # another fp32 summation order: valid, fastest on the fake clock, never `best`
+            assert rows[key(k)]["reorders"] and rows[key(k)]["valid"] and rows[key(k)]["max_abs_diff"] > 0, rows[key(k)]
+        assert rep["best"] == dict(qkv_tc=12, da_pipe=3) and rep["ms_per_token"] == 0.7
+        assert rep["best_any"] == dict(reorder, da_pipe=3) and rep["ms_per_token_any"] == 0.25
+        assert len(seen_geometry) == 1 and seen_geometry[0][0]["d_ks2"] == 1 and seen_geometry[0][1]["da_pipe"] == 3
+        assert rep["best_any_validated"] is True and rep["adopted"] == rep["best_any"], rep  # the oracle's tokens on the reordered geometry
+        assert eng.tune["od_tc"] == 4 and eng.tune["d_ks2"] == 1 and eng.tune["qkv_tc"] == 0 and eng.lib_knobs["da_pipe"] == 3
+        assert "wd_pk4" in eng.layers[0] and not [k for k in eng._state if k[3] == 7]
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the library knobs are process-wide

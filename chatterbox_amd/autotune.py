@@ -31,14 +31,18 @@ TILE_VARIANTS = (dict(), dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4
                  dict(od_tc=4, d_ks2=1, d_nw2=8), dict(od_tc=4, d_ks2=1, d_nw2=16), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16),
                  dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, deep=1))
 # process-wide library knobs of the decode attention (cbx_set_decode_attn_pipeline / _unroll), tried on top of the best tile geometry
-ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe=1, da_u=8), dict(da_u=8))
-LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0)  # library defaults
+ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe=4), dict(da_pipe=5), dict(da_pipe=6), dict(da_pipe=7),
+                 dict(da_pipe=1, da_u=8), dict(da_u=8))
+# process-wide knob of every GEMV launch (cbx_set_gemv_epilogue_prefetch), tried on top of the best geometry so far
+EPI_VARIANTS = (dict(pre_epi=1),)
+LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)  # library defaults
 
 
 def env_knobs():
-    """The library knobs as the environment sets them when libcbx_hip.so loads (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP)."""
+    """The library knobs as the environment sets them when libcbx_hip.so loads (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP, CBX_GEMV_PRE_EPI)."""
     e = os.environ.get
-    return dict(da_pipe=int(e("CBX_DA_PIPE") or 0) & 3, da_u=int(e("CBX_DA_U") or 0) or 4, deep=int(e("CBX_GEMV_DEEP") or 0))
+    return dict(da_pipe=int(e("CBX_DA_PIPE") or 0) & 7, da_u=int(e("CBX_DA_U") or 0) or 4, deep=int(e("CBX_GEMV_DEEP") or 0),
+                pre_epi=int(bool(int(e("CBX_GEMV_PRE_EPI") or 0))))
 
 
 def split_variant(v):
@@ -47,7 +51,7 @@ def split_variant(v):
 
 
 def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, use_graph=True, tiles=TILE_VARIANTS, attn=ATTN_VARIANTS,
-                log=None):
+                epi=EPI_VARIANTS, log=None):
     """Time every candidate on `eng` (in this process) and return the report; `eng` is left on the geometry it came with.
     report["best"]: the fastest candidate whose logits are bit-identical to the current geometry's ({} = keep it); report["best_any"]: the
     fastest candidate overall, reordering ones included (== best unless a reordering candidate is faster still by min_gain) -- for callers
@@ -92,6 +96,9 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
     for base in (pick(True), pick(False)):  # the attention knobs on top of the best identical tile geometry and of the best one overall
         for a in attn:
             consider(dict(base, **a))
+    for base in (pick(True), pick(False)):  # the GEMV epilogue prefetch on top of whatever leads now
+        for a in epi:
+            consider(dict(base, **a))
 
     def confirm(v):  # back to back against the current geometry (`reps` more rounds each): the pool's boxes drift by a few per cent over seconds
         if not v:
@@ -120,7 +127,8 @@ def tune_in_child(layers, B, ctx, steps, reps, min_gain, allow_reorder, device_i
            json.dumps(base_knobs)] + (["--allow-reorder"] if allow_reorder else [])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CBX_T3_TUNE", "CBX_DA_PIPE", "CBX_DA_U", "CBX_GEMV_DEEP"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CBX_T3_TUNE", "CBX_DA_PIPE", "CBX_DA_U", "CBX_GEMV_DEEP",
+              "CBX_GEMV_PRE_EPI"):
         env.pop(k, None)  # the child is a plain single-device process whose starting geometry arrives on the command line
     for k in [k for k in env if k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")) or (k == "LD_PRELOAD" and "rocprof" in env[k])]:
         env.pop(k)  # under rocprofv3 the candidates' kernels (same names, other geometries) must not enter the parent's kernel statistics
@@ -154,7 +162,8 @@ def tune_in_child(layers, B, ctx, steps, reps, min_gain, allow_reorder, device_i
     return rep
 
 
-def main(argv=None):
+def main(argv=None, device=None):
+    """`device` is for tests (the SIMT emulator drives this on the CPU); the command line always measures on the GPU."""
     import argparse
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--layers", type=int, default=30)
@@ -173,12 +182,15 @@ def main(argv=None):
 
     from . import synth
     from .t3 import T3Engine
-    assert torch.cuda.is_available(), "the autotuner measures on the GPU"
-    torch.cuda.set_device(a.device)
-    eng = T3Engine(synth.t3_state_dict(a.layers, 0), torch.device("cuda", a.device), n_layers=a.layers)
+    if device is None:
+        assert torch.cuda.is_available(), "the autotuner measures on the GPU"
+        torch.cuda.set_device(a.device)
+        device = torch.device("cuda", a.device)
+    eng = T3Engine(synth.t3_state_dict(a.layers, 0), device, n_layers=a.layers)
     eng.apply_variant(dict(eng.tune, **json.loads(a.tune)), dict(LIB_KNOBS, **json.loads(a.knobs)))
     log = (lambda m: print(m, file=sys.stderr, flush=True)) if a.verbose else None
-    rep = tune_decode(eng, B=a.batch, ctx=a.ctx, steps=a.steps, reps=a.reps, min_gain=a.min_gain, allow_reorder=a.allow_reorder, log=log)
+    rep = tune_decode(eng, B=a.batch, ctx=a.ctx, steps=a.steps, reps=a.reps, min_gain=a.min_gain, allow_reorder=a.allow_reorder, log=log,
+                      use_graph=device.type == "cuda")
     print(json.dumps(rep), flush=True)
 
 

@@ -264,7 +264,13 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
 // the measured slope of 1.6 us per 64 positions, profiles/r02_decode_micro.log, is that round trip).  Same arithmetic, same order, same results.
 // NT (cbx_set_decode_attn_pipeline(2 | 3), same provenance): the K / V rows are read with the non-temporal policy -- a (row, head)'s cache is
 // streamed once per token step by one CU, the case for which MI355X_MICROARCH.md measures nt loads 5-10 % ahead on a decode layer.
-template <int DA_U, bool SPLIT, bool PIPE = false, bool NT = false>
+// SPEC (cbx_set_decode_attn_pipeline bit 2, 4 rows per step; written after the GPU budget of round 3 was spent, emulator-verified, timed by
+// the autotuner): the FIRST step's K / V rows (positions 0 .. 63 of the (row, head)) are requested before positions[row] has arrived -- their
+// addresses do not depend on it -- instead of after it: one dependent memory round trip less on a launch that is a chain of five or six.
+// Rows at or past the new position are then discarded (k, v := 0 before the step: they are masked to -inf / weight 0 either way, and the
+// clamped form multiplied row 0's finite values by the same 0), so a cache holding anything at all past its context stays harmless.
+// Needs 64 positions of cache behind every (row, head) (head_stride >= 64 * 64; rows beyond it are clamped to row 0).
+template <int DA_U, bool SPLIT, bool PIPE = false, bool NT = false, bool SPEC = false>
 __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __restrict__ qkv, const int* __restrict__ positions,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
@@ -283,18 +289,32 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     // still walked by ONE workgroup (split 0; the others leave at once): the hand-off costs ~5 us on the critical path (release, ticket,
     // acquire, merge), more than the 1-2 round trips a short context takes (measured: batch-1 Llama decode +15 % with an unconditional split)
     const int sp = SPLIT ? (int)blockIdx.z : 0;
-    const int S = SPLIT && positions[blockIdx.y] + 1 >= split_min_ctx ? (int)gridDim.z : 1;
-    if (SPLIT && S == 1 && sp != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
-    const int pos = positions[row];
-    const int ctx = pos + 1;
     float* kb = kc + (long)row * row_stride + (long)head * head_stride;
     float* vb = vc + (long)row * row_stride + (long)head * head_stride;
-
     // lane group g = wid*4 + sub handles positions g, g+16, g+32, ...
     f32x4 kv[DA_U], vv[DA_U];
     f32x4 kv2[PIPE ? DA_U : 1], vv2[PIPE ? DA_U : 1];  // PIPE: the second register set
+    if constexpr (SPEC) {  // split 0's first step (positions wid*4 + sub + 16 u), before anything that depends on positions[]
+#pragma unroll
+        for (int u = 0; u < DA_U; ++u) {
+            const int p = wid * 4 + sub + 16 * u;
+            const int pc = (long)(p + 1) * 64 <= head_stride ? p : 0;
+            if constexpr (NT) {
+                kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4));
+            } else {
+                kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)pc * 64 + l16 * 4);
+                vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)pc * 64 + l16 * 4);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int S = SPLIT && positions[blockIdx.y] + 1 >= split_min_ctx ? (int)gridDim.z : 1;
+    if (SPLIT && S == 1 && sp != 0) return;
+    const int pos = positions[row];
+    const int ctx = pos + 1;
     auto load_rows = [&](f32x4* kd, f32x4* vd, int p0) {
 #pragma unroll
         for (int u = 0; u < DA_U; ++u) {
@@ -314,7 +334,17 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     const int slice = S > 1 ? ((ctx + 16 * S - 1) / (16 * S)) * 16 : ctx;
     const int p_lo = sp * slice, p_hi = min(ctx, p_lo + slice);
     int p0 = p_lo + wid * 4 + sub;
-    load_chunk(p0);
+    if (!SPEC || p_lo != 0) load_chunk(p0);  // SPEC: already on its way (a later split of a long context starts elsewhere: requested now)
+    // SPEC: rows of the first step at or past the new position hold whatever the cache holds there -- dropped when the step consumes them
+    auto drop_unwritten = [&](f32x4* kd, f32x4* vd, int p0) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < DA_U; ++u)
+            if (p0 + 16 * u >= pos) kd[u] = z4, vd[u] = z4;
+    };
+    // (pos == 0, any form: the clamped loads fetched row 0, which is the not yet written slot of the new token itself -- the only case in
+    // which the clamp does not land on a finite row of a cache that holds garbage past its context)
+    bool spec_first = (SPEC && p_lo == 0) || pos == 0;
 
     if (wid == 0) {
         const float* qp = qkv + (long)row * ld_qkv + head * 64;
@@ -372,6 +402,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         while (true) {
             load_rows(kv2, vv2, p0 + STEP);  // requested before the arithmetic on the set that has landed
             __builtin_amdgcn_sched_barrier(0);
+            if (spec_first) drop_unwritten(kv, vv, p0), spec_first = false;
             step(kv, vv, p0);
             p0 += STEP;
             if (p0 >= p_hi) break;
@@ -382,6 +413,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             if (p0 >= p_hi) break;
         }
     } else {
+        if (spec_first) drop_unwritten(kv, vv, p0);
         while (true) {
             step(kv, vv, p0);
             p0 += 16 * DA_U;
@@ -543,8 +575,8 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     return 0;
 }
 static int g_da_pipe = getenv("CBX_DA_PIPE") ? atoi(getenv("CBX_DA_PIPE")) : 0;
-extern "C" int cbx_set_decode_attn_pipeline(int on) {  // bit 0: pipelined K / V stream; bit 1: non-temporal K / V loads (4 rows per step)
-    g_da_pipe = on & 3;
+extern "C" int cbx_set_decode_attn_pipeline(int on) {  // bit 0: pipelined K / V stream; bit 1: non-temporal K / V loads; bit 2: speculative first step
+    g_da_pipe = on & 7;
     return 0;
 }
 constexpr int DA_MAX_SPLIT = 8;
@@ -580,24 +612,31 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     // at contexts of 200-700 by 1-4 %; the split engages on contexts >= cbx_set_decode_attn_split_min (512): a 1000-token Turbo generation
     // (contexts to ~1450) decodes at 1.03 ms / token with it, 1.20 without (profiles/r03_turbo_long_context.log).
     const int da_u = g_da_u > 0 ? g_da_u : 4;
-#define CBX_DA_LAUNCH(U, P, N)                                                                                                             \
+#define CBX_DA_LAUNCH(U, P, N, SP)                                                                                                         \
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N, SP>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
         else                                                                                                                               \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N, SP>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
                                ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
     } while (0)
-    if (g_da_pipe & 2) {  // non-temporal K / V loads (4 rows per lane group and step), plain or pipelined
-        if (g_da_pipe & 1) CBX_DA_LAUNCH(4, true, true);
-        else CBX_DA_LAUNCH(4, false, true);
+    if (g_da_pipe & 4) {  // speculative first step (4 rows per lane group and step), with or without the pipelined stream / non-temporal loads
+        switch (g_da_pipe & 3) {
+            case 0: CBX_DA_LAUNCH(4, false, false, true); break;
+            case 1: CBX_DA_LAUNCH(4, true, false, true); break;
+            case 2: CBX_DA_LAUNCH(4, false, true, true); break;
+            default: CBX_DA_LAUNCH(4, true, true, true); break;
+        }
+    } else if (g_da_pipe & 2) {  // non-temporal K / V loads (4 rows per lane group and step), plain or pipelined
+        if (g_da_pipe & 1) CBX_DA_LAUNCH(4, true, true, false);
+        else CBX_DA_LAUNCH(4, false, true, false);
     } else if (g_da_pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
-        if (da_u == 8) CBX_DA_LAUNCH(8, true, false);
-        else CBX_DA_LAUNCH(4, true, false);
-    } else if (da_u == 8) CBX_DA_LAUNCH(8, false, false);
-    else if (da_u == 16) CBX_DA_LAUNCH(16, false, false);
-    else CBX_DA_LAUNCH(4, false, false);
+        if (da_u == 8) CBX_DA_LAUNCH(8, true, false, false);
+        else CBX_DA_LAUNCH(4, true, false, false);
+    } else if (da_u == 8) CBX_DA_LAUNCH(8, false, false, false);
+    else if (da_u == 16) CBX_DA_LAUNCH(16, false, false, false);
+    else CBX_DA_LAUNCH(4, false, false, false);
 #undef CBX_DA_LAUNCH
     return cbx_check_launch("decode_attn_rope");
 }

@@ -113,6 +113,48 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         ss[t] = 0.f;
         sx[t] = 0.f;
     }
+    // ---- epilogue operands requested FIRST (opt-in: cbx_set_gemv_epilogue_prefetch / p.reserved1, written after the GPU budget of round 3
+    // was spent: emulator-verified, timed by the autotuner).  The element(s) a thread finishes after the reduction are known now; its
+    // residual, bias and LayerNorm-fold constants do not depend on the contraction, so their loads go out with the first weight batch instead
+    // of after the LDS reduction -- where each is a dependent global round trip (~1 us) on the critical path of a launch that lasts 5-9 us.
+    // Same values, same order of the additions: results unchanged bit for bit.  (res may alias out: a thread reads exactly the element it
+    // writes.)
+    const bool PRE = p.reserved1 != 0;  // uniform (kernel argument)
+    constexpr int EIT = (MT * 256 + NW * 64 - 1) / (NW * 64);
+    float e_res[EIT], e_bias[EIT], e_cw[EIT], e_cb[EIT];
+    long e_o[EIT];
+    int e_n[EIT];
+#pragma unroll
+    for (int j = 0; j < EIT; ++j) {
+        const int e = tid + j * NW * 64;
+        const int t = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
+        // threads without an element (idle waves, rows >= M, columns past the tile / N) address this workgroup's element (0, n0): the loads
+        // below stay unconditional per lane (a lane-predicated load would put a wait in front of the weight stream)
+        const bool ok = e < MT * 256 && (t * 16 + row) < p.M && (n0 + col) < p.N && col < tc;
+        const int tt = ok ? t : 0, rr = ok ? row : 0, n = ok ? n0 + col : n0;
+        if (p.out_packed)  // the consumer's lane-ordered operand layout (its K = this N): see cbx.h
+            e_o[j] = (long)ks * p.part_stride + (((long)tt * (p.N >> 5) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + rr) * 4 + (n & 3);
+        else
+            e_o[j] = (long)ks * p.part_stride + (long)(tt * 16 + rr) * p.ldo + n;
+        e_n[j] = n;
+        e_res[j] = e_bias[j] = e_cw[j] = e_cb[j] = 0.f;
+    }
+    if (PRE && p.res) {  // uniform branches (kernel arguments)
+#pragma unroll
+        for (int j = 0; j < EIT; ++j) e_res[j] = p.res[e_o[j]];
+    }
+    if constexpr (!SWIGLU) {
+        if (PRE && p.bias && ks == 0) {
+#pragma unroll
+            for (int j = 0; j < EIT; ++j) e_bias[j] = p.bias[e_n[j]];
+        }
+    }
+    if constexpr (RMS) {
+        if (PRE && p.ln_cw) {
+#pragma unroll
+            for (int j = 0; j < EIT; ++j) e_cw[j] = p.ln_cw[e_n[j]], e_cb[j] = p.ln_cb[e_n[j]];
+        }
+    }
     constexpr int DEPTH = D8 ? 8 : (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
@@ -217,7 +259,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         }
     }
     __syncthreads();
-    for (int e = tid; e < MT * 256; e += NW * 64) {
+#pragma unroll
+    for (int j = 0; j < EIT; ++j) {
+        const int e = tid + j * NW * 64;
+        if (e >= MT * 256) break;
         const int t = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
         const int m = t * 16 + row, n = n0 + col;
         if (m >= p.M || n >= p.N || col >= tc) continue;
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                 for (int ww = 0; ww < NW; ++ww) su += ssx[(ww * MT + t) * 16 + row];
                 const float mean = su / (float)p.K;
                 const float rstd = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.f) + p.eps);
-                v = rstd * (v - mean * p.ln_cw[n]) + p.ln_cb[n];
+                v = PRE ? rstd * (v - mean * e_cw[j]) + e_cb[j] : rstd * (v - mean * p.ln_cw[n]) + p.ln_cb[n];
             } else {
                 const float rstd = rsqrtf(sq / (float)p.K + p.eps);
                 v *= rstd;
@@ -247,20 +292,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         if constexpr (SWIGLU) {
             v = (v / (1.0f + __expf(-v))) * v2;
         } else {
-            if (p.bias && ks == 0) v += p.bias[n];
+            if (p.bias && ks == 0) v += PRE ? e_bias[j] : p.bias[n];
             if (p.act) v = cbx_act(v, p.act, 0.f, 0.f);  // only meaningful with ksplit == 1
         }
-        long o;
-        if (p.out_packed)  // the consumer's lane-ordered operand layout (its K = this N): see cbx.h
-            o = (long)ks * p.part_stride + (((long)t * (p.N >> 5) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + row) * 4 + (n & 3);
-        else
-            o = (long)ks * p.part_stride + (long)m * p.ldo + n;
-        if (p.res) v += p.res[o];  // residual stream in the same layout as out (in place is fine: one thread per element)
-        p.out[o] = v;
+        if (p.res) v += PRE ? e_res[j] : p.res[e_o[j]];  // residual stream in the same layout as out (in place is fine: one thread per element, read before written)
+        p.out[e_o[j]] = v;
     }
 }
 
 int g_gemv_deep = getenv("CBX_GEMV_DEEP") ? atoi(getenv("CBX_GEMV_DEEP")) : 0;  // cbx_set_gemv_deep_batches
+int g_gemv_pre_epi = getenv("CBX_GEMV_PRE_EPI") ? atoi(getenv("CBX_GEMV_PRE_EPI")) : 0;  // cbx_set_gemv_epilogue_prefetch
 
 template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0, bool WB = false>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
@@ -511,10 +552,16 @@ extern "C" int cbx_set_gemv_deep_batches(int on) {
     return 0;
 }
 
+extern "C" int cbx_set_gemv_epilogue_prefetch(int on) {
+    g_gemv_pre_epi = on != 0;
+    return 0;
+}
+
 extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     cbx_gemv_t p = *pp;
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.nw != 8 && p.nw != 16) p.nw = 4;
+    p.reserved1 = g_gemv_pre_epi != 0;  // the process-wide knob travels to the kernel in the descriptor's spare word
     CBX_REQUIRE(p.x && p.W && p.out, "gemv: null operand");
     CBX_REQUIRE(p.M >= 1 && p.M <= 64 && p.N > 0 && p.K > 0, "gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);

@@ -176,7 +176,7 @@ class T3Engine:
 
     # ------------------------------------------------------------------ decode-step geometry: measured, not guessed (autotune.py)
     def apply_variant(self, tune, knobs=None):
-        """Switch the decode geometry: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep) are the process-wide library knobs of the
+        """Switch the decode geometry: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep, pre_epi) are the process-wide library knobs of the
         decode attention / GEMV load batches.  Captured decode graphs and C step descriptors bake the geometry in: they are dropped."""
         from .autotune import LIB_KNOBS
         self.tune = dict(tune)
@@ -184,6 +184,7 @@ class T3Engine:
         ops.lib.cbx_set_decode_attn_pipeline(int(k["da_pipe"]))
         ops.lib.cbx_set_decode_attn_unroll(int(k["da_u"]))
         ops.lib.cbx_set_gemv_deep_batches(int(k["deep"]))
+        ops.lib.cbx_set_gemv_epilogue_prefetch(int(k["pre_epi"]))
         self.lib_knobs = k
         for st in self._state.values():
             st["graph"] = None
@@ -251,7 +252,7 @@ class T3Engine:
         return best, logits
 
     def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None,
-                 validate=None):
+                 epi=None, validate=None):
         """Measure the decode-step geometries (autotune.py) and adopt the fastest one whose logits are bit-identical to the current
         geometry's.  in_child: the candidates run in a child process on synthetic weights of this shape, so a faulting candidate cannot take
         the serving process down; its failure leaves the geometry unchanged.  validate: a callable run on THIS engine after the fastest
@@ -268,7 +269,8 @@ class T3Engine:
             rep = at.tune_in_child(self.L, B, ctx, steps, reps, min_gain, allow_reorder, self.dev.index or 0, base, knobs, timeout, log)
         else:
             rep = at.tune_decode(self, B, ctx, steps, reps, min_gain, allow_reorder, use_graph=self.dev.type == "cuda", log=log,
-                                 tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn)
+                                 tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn,
+                                 epi=at.EPI_VARIANTS if epi is None else epi)
 
         def adopt(v):
             t, k = at.split_variant(v)

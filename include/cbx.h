@@ -190,6 +190,11 @@ int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
 /* ABI v9, A/B knob (env CBX_GEMV_DEEP, default 0): 1 = an 8-wave plain packed GEMV whose waves own >= 256 of K (the down projection with
  * ksplit = 1) requests 8 K blocks per batch instead of 4 -- half the dependent load batches; bit-identical results. */
 int cbx_set_gemv_deep_batches(int on);
+/* ABI v9, A/B knob (env CBX_GEMV_PRE_EPI, default 0): 1 = every cbx_gemv_f32 launch requests the operands of its epilogue (residual element,
+ * bias, LayerNorm-fold constants) together with its first weight batch instead of after the reduction -- one dependent memory round trip less
+ * per launch; same values added in the same order, bit-identical results.  (Travels to the kernel in cbx_gemv_t.reserved1, which callers
+ * leave 0: the entry point overwrites it with the knob.) */
+int cbx_set_gemv_epilogue_prefetch(int on);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
@@ -268,8 +273,9 @@ int cbx_set_split_tile(int t);
 /* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
 int cbx_set_decode_attn_unroll(int u);
 /* ABI v9: bit 0 = software-pipelined K / V stream (the rows of the next step are requested before the current step is multiplied; two register
- * sets; 4 or 8 rows per lane group and step); bit 1 = non-temporal K / V loads (4 rows per step).  Same results bit for bit.  Default 0
- * (env CBX_DA_PIPE = 0 .. 3). */
+ * sets; 4 or 8 rows per lane group and step); bit 1 = non-temporal K / V loads (4 rows per step); bit 2 = speculative first step (positions
+ * 0 .. 63 of every (row, head) are requested before positions[row] has arrived; needs cache_head_stride >= 64 * 64; 4 rows per step).
+ * Same results bit for bit.  Default 0 (env CBX_DA_PIPE = 0 .. 7). */
 int cbx_set_decode_attn_pipeline(int on);
 /* Workspace of cbx_decode_attn_rope_f32's split-context form, used when rows * n_heads < 128 (Turbo / Nano at small batch): ws = 66 * 8 floats
  * per (row, head), zeroed_counters = one int per (row, head), initialised to 0 once; registered for the calling thread's current device. */

@@ -72,6 +72,10 @@ _OPS = [
     ("test_gemv_narrow_tiles", (9, 1024, 4096, 1, 8, 4, "plain")), ("test_gemv_narrow_tiles", (5, 40, 256, 2, 4, 12, "plain")),
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
 ]
+_EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
+        ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
+        ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
+        ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2"))]
 
 
 @pytest.mark.parametrize("name,args", _OPS, ids=[f"{n}{list(a)}" for n, a in _OPS])
@@ -79,6 +83,12 @@ def test_gpu_op_bodies_on_the_emulator(emu, name, args):
     import test_ops_gpu
     import test_zz_abi_v9_gpu
     getattr(test_ops_gpu if hasattr(test_ops_gpu, name) else test_zz_abi_v9_gpu, name)(CPU, *args)
+
+
+@pytest.mark.parametrize("name,args", _EPI, ids=[f"{n}{list(a)}" for n, a in _EPI])
+def test_gemv_epilogue_prefetch_on_the_emulator(emu, name, args, monkeypatch):
+    import test_zz_abi_v9_gpu
+    test_zz_abi_v9_gpu.test_gemv_epilogue_prefetch_equals_plain(CPU, name, args, monkeypatch)
 
 
 _PLANES = [("test_split_planes_roundtrip_and_range_flag", ()), ("test_layernorm_planes", ()), ("test_gemm_planes_transposed_rejects_bad_arguments", ())]
@@ -506,7 +516,7 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     """chatterbox_amd/autotune.py driven on the emulator (in-process, eager steps): every candidate geometry runs one real token step of a 1-layer
     Llama T3 at the real width; the narrow-tile and pipelined-attention candidates reproduce the current geometry's logits BIT FOR BIT, the
     candidates that sum the down projection in another order are flagged (`reorders`) and are not `best`; with the clock replaced by a table the
-    adoption rule is checked (fastest identical candidate = best, tile geometry first, attention knobs on top, confirmed back to back; the fastest
+    adoption rule is checked (fastest identical candidate = best, tile geometry first, attention knobs, then the GEMV epilogue prefetch on top, confirmed back to back; the fastest
     candidate overall = best_any, adopted only because the validate callback -- here: the engine samples the ORACLE's tokens on it -- says so)."""
     from chatterbox_amd import autotune as at, synth
     from chatterbox_amd.t3 import T3Engine
@@ -517,7 +527,7 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     reorder = dict(od_tc=4, d_ks2=1, d_nw2=8)
     key = lambda v: tuple(sorted(v.items()))
     fake = {(): 1.0, key(dict(qkv_tc=12)): 0.8, key(dict(od_tc=4)): 0.9, key(reorder): 0.3, key(dict(qkv_tc=12, da_pipe=3)): 0.7,
-            key(dict(reorder, da_pipe=3)): 0.25}
+            key(dict(reorder, da_pipe=3)): 0.25, key(dict(qkv_tc=12, da_pipe=3, pre_epi=1)): 0.65, key(dict(reorder, da_pipe=3, pre_epi=1)): 0.2}
     real = T3Engine.measure_decode
 
     def measure(self, **kw):
@@ -544,15 +554,15 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
                            validate=validate)
         rows = {key(r["variant"]): r for r in rep["candidates"] if "variant" in r}
         assert all("error" not in r for r in rows.values()), rows
-        for k in (dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, da_pipe=3)):
+        for k in (dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, da_pipe=3), dict(qkv_tc=12, da_pipe=3, pre_epi=1)):
             assert rows[key(k)]["identical"], f"{k}: logits differ from the current geometry's by {rows[key(k)]['max_abs_diff']:.3e}"
-        for k in (reorder, dict(reorder, da_pipe=3)):  # another fp32 summation order: valid, fastest on the fake clock, never `best`
+        for k in (reorder, dict(reorder, da_pipe=3), dict(reorder, da_pipe=3, pre_epi=1)):  # another fp32 summation order: valid, fastest on the fake clock, never `best`
             assert rows[key(k)]["reorders"] and rows[key(k)]["valid"] and rows[key(k)]["max_abs_diff"] > 0, rows[key(k)]
-        assert rep["best"] == dict(qkv_tc=12, da_pipe=3) and rep["ms_per_token"] == 0.7
-        assert rep["best_any"] == dict(reorder, da_pipe=3) and rep["ms_per_token_any"] == 0.25
-        assert len(seen_geometry) == 1 and seen_geometry[0][0]["d_ks2"] == 1 and seen_geometry[0][1]["da_pipe"] == 3
+        assert rep["best"] == dict(qkv_tc=12, da_pipe=3, pre_epi=1) and rep["ms_per_token"] == 0.65
+        assert rep["best_any"] == dict(reorder, da_pipe=3, pre_epi=1) and rep["ms_per_token_any"] == 0.2
+        assert len(seen_geometry) == 1 and seen_geometry[0][0]["d_ks2"] == 1 and seen_geometry[0][1]["da_pipe"] == 3 and seen_geometry[0][1]["pre_epi"] == 1
         assert rep["best_any_validated"] is True and rep["adopted"] == rep["best_any"], rep  # the oracle's tokens on the reordered geometry
-        assert eng.tune["od_tc"] == 4 and eng.tune["d_ks2"] == 1 and eng.tune["qkv_tc"] == 0 and eng.lib_knobs["da_pipe"] == 3
+        assert eng.tune["od_tc"] == 4 and eng.tune["d_ks2"] == 1 and eng.tune["qkv_tc"] == 0 and eng.lib_knobs["da_pipe"] == 3 and eng.lib_knobs["pre_epi"] == 1
         assert "wd_pk4" in eng.layers[0] and not [k for k in eng._state if k[3] == 7]
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the library knobs are process-wide

@@ -90,14 +90,22 @@ def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
                 pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
                 qkv = _r((rows, 3 * H * 64), 100 + n)
                 res = []
-                for pipe in (0, 1) + ((2, 3) if u == 4 else ()):  # 2 / 3: non-temporal K / V loads, plain / pipelined
+                # 2 / 3: non-temporal K / V loads, plain / pipelined; 4 .. 7: the same four with the speculative first step (positions 0 .. 63 requested
+                # before positions[row] has arrived) -- the cache past each row's context is poisoned with NaN: whatever is read there must not matter
+                for pipe in (0, 1) + ((2, 3, 4, 5, 6, 7) if u == 4 else ()):
                     ops.lib.cbx_set_decode_attn_pipeline(pipe)
-                    kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.zeros(rows, H * 64, device=dev)
+                    kc, vc, out = kc0.clone(), vc0.clone(), torch.zeros(rows, H * 64, device=dev)
+                    for r in range(rows):
+                        kc[r, :, int(pos[r]):], vc[r, :, int(pos[r]):] = float("nan"), float("nan")
+                    kc, vc = kc.to(dev), vc.to(dev)
                     ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
-                    res.append((out.cpu(), kc.cpu(), vc.cpu()))
+                    kc, vc = kc.cpu(), vc.cpu()
+                    assert all(bool(torch.isnan(c[r, :, int(pos[r]) + 1:]).all()) and bool(torch.isfinite(c[r, :, : int(pos[r]) + 1]).all())
+                               for c in (kc, vc) for r in range(rows)), "exactly one row appended per (row, head)"
+                    res.append((out.cpu(), torch.nan_to_num(kc), torch.nan_to_num(vc)))
                 for other in res[1:]:
                     for a, b, what in zip(res[0], other, ("output", "k cache", "v cache")):
-                        assert torch.equal(a, b), f"pipelined / non-temporal decode attention differs in the {what} (U = {u}, context {n + 1})"
+                        assert torch.equal(a, b) and bool(torch.isfinite(a).all()), f"pipelined / non-temporal / speculative decode attention differs in the {what} (U = {u}, context {n + 1})"
                 if n in (0, 63, 64, 65, 300):  # and the result itself against torch
                     q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
                     if rope:
@@ -230,3 +238,45 @@ def test_decode_autotuner_adopts_only_bit_identical_geometries(dev):
         assert toks[0].tolist() == g["tokens"].tolist(), f"adopted geometry {best}"
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the attention knobs are process-wide
+
+
+_EPI_BODIES = [("test_gemv_decode", (16, 3072, 1024, 1, 8)), ("test_gemv_decode", (40, 1024, 1024, 2, 4)), ("test_gemv_decode", (6, 64, 256, 1, 4)),
+               ("test_gemv_swiglu", ()), ("test_gemv_packed_rms_fused", (16, 3072, 1024, False, 8)),
+               ("test_gemv_packed_residual_epilogue", (16, 1024, 1024, 16)), ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)),
+               ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)), ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)),
+               ("test_gemv_half_tile", (16, 1024, 1024, 1, 8, True)), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
+               ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2")), ("test_gemv_deep_batches_equal_plain", (16, 1024, 4096, 1, 4, True))]
+
+
+@pytest.mark.parametrize("name,args", _EPI_BODIES, ids=[f"{n}{list(a)}" for n, a in _EPI_BODIES])
+def test_gemv_epilogue_prefetch_equals_plain(dev, name, args, monkeypatch):
+    """cbx_set_gemv_epilogue_prefetch(1): the residual element, the bias and the LayerNorm-fold constants of a GEMV's epilogue are requested
+    with the first weight batch instead of after the reduction.  Every GEMV launch of the established bodies (bias, split-K, swiglu, RMSNorm
+    and LayerNorm folds, in-place packed residual, narrow tiles, deep batches) runs twice -- knob off, knob on -- from the same memory state:
+    outputs bit-identical, and the body's own comparison against torch holds with the knob on."""
+    import sys
+    import test_ops_gpu
+    from chatterbox_amd import ops
+    real, n = ops.gemv, [0]
+
+    def both(x, w, out, **kw):
+        keep = [(t, t.clone()) for t in (out, kw.get("x_out")) if t is not None]
+        ops.lib.cbx_set_gemv_epilogue_prefetch(0)
+        real(x, w, out, **kw)
+        plain = [t.clone() for t, _ in keep]
+        for t, c in keep:
+            t.copy_(c)
+        ops.lib.cbx_set_gemv_epilogue_prefetch(1)
+        r = real(x, w, out, **kw)
+        for (t, _), p in zip(keep, plain):
+            assert torch.equal(t.cpu(), p.cpu()), f"{name}{list(args)}: launch {n[0]} differs with the epilogue operands prefetched"
+        n[0] += 1
+        return r
+
+    monkeypatch.setattr(ops, "gemv", both)
+    try:
+        body = getattr(test_ops_gpu, name, None) or getattr(sys.modules[__name__], name)
+        body(dev, *args)
+    finally:
+        ops.lib.cbx_set_gemv_epilogue_prefetch(0)
+    assert n[0] >= 1

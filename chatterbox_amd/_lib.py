@@ -94,6 +94,7 @@ _SIGS = {
     "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
     "cbx_add_rmsnorm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_f], c_int),
     "cbx_layernorm_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_float, c_int, c_int, c_float, c_f], c_int),
+    "cbx_flash_relpos_f32": ([c_f] * 7 + [c_int] * 3 + [c_long] * 5 + [c_float, c_f], c_int),
     "cbx_flash_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_f], c_int),
     "cbx_flash_attn_split_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),

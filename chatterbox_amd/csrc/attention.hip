@@ -170,6 +170,221 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Flash attention with the relative-position term of the conformer encoder (RelPositionMultiHeadedAttention, reference
+// transformer/attention.py:249-330), exact fp32:  o_i = softmax_j( scale * ((q_i + u) k_j + (q_i + v) p_{T-1-i+j}) ) V  without the
+// (T, T) and (T, 2T-1) score tensors of the materialised path (cbx_gemm_f32 x 3 + cbx_softmax_relpos_f32: 16 T^2 floats per head).
+//
+// Same swapped formulation as flash_attn_f32_kernel (S^T = K Q^T: a lane owns one query, softmax statistics are lane-local).  The
+// position term of a 32-key x 32-query block is a diagonal band of G^T = P_rows (q + v)^T:  bd^T[jj][c] = G^T[R0 + jj - c][c], a shift
+// along the ROW index by the lane's own column -- i.e. along the register index of the MFMA C layout, by a lane-dependent amount.  That
+// needs one trip through memory: every wave keeps a ring of three 32-row G^T blocks in LDS ([position row][query], row stride 40 floats:
+// bank = 40 row + c is conflict-free for the C-layout stores and for the diagonal loads alike) and reads its band back.  Position rows
+// advance with the keys: a 64-key tile needs blocks 2n, 2n + 1, 2n + 2 of the wave's row window, and block 2n is the previous tile's
+// 2n + 2 -- so the term costs 64 MFMAs per key tile, as many as q k^T itself (not the 2x of the full (T, 2T-1) product).
+// The rows of P are read straight from global memory as the MFMA A operand (P is (2T-1, n_heads * 64) floats: L2-resident).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int G_LD = 40;               // row stride (floats) of a G^T block
+constexpr int G_WAVE = 3 * 32 * G_LD;  // floats per wave: ring of three blocks
+constexpr int RELPOS_LDS = (KT * K_LD + KT * V_LD + 4 * G_WAVE) * 4;
+
+struct FlashRelArgs {
+    const float* qu; const float* qv; const float* k; const float* v; const float* pp; float* o; const int* key_lens;
+    int T, P;
+    long q_sb, q_st, pp_st, o_sb, o_st;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void flash_relpos_f32_kernel(const FlashRelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rel_smem[];
+    float* Ks = rel_smem;
+    float* Vs = rel_smem + KT * K_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    float* Gw = rel_smem + KT * K_LD + KT * V_LD + wid * G_WAVE;
+    const int tile = cbx_xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int qt = tile % gridDim.x, head = (tile / gridDim.x) % gridDim.y, z = tile / (gridDim.x * gridDim.y);
+    const int q0 = qt * 128;
+    const int i0w = q0 + wid * 32;  // the wave's first query
+    const int qi = i0w + lr;        // this lane's query
+    const long zoff = (long)z * a.q_sb + head * 64;
+    const float* kb = a.k + zoff;
+    const float* vb = a.v + zoff;
+    const float* pb = a.pp + head * 64 + 32 * lh;
+    const int klen = a.key_lens ? min(a.T, a.key_lens[z]) : a.T;
+    const int rb0 = a.T - 1 - i0w - 31;  // position row of (block 0, row 0) of this wave's window: block b covers rows rb0 + 32 b .. + 31
+
+    // (q + u) and (q + v) fragments of this lane's query: d = s + 32*lh, pre-scaled
+    float qreg[32], qvreg[32];
+    {
+        const bool ok = qi < a.T;
+        const long off = zoff + (long)(ok ? qi : 0) * a.q_st + 32 * lh;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(a.qu + off + s4 * 4);
+            f32x4 w = *reinterpret_cast<const f32x4*>(a.qv + off + s4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qreg[s4 * 4 + e] = ok ? t[e] * a.scale : 0.f;
+                qvreg[s4 * 4 + e] = ok ? w[e] * a.scale : 0.f;
+            }
+        }
+    }
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ld_row = tid >> 2, ld_c = (tid & 3) * 16;
+    f32x4 kreg[4], vreg[4];
+    auto fetch = [&](int j0) {
+        const int j = j0 + ld_row;
+        const bool ok = j < klen;
+        const float* kp = kb + (long)(ok ? j : 0) * a.q_st + ld_c;
+        const float* vp = vb + (long)(ok ? j : 0) * a.q_st + ld_c;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kreg[c] = ok ? *reinterpret_cast<const f32x4*>(kp + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vreg[c] = ok ? *reinterpret_cast<const f32x4*>(vp + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ks[ld_row * K_LD + ld_c + c * 4 + e] = kreg[c][e];
+            *reinterpret_cast<f32x4*>(&Vs[ld_row * V_LD + ld_c + c * 4]) = vreg[c];
+        }
+    };
+    // G^T block b of this wave's window -> ring slot b % 3:  G^T[row][c] = sum_d P[rb0 + 32 b + row][d] * scale (q + v)[i0w + c][d].
+    // The rows of P of the NEXT key tile's two blocks are requested right after this tile's barrier (with its K / V rows) and held in
+    // registers across the tile: with one wave per SIMD (the ring's LDS) nothing else would hide their L2 round trip.
+    auto p_load = [&](int b, float (&dst)[32]) {
+        const int r = min(max(rb0 + 32 * b + lr, 0), a.P - 1);  // rows outside P only meet masked keys / absent queries
+        const float* pr = pb + (long)r * a.pp_st;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(pr + s4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[s4 * 4 + e] = t[e];
+        }
+    };
+    auto g_block = [&](int b, const float (&preg)[32]) {
+        f32x16 g;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) g[rr] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) g = __builtin_amdgcn_mfma_f32_32x32x2f32(preg[s], qvreg[s], g, 0, 0, 0);
+        float* gs = Gw + (b % 3) * (32 * G_LD) + lr;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) gs[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * G_LD] = g[rr];
+    };
+    float pn0[32], pn1[32];
+    if (klen > 0) {
+        fetch(0);
+        p_load(1, pn0);
+        p_load(2, pn1);
+    }
+
+    for (int j0 = 0, n = 0; j0 < klen; j0 += KT, ++n) {
+        stage();
+        if (n == 0) {
+            float p0[32];
+            p_load(0, p0);
+            g_block(0, p0);
+        }
+        g_block(2 * n + 1, pn0);
+        g_block(2 * n + 2, pn1);
+        __syncthreads();  // K / V tile staged by all waves; this wave's G^T blocks written by all of its lanes
+        if (j0 + KT < klen) {
+            fetch(j0 + KT);
+            p_load(2 * n + 3, pn0);
+            p_load(2 * n + 4, pn1);
+        }
+
+        // ---- S^T = K (q + u)^T  (2 sub-tiles of 32 keys) + the diagonal band of G^T
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+            const float* kr = &Ks[(t * 32 + lr) * K_LD + 32 * lh];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[s], qreg[s], st[t], 0, 0, 0);
+            // key jj = row(r) of sub-tile t, query c = lr: window row 31 + 64 n + 32 t + jj - c = block 2n + t (jj <= c) or 2n + t + 1, row (31 + jj - c) & 31
+            const float* gA = Gw + ((2 * n + t) % 3) * (32 * G_LD) + lr;
+            const float* gB = Gw + ((2 * n + t + 1) % 3) * (32 * G_LD) + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int dlt = 31 + jj - lr;
+                st[t][r] += (dlt >= 32 ? gB : gA)[(dlt & 31) * G_LD];
+            }
+        }
+
+        // ---- mask + online softmax (lane owns query qi; registers hold keys row(r) + 4*lh of each sub-tile)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float sv = j < klen ? st[t][r] : -INFINITY;
+                st[t][r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        float alpha = 1.f;
+        if (m_new > -INFINITY) alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = (m_new > -INFINITY) ? __expf(st[t][r] - m_new) : 0.f;
+                st[t][r] = pv;
+                ls += pv;
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T : MFMA step (t,r) contracts keys t*32 + row(r) (+4 for the upper half-wave)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float* vr = &Vs[key * V_LD + lr];
+                ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[t][r], ot[0], 0, 0, 0);
+                ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[t][r], ot[1], 0, 0, 0);
+            }
+        __syncthreads();  // the tile (and ring slots 2n, 2n + 1: overwritten as 2n + 3, 2n + 4) are free again
+    }
+
+    // ---- finalise: both half-waves hold partial sums of the same query
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.T) {
+        float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t = {ot[d][g * 4 + 0] * inv, ot[d][g * 4 + 1] * inv, ot[d][g * 4 + 2] * inv, ot[d][g * 4 + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + d * 32 + 8 * g + 4 * lh) = t;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Decode attention: one query row per (row, head), KV cache [row][head][pos][64] streamed once.
 // 4 waves split the context; inside a wave 16 lanes x float4 cover one key row (4 keys per wave-iteration,
 // 1 KiB contiguous per load instruction).  Scores go through LDS (two-pass softmax), then V is streamed.
@@ -542,6 +757,24 @@ extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(flash_attn_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     return cbx_check_launch("flash_attn");
+}
+
+extern "C" int cbx_flash_relpos_f32(const float* qu, const float* qv, const float* k, const float* v, const float* pp, float* o,
+                                    const int* key_lens, int nz1, int n_heads, int T, long q_sb, long q_st, long pp_st, long o_sb, long o_st,
+                                    float scale, void* stream) {
+    CBX_REQUIRE(qu && qv && k && v && pp && o, "flash_relpos: null operand");
+    CBX_REQUIRE(T > 0 && nz1 > 0 && n_heads > 0, "flash_relpos: bad shape");
+    CBX_REQUIRE((q_st | q_sb | pp_st | o_st | o_sb) % 4 == 0, "flash_relpos: strides must be multiples of 4");
+    CBX_REQUIRE((((uintptr_t)qu | (uintptr_t)qv | (uintptr_t)k | (uintptr_t)v | (uintptr_t)pp | (uintptr_t)o) & 15) == 0, "flash_relpos: 16-byte alignment");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_relpos_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RELPOS_LDS);
+        if (e != hipSuccess) return cbx_set_error((int)e, "flash_relpos: cannot reserve %d B of LDS", RELPOS_LDS);
+        configured = true;
+    }
+    FlashRelArgs a{qu, qv, k, v, pp, o, key_lens, T, 2 * T - 1, q_sb, q_st, pp_st, o_sb, o_st, scale};
+    hipLaunchKernelGGL(flash_relpos_f32_kernel, dim3((T + 127) / 128, n_heads, nz1), dim3(256), RELPOS_LDS, (hipStream_t)stream, a);
+    return cbx_check_launch("flash_relpos");
 }
 
 extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float* o, const int* ctx_lens,

@@ -438,6 +438,19 @@ def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
     return out
 
 
+def flash_relpos(q4, pp, out, scale, key_lens=None):
+    """Conformer rel-pos attention without materialised scores.  q4 (Z,T,4,H,64): the fused [q + u | q + v | k | v] projection (any batch /
+    token strides, unit inner strides); pp (2T-1, H*64) = linear_pos(pos_emb); out (Z,T,H,64) view."""
+    Z, T, four, H, D = q4.shape
+    assert four == 4 and D == 64 and q4.stride(4) == 1 and q4.stride(3) == 64 and q4.stride(2) == H * 64
+    assert pp.shape[0] == 2 * T - 1 and pp.stride(1) == 1 and out.stride(3) == 1 and out.stride(2) == 64
+    args = (_p(q4[:, :, 0]), _p(q4[:, :, 1]), _p(q4[:, :, 2]), _p(q4[:, :, 3]), _p(pp), _p(out), _p(key_lens), Z, H, T,
+            q4.stride(0), q4.stride(1), pp.stride(0), out.stride(0), out.stride(1), scale)
+    _timed("flash_relpos_f32", 6.0 * Z * H * T * T * 64, 4.0 * Z * H * 64 * 5 * T + 4.0 * H * 64 * (2 * T - 1),
+           lambda: check(lib.cbx_flash_relpos_f32(*args, _stream()), "cbx_flash_relpos_f32"))
+    return out
+
+
 def decode_attn(q, kc, vc, out, ctx_lens, scale):
     """q/out (rows, H*64) views; kc/vc (rows, H, max_pos, 64) contiguous caches; ctx_lens int32 (rows,)."""
     rows, H = kc.shape[0], kc.shape[1]

@@ -144,13 +144,15 @@ class FlowEngine:
         pp = ws["pp"][:P]
         ops.linear(pe, lw["wpos"], pp)
         q5 = q4.view(B, T, 4, 8, 64)
-        Tp, Pp = ws["Tp"], ws["Pp"]
-        ac, bd, pr = ws["ac"], ws["bd"], ws["pr"]
-        ops.bmm(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3), ac[..., :T])
-        ops.bmm(q5[:, :, 1].permute(0, 2, 1, 3), pp.view(1, P, 8, 64).permute(0, 2, 1, 3).expand(B, 8, P, 64), bd[..., :P])
-        ops.softmax_relpos(ac[..., :T], bd, pr, 0.125, key_lens=lens)
         att = ws["att"][:M]
-        ops.bmm(pr[..., :T], q5[:, :, 3].permute(0, 2, 1, 3), att.view(B, T, 8, 64).permute(0, 2, 1, 3), nn=True)
+        if ws.get("ac") is None:  # flash form: no (T, T) / (T, 2T-1) score tensors (cbx_flash_relpos_f32)
+            ops.flash_relpos(q5, pp, att.view(B, T, 8, 64), 0.125, key_lens=lens)
+        else:
+            ac, bd, pr = ws["ac"], ws["bd"], ws["pr"]
+            ops.bmm(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3), ac[..., :T])
+            ops.bmm(q5[:, :, 1].permute(0, 2, 1, 3), pp.view(1, P, 8, 64).permute(0, 2, 1, 3).expand(B, 8, P, 64), bd[..., :P])
+            ops.softmax_relpos(ac[..., :T], bd, pr, 0.125, key_lens=lens)
+            ops.bmm(pr[..., :T], q5[:, :, 3].permute(0, 2, 1, 3), att.view(B, T, 8, 64).permute(0, 2, 1, 3), nn=True)
         ops.linear(att, lw["wo"], x, bias=lw["bo"], residual=x)
         ops.layernorm(x, lw["ln_ff"][0], lw["ln_ff"][1], h, 1e-12)
         f = ws["ff"][:M]
@@ -161,24 +163,33 @@ class FlowEngine:
     # larger batch is walked in row groups (rows are independent).  60 s of audio = 1.15 GB per utterance: of 288 GB, not a capacity
     # problem, but a bound keeps one long VC batch from taking the allocator's whole pool.
     ENC_SCORE_BYTES = int(float(os.environ.get("CBX_ENC_SCORE_GB", "32")) * 2 ** 30)
+    # CBX_ENC_FLASH: "1" = the encoder's rel-pos attention always runs in the flash form (cbx_flash_relpos_f32: no score tensors, memory O(T));
+    # "0" = always materialised (the measured path; a batch above ENC_SCORE_BYTES is walked in row groups); "auto" (default) = flash for
+    # the calls the materialised form would have to split.  Both are exact fp32 MFMA; they differ by fp32 summation order.
+    ENC_FLASH = os.environ.get("CBX_ENC_FLASH", "auto")
 
     def encode(self, tok, lens):
         """tok (B,N) int64 padded with any valid id, lens (B,) int32 -> mu (B, 2N, 80) channel-last."""
         B, N = tok.shape
         per_row = 8 * 4 * (2 * N) ** 2 * 4
         group = max(1, min(B, self.ENC_SCORE_BYTES // max(per_row, 1)))
+        if self.ENC_FLASH == "1" or (self.ENC_FLASH != "0" and group < B):
+            return self._encode_rows(tok, lens, flash=True)
         if group >= B:
             return self._encode_rows(tok, lens)
         return torch.cat([self._encode_rows(tok[i:i + group], lens[i:i + group]) for i in range(0, B, group)], 0)
 
     @ops.on_device
-    def _encode_rows(self, tok, lens):
+    def _encode_rows(self, tok, lens, flash=False):
         dev, (B, N) = self.dev, tok.shape
         T2 = 2 * N
         f = lambda *s: torch.empty(*s, device=dev)
         Tp, Pp = (T2 + 3) // 4 * 4, (2 * T2 - 1 + 3) // 4 * 4
-        ws = dict(h=f(B * T2, 512), q4=f(B * T2, 2048), pp=f(2 * T2, 512), att=f(B * T2, 512), ff=f(B * T2, 2048),
-                  ac=f(B, 8, T2, Tp), bd=f(B, 8, T2, Pp), pr=f(B, 8, T2, Tp), Tp=Tp, Pp=Pp)
+        ws = dict(h=f(B * T2, 512), q4=f(B * T2, 2048), pp=f(2 * T2, 512), att=f(B * T2, 512), ff=f(B * T2, 2048), Tp=Tp, Pp=Pp)
+        if flash:
+            ws.update(ac=None, bd=None, pr=None)
+        else:
+            ws.update(ac=f(B, 8, T2, Tp), bd=f(B, 8, T2, Pp), pr=f(B, 8, T2, Tp))
         ids = tok.reshape(-1).clone()
         pad = (torch.arange(N, device=dev)[None, :] >= lens[:, None]).reshape(-1)
         ids[pad] = -1  # `input_embedding(token) * mask` (flow.py:161-166): padded rows are zero vectors
@@ -199,9 +210,10 @@ class FlowEngine:
         ops.conv1d(y1, self.pl2[0], x2, taps=3, cin=512, bias=self.pl2[1], pad_left=2, residual=x3)
         x = x2.view(B * N, 512)
         pe = self._rel_pos_table(N, dev)
-        wsN = dict(ws, ac=ws["ac"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4),
-                   bd=ws["bd"].view(-1)[: B * 8 * N * ((2 * N - 1 + 3) // 4 * 4)].view(B, 8, N, (2 * N - 1 + 3) // 4 * 4),
-                   pr=ws["pr"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4))
+        wsN = ws if flash else dict(
+            ws, ac=ws["ac"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4),
+            bd=ws["bd"].view(-1)[: B * 8 * N * ((2 * N - 1 + 3) // 4 * 4)].view(B, 8, N, (2 * N - 1 + 3) // 4 * 4),
+            pr=ws["pr"].view(-1)[: B * 8 * N * ((N + 3) // 4 * 4)].view(B, 8, N, (N + 3) // 4 * 4))
         for lw in self.enc:
             self._conformer(lw, x, B, N, pe, lens, wsN)
         # Upsample1D (upsample_encoder.py:59-63): nearest x2, left-pad 4, conv k5 -- fused in the A-operand address map

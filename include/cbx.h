@@ -291,6 +291,16 @@ int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int
                            int Tq, int Tk, long ld_ac, long ld_bd, long ld_p, long zs_ac, long zs_bd, long zs_p,
                            float scale, void* stream);
 
+/* The same attention WITHOUT materialised scores (flash form, exact fp32 MFMA; written after the GPU budget of round 3 was spent: verified on
+ * the SIMT emulator against the materialised path, not yet timed):
+ *   o[z][i][h] = sum_j softmax_j( scale*(qu[z][i][h] . k[z][j][h] + qv[z][i][h] . pp[T-1-i+j][h]) ) v[z][j][h],  keys j >= key_lens[z] masked.
+ * qu = q + pos_bias_u, qv = q + pos_bias_v, k, v: [z][token][head][64] views that share one batch stride q_sb and token stride q_st (the
+ * fused q | q | k | v projection); pp = linear_pos(pos_emb): (2T-1) rows of n_heads*64, row stride pp_st; o: [z][token][head][64].
+ * Memory O(T) instead of 16 T^2 floats per head; the position term costs as many MFMAs as q k^T (each 32-row block of pp (q+v)^T serves
+ * two key blocks).  Replaces RelPositionMultiHeadedAttention.forward (transformer/attention.py:249-330) for long utterances (60 s VC). */
+int cbx_flash_relpos_f32(const float* qu, const float* qv, const float* k, const float* v, const float* pp, float* o, const int* key_lens,
+                         int nz1, int n_heads, int T, long q_sb, long q_st, long pp_st, long o_sb, long o_st, float scale, void* stream);
+
 /* ---- elementwise / glue ---- */
 /* y[r][c] = act(x[r][c]) (per-column param for snake), 2-D strided: the activations that cannot ride a GEMM / LayerNorm epilogue
  * (Mish of the ResNet time MLPs, matcha/decoder.py:49,58; Snake at a ResBlock entry, hifigan.py:34-60,146-150). */

@@ -23,7 +23,11 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             ("v2", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)), ("v2", dict(od_tc=4, d_ks2=1, d_nw2=16, o_nw2=16)),
             # software-pipelined decode attention (cbx_set_decode_attn_pipeline): alone, with 8 rows per step, and with the tile variants
             ("v2", dict(od_tc=4, d_ks2=1, d_nw2=8, deep=1)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, deep=1)),
-            ("v2", dict(da_pipe=1)), ("v2", dict(da_pipe=1, da_u=8)), ("v2", dict(prefill_prec=6)), ("v2", dict(da_pipe=2)), ("v2", dict(da_pipe=3)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16))]
+            ("v2", dict(da_pipe=1)), ("v2", dict(da_pipe=1, da_u=8)), ("v2", dict(prefill_prec=6)), ("v2", dict(da_pipe=2)), ("v2", dict(da_pipe=3)), ("v2", dict(da_pipe=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16)),
+            # last session of round 3 (no GPU): speculative first K / V step of the decode attention (da_pipe bit 2), epilogue operands of every
+            # GEMV requested with its first weight batch (pre_epi), and both with the pipelined stream / on the reordered geometry
+            ("v2", dict(da_pipe=4)), ("v2", dict(da_pipe=5)), ("v2", dict(da_pipe=7)), ("v2", dict(pre_epi=1)), ("v2", dict(da_pipe=5, pre_epi=1)),
+            ("v2", dict(da_pipe=5, pre_epi=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:
@@ -32,6 +36,8 @@ for mode, tune in VARIANTS:
     tune = dict(tune)
     da_u, da_pipe = tune.pop("da_u", 4), tune.pop("da_pipe", 0)
     ops.lib.cbx_set_gemv_deep_batches(tune.pop("deep", 0))
+    pre_epi = tune.pop("pre_epi", 0)
+    ops.lib.cbx_set_gemv_epilogue_prefetch(pre_epi)
     ops.lib.cbx_set_decode_attn_unroll(da_u)
     ops.lib.cbx_set_decode_attn_pipeline(da_pipe)
     eng.tune.update(tune)
@@ -44,7 +50,7 @@ for mode, tune in VARIANTS:
         toks = eng.generate(synth.t3_cond(), texts, **kw)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    key = f"{mode} {tune} da_u={da_u} da_pipe={da_pipe}"
+    key = f"{mode} {tune} da_u={da_u} da_pipe={da_pipe} pre_epi={pre_epi}"
     res[key] = [t.tolist() for t in toks]
     print(f"{key:50s} T3 stage {min(ts) * 1e3:7.1f} ms  ({min(ts) / (N - 1) * 1e3:.3f} ms/token incl. prefill)", flush=True)
     del eng

@@ -280,3 +280,76 @@ def test_gemv_epilogue_prefetch_equals_plain(dev, name, args, monkeypatch):
     finally:
         ops.lib.cbx_set_gemv_epilogue_prefetch(0)
     assert n[0] >= 1
+
+
+@pytest.mark.parametrize("B,T,H,lens", [(2, 150, 2, (150, 70)), (1, 64, 8, None), (3, 33, 1, (33, 1, 0)), (1, 300, 2, (257,))])
+def test_flash_relpos_equals_materialised_scores(dev, B, T, H, lens):
+    """cbx_flash_relpos_f32 (conformer rel-pos attention without the (T, T) / (T, 2T-1) score tensors) against fp64 torch and against the
+    materialised path it replaces (bmm, bmm, softmax_relpos, bmm): ragged key lengths incl. an empty row, T across query-tile (128), key-tile
+    (64) and 32-row position-block boundaries."""
+    from chatterbox_amd import ops
+    q4 = _r((B, T, 4, H, 64), 1, 0.5)
+    pp = _r((2 * T - 1, H * 64), 2, 0.5)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32)
+    qu, qv, k, v = (q4[:, :, i].permute(0, 2, 1, 3).double() for i in range(4))  # (B, H, T, 64)
+    p = pp.view(2 * T - 1, H, 64).permute(1, 0, 2).double()                     # (H, 2T-1, 64)
+    ac = qu @ k.transpose(-1, -2)
+    bd_full = qv @ p.transpose(-1, -2)[None]                                     # (B, H, T, 2T-1)
+    idx = (T - 1 - torch.arange(T)[:, None] + torch.arange(T)[None, :])          # [i][j] -> T-1-i+j
+    bd = torch.gather(bd_full, 3, idx.expand(B, H, T, T))
+    sc = (ac + bd) * 0.125
+    if kl is not None:
+        sc = sc.masked_fill(torch.arange(T)[None, None, None, :] >= kl[:, None, None, None], float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(sc, -1))  # an empty row: all keys masked -> zeros
+    ref = (pr @ v).permute(0, 2, 1, 3)                                           # (B, T, H, 64)
+
+    q4d, ppd, kld = q4.to(dev), pp.to(dev), None if kl is None else kl.to(dev)
+    out = torch.full((B, T, H, 64), float("nan"), device=dev)
+    ops.flash_relpos(q4d, ppd, out, 0.125, key_lens=kld)
+    _close(out, ref, 2e-5, "flash rel-pos attention vs fp64")
+
+    Tp, Pp = (T + 3) // 4 * 4, (2 * T - 1 + 3) // 4 * 4
+    f = lambda *s: torch.zeros(*s, device=dev)
+    acd, bdd, prd, att = f(B, H, T, Tp), f(B, H, T, Pp), f(B, H, T, Tp), f(B, T, H, 64)
+    ops.bmm(q4d[:, :, 0].permute(0, 2, 1, 3), q4d[:, :, 2].permute(0, 2, 1, 3), acd[..., :T])
+    ops.bmm(q4d[:, :, 1].permute(0, 2, 1, 3), ppd.view(1, 2 * T - 1, H, 64).permute(0, 2, 1, 3).expand(B, H, 2 * T - 1, 64), bdd[..., : 2 * T - 1])
+    ops.softmax_relpos(acd[..., :T], bdd, prd, 0.125, key_lens=kld)
+    ops.bmm(prd[..., :T], q4d[:, :, 3].permute(0, 2, 1, 3), att.permute(0, 2, 1, 3), nn=True)
+    _close(out, att.cpu().double(), 2e-5, "flash rel-pos attention vs the materialised path")
+
+
+def test_encoder_flash_relpos_modes_match_the_materialised_encoder(dev):
+    """FlowEngine.encode through cbx_flash_relpos_f32: by default ("auto") a batch whose rel-pos score tensors would exceed ENC_SCORE_BYTES takes
+    the flash form (instead of being walked in row groups), CBX_ENC_FLASH=1 always does.  Ragged batch of 3 through encoder + CFM: the mel equals
+    the materialised encoder's to rounding and the oracle's at the usual tolerances."""
+    from chatterbox_amd import ops, synth
+    from chatterbox_amd.s3gen import FlowEngine
+    from oracle import ref_torch as O
+    from test_models_gpu import _s3_inputs
+    sd = synth.s3gen_state_dict(0, n_mid=2, n_enc=2, n_up_enc=1)
+    eng = FlowEngine(sd, dev)
+    P, Ns = 10, [14, 9, 3]
+    ref, toks, lens = _s3_inputs(P, Ns)
+    z = synth.randn((3, 80, 2 * (P + max(Ns))), seed=5).transpose(1, 2).contiguous()
+    eng.ENC_FLASH = "0"
+    mel = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
+    calls, real = [0], ops.flash_relpos
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return real(*a, **k)
+
+    ops.flash_relpos = counted
+    try:
+        for mode, cap, want in (("auto", 32 << 30, 0), ("auto", 1, 3), ("1", 32 << 30, 3)):  # 2 + 1 conformer layers in this small model
+            calls[0] = 0
+            eng.ENC_FLASH, eng.ENC_SCORE_BYTES = mode, cap
+            mel2 = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
+            assert calls[0] == want, f"CBX_ENC_FLASH={mode}, cap {cap}: {calls[0]} flash launches"
+            assert (mel - mel2).abs().max() <= 2e-5, f"flash rel-pos encoder ({mode}, cap {cap}): {(mel - mel2).abs().max():.3e}"
+    finally:
+        ops.flash_relpos = real
+    for b, n in enumerate(Ns):
+        om = O.flow_inference(sd, toks[b:b + 1, :n], torch.tensor([n]), ref, z[b:b + 1, : 2 * (P + n)].transpose(1, 2), 3)
+        err = (mel2[b, : 2 * n] - om[0].t()).abs()
+        assert err.mean() <= 1e-4 and err.max() <= 1e-3, f"utt {b}: mel L1 {err.mean():.3e} max {err.max():.3e}"

@@ -19,6 +19,11 @@ for tune in "" "qkv_tc=12" "od_tc=4,d_ks=1,d_nw=8" "qkv_tc=12,od_tc=4,d_ks=1,d_n
         --no-alt-precisions --no-streaming 2> /dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('turbo b1 tune=[$tune] pipe=$pipe', d['value'], d.get('stage_ms_per_step'), d.get('decode_step', {}).get('ms_per_token'))" | tee -a $O/turbo_b1_variants.log
   done
 done
+# GPT-2 decode GEMVs all carry a bias / LayerNorm-fold constants in their epilogue: the epilogue prefetch and the speculative attention step on Turbo, batch 1
+for env in "CBX_GEMV_PRE_EPI=1" "CBX_DA_PIPE=4" "CBX_GEMV_PRE_EPI=1 CBX_DA_PIPE=5"; do
+  env $env timeout 300 python bench.py --workload turbo --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt-precisions --no-streaming 2> /dev/null \
+      | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('turbo b1 [$env]', d['value'], d.get('stage_ms_per_step'), d.get('decode_step', {}).get('ms_per_token'))" | tee -a $O/turbo_b1_variants.log
+done
 # the flash form of the encoder's rel-pos attention (cbx_flash_relpos_f32, emulator-verified): encoder time at the bench shape and at 60 s
 for fl in 0 1; do
   CBX_ENC_FLASH=$fl timeout 300 python - <<'PY' 2>&1 | tail -2 | tee -a $O/enc_flash_ab.log

@@ -76,8 +76,7 @@ _OPS = [
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
-        ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
-        ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2"))]
+        ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res"))]
 
 
 @pytest.mark.parametrize("name,args", _OPS, ids=[f"{n}{list(a)}" for n, a in _OPS])
@@ -515,6 +514,8 @@ def test_frontend_model_bodies_on_the_emulator(emu, name):
     fn(CPU) if name.endswith("oracle") else fn(CPU, np.load(os.path.join(test_frontend_gpu.GOLD, "frontend.npz")))
 
 
+@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="2 min on the emulator (13 real token steps at the real width): CBX_EMU_SLOW=1; the adoption rules "
+                    "alone are covered by tests/test_host_logic.py::test_decode_autotuner_adoption_rules")
 def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     """chatterbox_amd/autotune.py driven on the emulator (in-process, eager steps): every candidate geometry runs one real token step of a 1-layer
     Llama T3 at the real width; the narrow-tile and pipelined-attention candidates reproduce the current geometry's logits BIT FOR BIT, the

@@ -378,6 +378,17 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
     out_packed: out is written in the packed operand layout of the next gemv (ksplit > 1: out (ksplit, rows16, N) partial images);
     half_tile (True = 8, or 12 / 4): output columns per workgroup, w being the pack_gemv_weight image of that tile width;
     xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart)."""
+    p, M, N, K = _gemv_params(x, w, out, N=N, bias=bias, ksplit=ksplit, nw=nw, swiglu=swiglu, act=act, w_packed=w_packed, x_packed=x_packed, M=M, K=K,
+                              norm_w=norm_w, eps=eps, res=res, out_packed=out_packed, xpart=xpart, x_out=x_out, ln_cw=ln_cw, ln_cb=ln_cb,
+                              half_tile=half_tile)
+    _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
+           lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
+    return out
+
+
+def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
+                 norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False):
+    """The cbx_gemv_t descriptor of a gemv() call: (descriptor, M, N, K)."""
     if x_packed:
         assert w_packed and M is not None and K is not None
     else:
@@ -399,9 +410,20 @@ def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE
         p.ldo, p.part_stride = out.stride(1), out.stride(0)
     else:
         p.ldo, p.part_stride = out.stride(0), 0
-    _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
-           lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
-    return out
+    return p, M, N, K
+
+
+def gemv_pair(producer, consumer, sync_ws, spins=0):
+    """Two dependent decode GEMVs in ONE launch (cbx_gemv_pair_f32): `producer` / `consumer` are the (x, w, out, kwargs) of the two gemv()
+    calls it replaces -- a plain packed GEMV (+ residual) and the RMSNorm-folded SwiGLU GEMV that reads its output; sync_ws: 10 int32, zeroed
+    once (arrival counters, re-armed by the kernel; sync_ws[9] is raised if a consumer's wait ever ran out)."""
+    (xa, wa, oa, ka), (xb, wb, ob, kb) = producer, consumer
+    pa, M, Na, Ka = _gemv_params(xa, wa, oa, **ka)
+    pb, _, Nb, Kb = _gemv_params(xb, wb, ob, **kb)
+    assert sync_ws.dtype == torch.int32 and sync_ws.numel() >= 10
+    _timed("gemv_f32", 2.0 * M * (Na * Ka + 2 * Nb * Kb), 4.0 * (Na * Ka + 2 * Nb * Kb),
+           lambda: check(lib.cbx_gemv_pair_f32(ctypes.byref(pa), ctypes.byref(pb), _p(sync_ws), int(spins), _stream()), "cbx_gemv_pair_f32"))
+    return ob
 
 
 def add_rmsnorm(x, part, w, h, eps=1e-5, bias=None, rms=True):

@@ -43,7 +43,7 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -383,13 +383,19 @@ class T3Engine:
         red = {}  # partial images pending on the residual stream
         qtc, odtc = self._tiles()
         qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
+        pair = bool(tn.get("pair_ogu")) and tn["o_nw2"] == 8 and tn["gu_nw"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
         for i, lw in enumerate(self.layers):
             ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk)
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            ops.gemv(att, self._image(lw, "wo", odtc), cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
-            ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
+            o_kw = dict(N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
+            gu_kw = dict(N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
+            if pair:  # o projection and gate | up in ONE launch (cbx_gemv_pair_f32: opt-in, emulator-verified, never run on hardware)
+                ops.gemv_pair((att, self._image(lw, "wo", odtc), cur, o_kw), (cur, lw["wgu_pk"], g, gu_kw), ws["pair_ws"])
+            else:
+                ops.gemv(att, self._image(lw, "wo", odtc), cur, **o_kw)
+                ops.gemv(cur, lw["wgu_pk"], g, **gu_kw)
             if dks > 1:
                 ops.gemv(g, self._image(lw, "wd", odtc), pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ot, **pk)
                 red = dict(xpart=pd, x_out=nxt)
@@ -405,7 +411,7 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not self.tune.get("pair_ogu"):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
@@ -478,7 +484,8 @@ class T3Engine:
                            att_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
-                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
+                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev),
+                           pair_ws=torch.zeros(16, dtype=torch.int32, device=dev)),  # cbx_gemv_pair_f32 arrival counters (zeroed once)
                   graph=None, samp_dev=torch.zeros(B, 8, device=dev))
         self._state[key] = st
         return st

@@ -27,7 +27,9 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             # last session of round 3 (no GPU): speculative first K / V step of the decode attention (da_pipe bit 2), epilogue operands of every
             # GEMV requested with its first weight batch (pre_epi), and both with the pipelined stream / on the reordered geometry
             ("v2", dict(da_pipe=4)), ("v2", dict(da_pipe=5)), ("v2", dict(da_pipe=7)), ("v2", dict(pre_epi=1)), ("v2", dict(da_pipe=5, pre_epi=1)),
-            ("v2", dict(da_pipe=5, pre_epi=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))]
+            ("v2", dict(da_pipe=5, pre_epi=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
+            # o projection + gate | up in ONE launch (cbx_gemv_pair_f32: the consumer's weights are requested before it waits for the producer)
+            ("v2", dict(pair_ogu=1)), ("v2", dict(pair_ogu=1, da_pipe=5, pre_epi=1))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:

@@ -73,6 +73,7 @@ _OPS = [
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
+    ("test_gemv_pair_equals_the_two_launches", (16, 8)), ("test_gemv_pair_equals_the_two_launches", (9, 4)), ("test_gemv_pair_equals_the_two_launches", (2, 12)),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
@@ -470,7 +471,8 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
 
 
-def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu):
+@pytest.mark.parametrize("tune", [dict(), dict(pair_ogu=1)], ids=["default", "pair_ogu"])
+def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
     through the stage-level C entry point (the product default), the device sampler with the reference's processor order -- two utterances of
@@ -484,11 +486,21 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu):
     sd = synth.t3_state_dict(L, 0)
     eng = T3Engine(sd, CPU)
     assert eng.c_step and eng.decode_mode == "v2"
+    eng.tune.update(tune)  # pair_ogu: o projection + gate | up in one launch (cbx_gemv_pair_f32), sequenced from Python
     texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
     conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
     u = synth.rand((2, steps), seed=11)
-    toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
-    assert "cstep" in next(iter(eng._state.values())), "the decode steps went through cbx_t3_decode_step"
+    from chatterbox_amd import ops
+    pairs, real = [0], ops.gemv_pair
+    ops.gemv_pair = lambda *a, **k: (pairs.__setitem__(0, pairs[0] + 1), real(*a, **k))[1]
+    try:
+        toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    finally:
+        ops.gemv_pair = real
+    st = next(iter(eng._state.values()))
+    assert ("cstep" in st) == (not tune), "the default decode steps go through cbx_t3_decode_step"
+    assert pairs[0] == (L * (steps - 1) if tune else 0), f"{pairs[0]} paired launches"
+    assert st["dws"]["pair_ws"].tolist() == [0] * 16
     for b in range(2):
         ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"

@@ -121,7 +121,7 @@ def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
         ops.lib.cbx_set_decode_attn_split_min(512)
 
 
-@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8"])
+@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,od_tc=4,d_ks2=1,d_nw2=8"])
 def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypatch):
     """The round-3 decode geometries (CBX_T3_TUNE: 12-column q/k/v tiles, 4-column o / down tiles, down projection without partial images)
     against the golden tokens of the reference (t3_l2: 2 layers, 64 steps) on the hipGraph + C-step path, and against the default geometry
@@ -143,6 +143,8 @@ def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypa
     kw = dict(max_new_tokens=20, uniforms=u3, ban_eos=True, **SAMP)
     ra, rb = eng.generate(synth.t3_cond(), tt, **kw), T3Engine(sd, dev).generate(synth.t3_cond(), tt, **kw)
     assert [t.tolist() for t in ra] == [t.tolist() for t in rb]
+    if "pair_ogu" in tune:  # cbx_gemv_pair_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
+        assert all(st["dws"]["pair_ws"].cpu().tolist() == [0] * 16 for st in eng._state.values())
 
 
 
@@ -353,3 +355,36 @@ def test_encoder_flash_relpos_modes_match_the_materialised_encoder(dev):
         om = O.flow_inference(sd, toks[b:b + 1, :n], torch.tensor([n]), ref, z[b:b + 1, : 2 * (P + n)].transpose(1, 2), 3)
         err = (mel2[b, : 2 * n] - om[0].t()).abs()
         assert err.mean() <= 1e-4 and err.max() <= 1e-3, f"utt {b}: mel L1 {err.mean():.3e} max {err.max():.3e}"
+
+
+@pytest.mark.parametrize("M,tile", [(16, 8), (16, 0), (9, 4), (2, 12)])
+def test_gemv_pair_equals_the_two_launches(dev, M, tile):
+    """cbx_gemv_pair_f32: the o projection (+ residual, in place, packed) and the RMSNorm-folded gate | up SwiGLU GEMV that reads it, in ONE
+    launch whose consumer workgroups request their weights before they wait for the producers.  Bit-identical to the two cbx_gemv_f32
+    launches (same arithmetic, same order), twice in a row on the same counters (they re-arm themselves), error word untouched."""
+    from chatterbox_amd import ops
+    D, Fh = 1024, 2048
+    att, x0 = _r((M, D), 1), _r((M, D), 2)
+    wo, wg, wu, ln2 = _r((D, D), 3, 1 / math.sqrt(D)), _r((Fh, D), 4, 0.03), _r((Fh, D), 5, 0.03), 1 + 0.1 * _r((D,), 6)
+    pk = dict(w_packed=True, x_packed=True, M=M)
+    attp = ops.pack_gemv_weight(att.to(dev))
+    wop = ops.pack_gemv_weight(wo.to(dev), half_tile=tile)
+    wgu = ops.pack_gemv_weight(torch.cat([wg, wu]).to(dev), swiglu=True)
+    o_kw = lambda cur: dict(N=D, K=D, nw=8, res=cur, out_packed=True, half_tile=tile, **pk)
+    gu_kw = dict(N=Fh, K=D, swiglu=True, nw=8, norm_w=ln2.to(dev), out_packed=True, **pk)
+    rows16 = (M + 15) // 16 * 16
+
+    cur1, g1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev)
+    ops.gemv(attp, wop, cur1, **o_kw(cur1))
+    ops.gemv(cur1, wgu, g1, **gu_kw)
+
+    sync = torch.zeros(16, dtype=torch.int32, device=dev)
+    for rep in range(2):
+        cur2, g2 = ops.pack_gemv_weight(x0.to(dev)), torch.full((rows16, Fh), float("nan"), device=dev)
+        ops.gemv_pair((attp, wop, cur2, o_kw(cur2)), (cur2, wgu, g2, gu_kw), sync)
+        assert torch.equal(cur2.cpu(), cur1.cpu()), f"residual stream differs (launch {rep})"
+        assert torch.equal(_unpack_operand(g2.cpu(), M, Fh), _unpack_operand(g1.cpu(), M, Fh)), f"SwiGLU output differs (launch {rep})"
+        assert sync.cpu().tolist() == [0] * 16, f"counters re-armed, no time-out: {sync.cpu().tolist()}"
+    h = x0 + F.linear(att, wo)
+    hn = h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln2
+    _close(_unpack_operand(g2.cpu(), M, Fh), F.silu(F.linear(hn, wg)) * F.linear(hn, wu), 6e-5, "pair: SwiGLU(RMSNorm(x + att Wo^T))")

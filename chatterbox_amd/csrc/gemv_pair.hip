@@ -1,11 +1,12 @@
 // Two dependent decode GEMVs in one launch (cbx_gemv_pair_f32): the o projection (producer) and the RMSNorm-folded gate | up SwiGLU GEMV
-// (consumer) of a Llama decoder layer inside T3.inference's loop (reference models/t3/t3.py:378-386 via HF LlamaDecoderLayer).
+// (consumer) of a Llama decoder layer inside T3.inference's loop (reference models/t3/t3.py:378-386 via HF LlamaDecoderLayer) -- or a down
+// projection that adds the residual itself and the next layer's RMSNorm-folded q/k/v GEMV.
 //
 // The body below is the body of gemv_kernel (gemv_decode.hip: operand layouts, load batches, MFMA order, fixed-order reduction, epilogue --
 // see the comments there) with the block indices as arguments and a consumer mode; it lives in its own translation unit so that the
 // instruction streams of the established gemv_kernel instantiations -- the measured decode path -- stay exactly what they were.
 // Written after the GPU budget of round 3 was spent: verified on the SIMT emulator (bit-identical to the two launches), never run on
-// hardware, off by default (T3Engine.tune["pair_ogu"] / CBX_T3_TUNE="pair_ogu=1").
+// hardware, off by default (T3Engine.tune["pair_ogu"], ["pair_dq"] / CBX_T3_TUNE="pair_ogu=1,pair_dq=1,od_tc=4,d_ks2=1,d_nw2=8").
 #include <stdlib.h>
 #include "cbx_common.h"
 
@@ -346,7 +347,9 @@ __device__ __forceinline__ void gemv_body(const cbx_gemv_t& p, const unsigned bx
 // requests ALL its weights (128 KiB, one load batch per wave -- they do not depend on x), then waits on the producers' arrival counters, then
 // reads x.  What this removes from the chain of dependent launches: one kernel boundary and the consumer's cold start (launch, first HBM
 // round trip), which now overlap the producer.  Same arithmetic in the same order as the two launches: bit-identical results.
-template <bool HT>
+// CSW: the consumer is the SwiGLU form (gate | up after the o projection); else the plain RMSNorm-folded GEMV (the next layer's q/k/v after a
+// down projection that adds the residual itself).
+template <bool CSW>
 __global__ __launch_bounds__(512) void gemv_pair_kernel(const cbx_gemv_t pa, const cbx_gemv_t pb, const GemvDep dep) {
     if ((int)blockIdx.x < dep.n_prod) {
         gemv_body<1, 8, false, true, true, false, 0, false, false, false>(pa, blockIdx.x, 0, dep);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(512) void gemv_pair_kernel(const cbx_gemv_t pa, con
             __hip_atomic_fetch_add(dep.done + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
-        gemv_body<1, 8, true, true, true, true, 0, false, false, true>(pb, blockIdx.x - dep.n_prod, 0, dep);
+        gemv_body<1, 8, CSW, true, true, true, 0, false, false, true>(pb, blockIdx.x - dep.n_prod, 0, dep);
     }
 }
 
@@ -373,16 +376,20 @@ extern "C" int cbx_gemv_pair_f32(const cbx_gemv_t* pa, const cbx_gemv_t* pb, int
     CBX_REQUIRE(a.w_packed && a.x_packed && b.w_packed && b.x_packed && !a.w_bf16 && !b.w_bf16, "gemv_pair: packed fp32 operands");
     CBX_REQUIRE(a.nw == 8 && b.nw == 8, "gemv_pair: 8 waves per workgroup");
     CBX_REQUIRE(!a.swiglu && !a.norm_w && !a.n_xpart && !a.act && !a.bias, "gemv_pair: the producer is a plain GEMV (+ residual)");
-    CBX_REQUIRE(b.swiglu && b.norm_w && !b.n_xpart && !b.ln_cw && b.half_tile == 0 && b.N % 32 == 0, "gemv_pair: the consumer is the RMSNorm-folded SwiGLU GEMV");
+    CBX_REQUIRE(b.norm_w && !b.n_xpart && !b.ln_cw && !b.act && !b.bias && !b.res, "gemv_pair: the consumer is an RMSNorm-folded GEMV (SwiGLU or plain)");
+    CBX_REQUIRE(!b.swiglu || (b.half_tile == 0 && b.N % 32 == 0), "gemv_pair: the SwiGLU consumer uses 16-column tiles, N %% 32 == 0");
+    CBX_REQUIRE(b.half_tile == 0 || b.half_tile == 1 || b.half_tile == 8 || b.half_tile == 12 || b.half_tile == 4, "gemv_pair: half_tile");
+    CBX_REQUIRE(!b.out_packed || b.N % 32 == 0, "gemv_pair: out_packed needs N %% 32 == 0");
     CBX_REQUIRE(a.half_tile == 0 || a.half_tile == 1 || a.half_tile == 8 || a.half_tile == 12 || a.half_tile == 4, "gemv_pair: half_tile");
     CBX_REQUIRE(a.K % 256 == 0 && b.K % 256 == 0, "gemv_pair: K must be a multiple of 32 * 8 waves");
     CBX_REQUIRE(!a.out_packed || a.N % 32 == 0, "gemv_pair: out_packed needs N %% 32 == 0");
     GemvDep dep;
     dep.done = sync_ws, dep.passed = sync_ws + 8, dep.err = sync_ws + 9;
     dep.n_prod = (a.N + gemv_tile_cols(a.half_tile) - 1) / gemv_tile_cols(a.half_tile);
-    dep.n_cons = (b.N + 15) / 16;
+    dep.n_cons = (b.N + gemv_tile_cols(b.half_tile) - 1) / gemv_tile_cols(b.half_tile);
     dep.spins = spins > 0 ? spins : (1 << 16);
-    hipLaunchKernelGGL(gemv_pair_kernel<true>, dim3(dep.n_prod + dep.n_cons), dim3(512), 0, (hipStream_t)stream, a, b, dep);
+    if (b.swiglu) hipLaunchKernelGGL(gemv_pair_kernel<true>, dim3(dep.n_prod + dep.n_cons), dim3(512), 0, (hipStream_t)stream, a, b, dep);
+    else hipLaunchKernelGGL(gemv_pair_kernel<false>, dim3(dep.n_prod + dep.n_cons), dim3(512), 0, (hipStream_t)stream, a, b, dep);
     return cbx_check_launch("gemv_pair");
 }
 

@@ -43,7 +43,7 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0, pair_dq=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -384,8 +384,13 @@ class T3Engine:
         qtc, odtc = self._tiles()
         qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
         pair = bool(tn.get("pair_ogu")) and tn["o_nw2"] == 8 and tn["gu_nw"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
+        # pair_dq (with d_ks2 = 1, d_nw2 = 8): the down projection of layer i and the q/k/v GEMV of layer i + 1 in ONE launch as well -- then a
+        # layer is 3 launches (attention, o + gate | up, down + next q/k/v) instead of 5
+        pair_dq = bool(tn.get("pair_dq")) and dks == 1 and tn["d_nw2"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
+        q_kw = lambda lw: dict(N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk)
         for i, lw in enumerate(self.layers):
-            ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk)
+            if not (pair_dq and i > 0):  # (else: launched together with the previous layer's down projection)
+                ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, **q_kw(lw), **red)
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
             ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
@@ -400,7 +405,12 @@ class T3Engine:
                 ops.gemv(g, self._image(lw, "wd", odtc), pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ot, **pk)
                 red = dict(xpart=pd, x_out=nxt)
             else:  # the down projection adds the residual itself: no partial images, no fold in the next q/k/v GEMV
-                ops.gemv(g, self._image(lw, "wd", odtc), cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
+                d_kw = dict(N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
+                if pair_dq and i + 1 < len(self.layers):
+                    nl = self.layers[i + 1]
+                    ops.gemv_pair((g, self._image(lw, "wd", odtc), cur, d_kw), (cur, self._image(nl, "wqkv", qtc), qkv, q_kw(nl)), ws["pair_ws"])
+                else:
+                    ops.gemv(g, self._image(lw, "wd", odtc), cur, **d_kw)
         if red:
             red["x_out"] = None
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, **red, **pk)
@@ -411,7 +421,7 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not self.tune.get("pair_ogu"):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not (self.tune.get("pair_ogu") or self.tune.get("pair_dq")):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)

@@ -196,14 +196,16 @@ int cbx_set_gemv_deep_batches(int on);
  * leave 0: the entry point overwrites it with the knob.) */
 int cbx_set_gemv_epilogue_prefetch(int on);
 /* ABI v9 (verified on the SIMT emulator, NEVER run on hardware, off by default): two dependent GEMVs in ONE launch -- `producer`, a plain packed
- * GEMV with its residual epilogue (the o projection of a Llama decoder layer: M <= 16, nw = 8, ksplit = 1, any half_tile), and `consumer`, the
- * RMSNorm-folded SwiGLU GEMV that reads the producer's output (gate | up; nw = 8).  Workgroups [0, n_prod) run the producer; the consumer
+ * GEMV with its residual epilogue (the o projection of a Llama decoder layer, or a down projection that adds the residual itself: M <= 16,
+ * nw = 8, ksplit = 1, any half_tile), and `consumer`, an RMSNorm-folded GEMV that reads the producer's output (gate | up in the SwiGLU form,
+ * or the next layer's q/k/v projection; nw = 8, no partial-sum operand).  Workgroups [0, n_prod) run the producer; the consumer
  * workgroups behind them request all their weights first (these do not depend on x), then wait for the producers' arrival counters, then
  * read x: one kernel boundary and the consumer's cold start overlap the producer.  Same arithmetic in the same order as the two cbx_gemv_f32
  * launches: bit-identical results.  sync_ws: 10 ints, zeroed ONCE by the caller ([0..8) arrivals by producer index % 8, [8] consumers through,
  * re-armed by the last consumer; [9] is set to 1 if a consumer's wait ran out after `spins` polls (0 = 65536: it then proceeds on whatever
  * it finds instead of hanging the GPU -- check the word).  Relies on workgroups being dispatched in index order.
- * Replaces the o_proj -> post_attention_layernorm -> gate_proj / up_proj chain of HF LlamaDecoderLayer inside T3.inference (t3.py:378-386). */
+ * Replaces the o_proj -> post_attention_layernorm -> gate_proj / up_proj chain, resp. down_proj -> input_layernorm -> q/k/v_proj of the next
+ * layer, of HF LlamaDecoderLayer inside T3.inference (t3.py:378-386). */
 int cbx_gemv_pair_f32(const cbx_gemv_t* producer, const cbx_gemv_t* consumer, int* sync_ws, int spins, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */

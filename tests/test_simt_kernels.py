@@ -74,6 +74,7 @@ _OPS = [
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
     ("test_gemv_pair_equals_the_two_launches", (16, 8)), ("test_gemv_pair_equals_the_two_launches", (9, 4)), ("test_gemv_pair_equals_the_two_launches", (2, 12)),
+    ("test_gemv_pair_down_and_next_qkv", (16, 4, 12)), ("test_gemv_pair_down_and_next_qkv", (5, 4, 0)),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
@@ -471,7 +472,9 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
 
 
-@pytest.mark.parametrize("tune", [dict(), dict(pair_ogu=1)], ids=["default", "pair_ogu"])
+@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8), marks=pytest.mark.skipif(
+    os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1; the paired launches themselves run in test_gpu_op_bodies_on_the_emulator"))],
+    ids=["default", "pairs"])
 def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
@@ -482,11 +485,11 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     from chatterbox_amd.t3 import T3Engine
     from oracle import ref_torch as O
     samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
-    L, steps = 1, 3
+    L, steps = (2 if tune else 1), 3
     sd = synth.t3_state_dict(L, 0)
     eng = T3Engine(sd, CPU)
     assert eng.c_step and eng.decode_mode == "v2"
-    eng.tune.update(tune)  # pair_ogu: o projection + gate | up in one launch (cbx_gemv_pair_f32), sequenced from Python
+    eng.tune.update(tune)  # pairs: o + gate | up and down + the next layer's q/k/v in one launch each (cbx_gemv_pair_f32), sequenced from Python
     texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
     conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
     u = synth.rand((2, steps), seed=11)
@@ -499,7 +502,7 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
         ops.gemv_pair = real
     st = next(iter(eng._state.values()))
     assert ("cstep" in st) == (not tune), "the default decode steps go through cbx_t3_decode_step"
-    assert pairs[0] == (L * (steps - 1) if tune else 0), f"{pairs[0]} paired launches"
+    assert pairs[0] == ((2 * L - 1) * (steps - 1) if tune else 0), f"{pairs[0]} paired launches"
     assert st["dws"]["pair_ws"].tolist() == [0] * 16
     for b in range(2):
         ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)

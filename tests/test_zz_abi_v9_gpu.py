@@ -121,7 +121,7 @@ def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
         ops.lib.cbx_set_decode_attn_split_min(512)
 
 
-@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,od_tc=4,d_ks2=1,d_nw2=8"])
+@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,pair_dq=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8"])
 def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypatch):
     """The round-3 decode geometries (CBX_T3_TUNE: 12-column q/k/v tiles, 4-column o / down tiles, down projection without partial images)
     against the golden tokens of the reference (t3_l2: 2 layers, 64 steps) on the hipGraph + C-step path, and against the default geometry
@@ -143,7 +143,7 @@ def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypa
     kw = dict(max_new_tokens=20, uniforms=u3, ban_eos=True, **SAMP)
     ra, rb = eng.generate(synth.t3_cond(), tt, **kw), T3Engine(sd, dev).generate(synth.t3_cond(), tt, **kw)
     assert [t.tolist() for t in ra] == [t.tolist() for t in rb]
-    if "pair_ogu" in tune:  # cbx_gemv_pair_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
+    if "pair_" in tune:  # cbx_gemv_pair_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
         assert all(st["dws"]["pair_ws"].cpu().tolist() == [0] * 16 for st in eng._state.values())
 
 
@@ -388,3 +388,29 @@ def test_gemv_pair_equals_the_two_launches(dev, M, tile):
     h = x0 + F.linear(att, wo)
     hn = h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln2
     _close(_unpack_operand(g2.cpu(), M, Fh), F.silu(F.linear(hn, wg)) * F.linear(hn, wu), 6e-5, "pair: SwiGLU(RMSNorm(x + att Wo^T))")
+
+
+@pytest.mark.parametrize("M,dtile,qtile", [(16, 4, 12), (5, 4, 0), (16, 8, 0)])
+def test_gemv_pair_down_and_next_qkv(dev, M, dtile, qtile):
+    """cbx_gemv_pair_f32 with the plain consumer: the down projection of a layer (K = 4096 over 8 waves = four load batches, residual added in
+    place) and the RMSNorm-folded q/k/v GEMV of the next layer that reads it -- bit-identical to the two launches, counters re-armed."""
+    from chatterbox_amd import ops
+    D, Fh = 1024, 4096
+    g, x0 = _r((M, Fh), 1, 0.3), _r((M, D), 2)
+    wd, wq, ln1 = _r((D, Fh), 3, 1 / math.sqrt(Fh)), _r((3 * D, D), 4, 1 / math.sqrt(D)), 1 + 0.1 * _r((D,), 5)
+    pk = dict(w_packed=True, x_packed=True, M=M)
+    gp = ops.pack_gemv_weight(g.to(dev))
+    wdp, wqp = ops.pack_gemv_weight(wd.to(dev), half_tile=dtile), ops.pack_gemv_weight(wq.to(dev), half_tile=qtile)
+    d_kw = lambda cur: dict(N=D, K=Fh, nw=8, res=cur, out_packed=True, half_tile=dtile, **pk)
+    q_kw = dict(N=3 * D, K=D, nw=8, norm_w=ln1.to(dev), half_tile=qtile, **pk)
+    cur1, q1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(M, 3 * D, device=dev)
+    ops.gemv(gp, wdp, cur1, **d_kw(cur1))
+    ops.gemv(cur1, wqp, q1, **q_kw)
+    sync = torch.zeros(16, dtype=torch.int32, device=dev)
+    for rep in range(2):
+        cur2, q2 = ops.pack_gemv_weight(x0.to(dev)), torch.full((M, 3 * D), float("nan"), device=dev)
+        ops.gemv_pair((gp, wdp, cur2, d_kw(cur2)), (cur2, wqp, q2, q_kw), sync)
+        assert torch.equal(cur2.cpu(), cur1.cpu()) and torch.equal(q2.cpu(), q1.cpu()), f"pair differs from the two launches (launch {rep})"
+        assert sync.cpu().tolist() == [0] * 16, f"counters re-armed, no time-out: {sync.cpu().tolist()}"
+    h = x0 + F.linear(g, wd)
+    _close(q2, F.linear(h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln1, wq), 1e-4, "pair: RMSNorm(x + g Wd^T) Wqkv^T")

@@ -89,6 +89,7 @@ _SIGS = {
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
     "cbx_set_gemv_deep_batches": ([c_int], c_int),
     "cbx_set_gemv_epilogue_prefetch": ([c_int], c_int),
+    "cbx_gemv_chain_f32": ([ctypes.POINTER(GemvParams), c_f, c_int, c_f], c_int),
     "cbx_gemv_pair_f32": ([ctypes.POINTER(GemvParams), ctypes.POINTER(GemvParams), c_f, c_int, c_f], c_int),
     "cbx_pack_gemv_weight_f32": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
     "cbx_pack_gemv_weight_bf16": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),

@@ -175,7 +175,9 @@ __device__ __forceinline__ void gemv_body(const cbx_gemv_t& p, const unsigned bx
             for (int j = 0; j < EIT; ++j) e_cw[j] = p.ln_cw[e_n[j]], e_cb[j] = p.ln_cb[e_n[j]];
         }
     }
-    constexpr int DEPTH = D8 ? 8 : (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
+    // (consumer of the SwiGLU form: two K blocks of gate AND up per batch -- 64 KiB per workgroup before the wait -- keep it at <= 128 VGPRs, i.e. two
+    // workgroups per CU: the same bytes per CU in flight, twice the consumers co-resident with their producers; same block order, same results)
+    constexpr int DEPTH = D8 ? 8 : (DEP && SWIGLU) ? 2 : (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
     // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
@@ -365,7 +367,70 @@ __global__ __launch_bounds__(512) void gemv_pair_kernel(const cbx_gemv_t pa, con
     }
 }
 
+// The chain o projection -> gate | up -> down projection -> (next layer's q/k/v | speech head) of a Llama decoder layer as ONE launch
+// (cbx_gemv_chain_f32): four roles in block-index order, every role but the first in the consumer mode above (its first weight batch is in
+// flight before it waits for the role in front of it), every role but the last signalling its own arrival counters.  One counter set per
+// edge: sync + 16 * edge = done[8], passed.  With attention that is 2 launches per layer instead of 5.
+struct GemvChain {
+    cbx_gemv_t op[4];
+    int first[5];  // first block of role r; first[4] = grid size
+    int* sync;     // 3 edges x 16 ints (zeroed once), sync[63] = error word
+    int spins;
+};
+
+__global__ __launch_bounds__(512) void gemv_chain_kernel(const GemvChain c) {
+    const unsigned b = blockIdx.x;
+    const int r = (b >= (unsigned)c.first[1]) + (b >= (unsigned)c.first[2]) + (b >= (unsigned)c.first[3]);  // uniform
+    const unsigned lb = b - c.first[r];
+    GemvDep dep{};
+    if (r > 0) {
+        dep.done = c.sync + 16 * (r - 1), dep.passed = dep.done + 8, dep.err = c.sync + 63;
+        dep.n_prod = c.first[r] - c.first[r - 1], dep.n_cons = c.first[r + 1] - c.first[r], dep.spins = c.spins;
+    }
+    switch (r) {
+        case 0: gemv_body<1, 8, false, true, true, false, 0, false, false, false>(c.op[0], lb, 0, dep); break;  // o projection (+ residual)
+        case 1: gemv_body<1, 8, true, true, true, true, 0, false, false, true>(c.op[1], lb, 0, dep); break;     // RMSNorm + gate | up + SwiGLU
+        case 2: gemv_body<1, 8, false, true, true, false, 0, false, false, true>(c.op[2], lb, 0, dep); break;   // down projection (+ residual)
+        default: gemv_body<1, 8, false, true, true, true, 0, false, false, true>(c.op[3], lb, 0, dep); break;   // RMSNorm + q/k/v (or the head)
+    }
+    if (r < 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(c.sync + 16 * r + (lb & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spins, void* stream) {
+    CBX_REQUIRE(ops4 && sync_ws, "gemv_chain: null operand");
+    GemvChain c;
+    c.first[0] = 0;
+    for (int r = 0; r < 4; ++r) {
+        cbx_gemv_t& p = c.op[r];
+        p = ops4[r];
+        p.ksplit = 1, p.reserved1 = 0;
+        const bool rms = r == 1 || r == 3;
+        CBX_REQUIRE(p.x && p.W && p.out, "gemv_chain: null operand in role %d", r);
+        CBX_REQUIRE(p.M >= 1 && p.M <= 16 && p.M == ops4[0].M, "gemv_chain: 1..16 rows, the same for all four");
+        CBX_REQUIRE(p.w_packed && p.x_packed && !p.w_bf16 && p.nw == 8 && p.K % 256 == 0, "gemv_chain: role %d needs packed fp32 operands, 8 waves, K %% 256 == 0", r);
+        CBX_REQUIRE(!p.n_xpart && !p.ln_cw && !p.act && !p.bias, "gemv_chain: role %d: no partial-sum operand, LayerNorm form, activation or bias", r);
+        CBX_REQUIRE(rms ? (p.norm_w && !p.res) : !p.norm_w, "gemv_chain: roles 1 and 3 are RMSNorm-folded, roles 0 and 2 plain (+ residual)");
+        CBX_REQUIRE((r == 1) == (p.swiglu != 0), "gemv_chain: role 1 (and only it) is the SwiGLU form");
+        CBX_REQUIRE(p.half_tile == 0 || p.half_tile == 1 || p.half_tile == 8 || p.half_tile == 12 || p.half_tile == 4, "gemv_chain: half_tile");
+        CBX_REQUIRE(!p.swiglu || (p.half_tile == 0 && p.N % 32 == 0), "gemv_chain: the SwiGLU role uses 16-column tiles, N %% 32 == 0");
+        CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv_chain: out_packed needs N %% 32 == 0");
+        const int tc = gemv_tile_cols(p.half_tile);
+        c.first[r + 1] = c.first[r] + (p.N + tc - 1) / tc;
+    }
+    c.sync = sync_ws, c.spins = spins > 0 ? spins : (1 << 16);
+    hipLaunchKernelGGL(gemv_chain_kernel, dim3(c.first[4]), dim3(512), 0, (hipStream_t)stream, c);
+    return cbx_check_launch("gemv_chain");
+}
 
 extern "C" int cbx_gemv_pair_f32(const cbx_gemv_t* pa, const cbx_gemv_t* pb, int* sync_ws, int spins, void* stream) {
     cbx_gemv_t a = *pa, b = *pb;

@@ -413,6 +413,20 @@ def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, 
     return p, M, N, K
 
 
+def gemv_chain(ops4, sync_ws, spins=0):
+    """Four dependent decode GEMVs in ONE launch (cbx_gemv_chain_f32): ops4 = the (x, w, out, kwargs) of the gemv() calls o projection, gate | up,
+    down projection, next q/k/v (or the head); sync_ws: 64 int32, zeroed once (sync_ws[63] is raised if a wait ever ran out)."""
+    assert len(ops4) == 4 and sync_ws.dtype == torch.int32 and sync_ws.numel() >= 64
+    arr = (GemvParams * 4)()
+    fl = 0.0
+    for r, (x, w, out, kw) in enumerate(ops4):
+        p, M, N, K = _gemv_params(x, w, out, **kw)
+        arr[r] = p
+        fl += N * K * (2 if kw.get("swiglu") else 1)
+    _timed("gemv_f32", 2.0 * M * fl, 4.0 * fl, lambda: check(lib.cbx_gemv_chain_f32(arr, _p(sync_ws), int(spins), _stream()), "cbx_gemv_chain_f32"))
+    return ops4[3][2]
+
+
 def gemv_pair(producer, consumer, sync_ws, spins=0):
     """Two dependent decode GEMVs in ONE launch (cbx_gemv_pair_f32): `producer` / `consumer` are the (x, w, out, kwargs) of the two gemv()
     calls it replaces -- a plain packed GEMV (+ residual) and the RMSNorm-folded SwiGLU GEMV that reads its output; sync_ws: 10 int32, zeroed

@@ -43,7 +43,7 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0, pair_dq=0)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0, pair_dq=0, chain=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -388,6 +388,22 @@ class T3Engine:
         # layer is 3 launches (attention, o + gate | up, down + next q/k/v) instead of 5
         pair_dq = bool(tn.get("pair_dq")) and dks == 1 and tn["d_nw2"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
         q_kw = lambda lw: dict(N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk)
+        # chain (same preconditions): o -> gate | up -> down -> next q/k/v (behind the last layer: the head) in ONE launch: 2 launches per layer
+        chain = bool(tn.get("chain")) and dks == 1 and tn["d_nw2"] == 8 and tn["o_nw2"] == 8 and tn["gu_nw"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
+        if chain:
+            ops.gemv(cur, self._image(self.layers[0], "wqkv", qtc), qkv, **q_kw(self.layers[0]))
+            for i, lw in enumerate(self.layers):
+                ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
+                res_kw = dict(nw=8, res=cur, out_packed=True, half_tile=ot, **pk)
+                if i + 1 < len(self.layers):
+                    nl = self.layers[i + 1]
+                    last = (cur, self._image(nl, "wqkv", qtc), qkv, q_kw(nl))
+                else:
+                    last = (cur, self.head_pk, st["logits"], dict(N=self.V, K=self.D, nw=8, norm_w=self.norm, **pk))
+                ops.gemv_chain([(att, self._image(lw, "wo", odtc), cur, dict(N=self.D, K=self.D, **res_kw)),
+                                (cur, lw["wgu_pk"], g, dict(N=self.F, K=self.D, swiglu=True, nw=8, norm_w=lw["ln2"], out_packed=True, **pk)),
+                                (g, self._image(lw, "wd", odtc), cur, dict(N=self.D, K=self.F, **res_kw)), last], ws["pair_ws"])
+            return
         for i, lw in enumerate(self.layers):
             if not (pair_dq and i > 0):  # (else: launched together with the previous layer's down projection)
                 ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, **q_kw(lw), **red)
@@ -421,7 +437,7 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not (self.tune.get("pair_ogu") or self.tune.get("pair_dq")):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not (self.tune.get("pair_ogu") or self.tune.get("pair_dq") or self.tune.get("chain")):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
@@ -495,7 +511,7 @@ class T3Engine:
                            x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
                            g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev),
-                           pair_ws=torch.zeros(16, dtype=torch.int32, device=dev)),  # cbx_gemv_pair_f32 arrival counters (zeroed once)
+                           pair_ws=torch.zeros(64, dtype=torch.int32, device=dev)),  # cbx_gemv_pair_f32 / _chain_f32 arrival counters (zeroed once)
                   graph=None, samp_dev=torch.zeros(B, 8, device=dev))
         self._state[key] = st
         return st

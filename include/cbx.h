@@ -207,6 +207,13 @@ int cbx_set_gemv_epilogue_prefetch(int on);
  * Replaces the o_proj -> post_attention_layernorm -> gate_proj / up_proj chain, resp. down_proj -> input_layernorm -> q/k/v_proj of the next
  * layer, of HF LlamaDecoderLayer inside T3.inference (t3.py:378-386). */
 int cbx_gemv_pair_f32(const cbx_gemv_t* producer, const cbx_gemv_t* consumer, int* sync_ws, int spins, void* stream);
+/* The same mechanism over the whole chain  o_proj (+ residual) -> RMSNorm + gate | up + SwiGLU -> down_proj (+ residual) -> RMSNorm + q/k/v of the
+ * next layer (or, behind the last layer, the speech head)  as ONE launch: ops4[0..3] are the four cbx_gemv_t descriptors in that order (roles 0 and
+ * 2 plain, 1 the SwiGLU form, 3 RMSNorm-folded; all with M <= 16, nw = 8, packed fp32 operands, no partial-sum operand); every role but the first
+ * requests its first weight batch before it waits for the role in front of it.  sync_ws: 64 ints zeroed once (3 edges x 16, [63] = error word as
+ * above).  With cbx_decode_attn_rope_f32 a decoder layer of T3.inference's loop (t3.py:378-386) is 2 launches instead of 5.  Bit-identical to the
+ * four cbx_gemv_f32 launches.  Emulator-verified, never run on hardware, off by default (CBX_T3_TUNE="chain=1,od_tc=4,d_ks2=1,d_nw2=8"). */
+int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spins, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,

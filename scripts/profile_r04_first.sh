@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests/test_zz_abi_v9_gpu.py tests/test_ops_gpu.py t
     -k "abi_v9 or c_level_decode_step or half_tile or decode_attn or transposed_column_range or stream or flow_batched_ragged" > $O/pytest_v9.log 2>&1
 tail -3 $O/pytest_v9.log
 # T3 stage time, B = 8, 250 tokens, 30 layers: index 3 = the shipped default, 6.. = the round-3 variants (scripts/t3_decode_time.py VARIANTS)
-T3_VARIANTS=3,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29 timeout 1000 python scripts/t3_decode_time.py > $O/t3_decode_variants.log 2>&1
+T3_VARIANTS=3,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33 timeout 1200 python scripts/t3_decode_time.py > $O/t3_decode_variants.log 2>&1
 cat $O/t3_decode_variants.log | tail -24
 for tune in "" "qkv_tc=12" "od_tc=4,d_ks=1,d_nw=8" "qkv_tc=12,od_tc=4,d_ks=1,d_nw=16"; do
   for pipe in 0 1; do

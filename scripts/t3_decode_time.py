@@ -32,7 +32,10 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             ("v2", dict(pair_ogu=1)), ("v2", dict(pair_ogu=1, da_pipe=5, pre_epi=1)),
             # ... and down + the next layer's q/k/v as well: 3 launches per layer (on the partial-free geometry; 12-column q/k/v tiles = 256 + 256 workgroups)
             ("v2", dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(pair_ogu=1, pair_dq=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
-            ("v2", dict(pair_ogu=1, pair_dq=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, da_pipe=5))]
+            ("v2", dict(pair_ogu=1, pair_dq=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, da_pipe=5)),
+            # the whole chain o -> gate | up -> down -> next q/k/v (head) as ONE launch (cbx_gemv_chain_f32): attention + 1 launch per layer
+            ("v2", dict(chain=1, od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
+            ("v2", dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, da_pipe=5)), ("v2", dict(chain=1, half_tiles=1, d_ks2=1, d_nw2=8))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:

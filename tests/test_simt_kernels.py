@@ -75,6 +75,7 @@ _OPS = [
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
     ("test_gemv_pair_equals_the_two_launches", (16, 8)), ("test_gemv_pair_equals_the_two_launches", (9, 4)), ("test_gemv_pair_equals_the_two_launches", (2, 12)),
     ("test_gemv_pair_down_and_next_qkv", (16, 4, 12)), ("test_gemv_pair_down_and_next_qkv", (5, 4, 0)),
+    ("test_gemv_chain_equals_the_four_launches", (16, 4, 12)), ("test_gemv_chain_equals_the_four_launches", (3, 8, 0)),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
@@ -472,9 +473,12 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
 
 
-@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8), marks=pytest.mark.skipif(
-    os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1; the paired launches themselves run in test_gpu_op_bodies_on_the_emulator"))],
-    ids=["default", "pairs"])
+_SLOW2 = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1; the paired / chained launches themselves "
+                            "run in test_gpu_op_bodies_on_the_emulator")
+
+
+@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2),
+                                  pytest.param(dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2)], ids=["default", "pairs", "chain"])
 def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
@@ -494,16 +498,18 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
     u = synth.rand((2, steps), seed=11)
     from chatterbox_amd import ops
-    pairs, real = [0], ops.gemv_pair
+    pairs, real, real_c = [0], ops.gemv_pair, ops.gemv_chain
     ops.gemv_pair = lambda *a, **k: (pairs.__setitem__(0, pairs[0] + 1), real(*a, **k))[1]
+    ops.gemv_chain = lambda *a, **k: (pairs.__setitem__(0, pairs[0] + 100), real_c(*a, **k))[1]
     try:
         toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
     finally:
-        ops.gemv_pair = real
+        ops.gemv_pair, ops.gemv_chain = real, real_c
     st = next(iter(eng._state.values()))
     assert ("cstep" in st) == (not tune), "the default decode steps go through cbx_t3_decode_step"
-    assert pairs[0] == ((2 * L - 1) * (steps - 1) if tune else 0), f"{pairs[0]} paired launches"
-    assert st["dws"]["pair_ws"].tolist() == [0] * 16
+    want = 0 if not tune else 100 * L * (steps - 1) if tune.get("chain") else (2 * L - 1) * (steps - 1)
+    assert pairs[0] == want, f"{pairs[0]} paired (x 1) / chained (x 100) launches, expected {want}"
+    assert not st["dws"]["pair_ws"].any()
     for b in range(2):
         ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"

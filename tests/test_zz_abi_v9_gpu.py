@@ -121,7 +121,7 @@ def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
         ops.lib.cbx_set_decode_attn_split_min(512)
 
 
-@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,pair_dq=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8"])
+@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,pair_dq=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8", "chain=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8"])
 def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypatch):
     """The round-3 decode geometries (CBX_T3_TUNE: 12-column q/k/v tiles, 4-column o / down tiles, down projection without partial images)
     against the golden tokens of the reference (t3_l2: 2 layers, 64 steps) on the hipGraph + C-step path, and against the default geometry
@@ -143,8 +143,8 @@ def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypa
     kw = dict(max_new_tokens=20, uniforms=u3, ban_eos=True, **SAMP)
     ra, rb = eng.generate(synth.t3_cond(), tt, **kw), T3Engine(sd, dev).generate(synth.t3_cond(), tt, **kw)
     assert [t.tolist() for t in ra] == [t.tolist() for t in rb]
-    if "pair_" in tune:  # cbx_gemv_pair_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
-        assert all(st["dws"]["pair_ws"].cpu().tolist() == [0] * 16 for st in eng._state.values())
+    if "pair_" in tune or "chain" in tune:  # cbx_gemv_pair_f32 / cbx_gemv_chain_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
+        assert not any(bool(st["dws"]["pair_ws"].any()) for st in eng._state.values())
 
 
 
@@ -414,3 +414,43 @@ def test_gemv_pair_down_and_next_qkv(dev, M, dtile, qtile):
         assert sync.cpu().tolist() == [0] * 16, f"counters re-armed, no time-out: {sync.cpu().tolist()}"
     h = x0 + F.linear(g, wd)
     _close(q2, F.linear(h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln1, wq), 1e-4, "pair: RMSNorm(x + g Wd^T) Wqkv^T")
+
+
+@pytest.mark.parametrize("M,odtile,qtile", [(16, 4, 12), (3, 8, 0), (16, 0, 0)])
+def test_gemv_chain_equals_the_four_launches(dev, M, odtile, qtile):
+    """cbx_gemv_chain_f32: o projection (+ residual) -> RMSNorm + gate | up + SwiGLU -> down projection (+ residual) -> RMSNorm + q/k/v of the next
+    layer in ONE launch of four roles, each waiting on the arrival counters of the one in front of it after its first weight batch is in flight.
+    Bit-identical to the four cbx_gemv_f32 launches, three times in a row on the same counters."""
+    from chatterbox_amd import ops
+    D, Fh = 1024, 2048
+    att, x0 = _r((M, D), 1), _r((M, D), 2)
+    wo, wg, wu = _r((D, D), 3, 1 / math.sqrt(D)), _r((Fh, D), 4, 0.03), _r((Fh, D), 5, 0.03)
+    wd, wq = _r((D, Fh), 6, 1 / math.sqrt(Fh)), _r((3 * D, D), 7, 1 / math.sqrt(D))
+    ln2, ln1 = 1 + 0.1 * _r((D,), 8), 1 + 0.1 * _r((D,), 9)
+    pk = dict(w_packed=True, x_packed=True, M=M)
+    attp = ops.pack_gemv_weight(att.to(dev))
+    wop, wdp = ops.pack_gemv_weight(wo.to(dev), half_tile=odtile), ops.pack_gemv_weight(wd.to(dev), half_tile=odtile)
+    wgu, wqp = ops.pack_gemv_weight(torch.cat([wg, wu]).to(dev), swiglu=True), ops.pack_gemv_weight(wq.to(dev), half_tile=qtile)
+    rows16 = (M + 15) // 16 * 16
+
+    def four(cur, g, q):
+        res_kw = dict(nw=8, res=cur, out_packed=True, half_tile=odtile, **pk)
+        return [(attp, wop, cur, dict(N=D, K=D, **res_kw)),
+                (cur, wgu, g, dict(N=Fh, K=D, swiglu=True, nw=8, norm_w=ln2.to(dev), out_packed=True, **pk)),
+                (g, wdp, cur, dict(N=D, K=Fh, **res_kw)),
+                (cur, wqp, q, dict(N=3 * D, K=D, nw=8, norm_w=ln1.to(dev), half_tile=qtile, **pk))]
+
+    cur1, g1, q1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev), torch.zeros(M, 3 * D, device=dev)
+    for x, w, out, kw in four(cur1, g1, q1):
+        ops.gemv(x, w, out, **kw)
+    sync = torch.zeros(64, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        cur2, g2, q2 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev), torch.full((M, 3 * D), float("nan"), device=dev)
+        ops.gemv_chain(four(cur2, g2, q2), sync)
+        assert torch.equal(cur2.cpu(), cur1.cpu()) and torch.equal(g2.cpu(), g1.cpu()) and torch.equal(q2.cpu(), q1.cpu()), f"chain differs from the four launches (launch {rep})"
+        assert not sync.cpu().any(), f"counters re-armed, no time-out: {sync.cpu().tolist()}"
+    h = x0 + F.linear(att, wo)
+    rms = lambda t, w: t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-5) * w
+    hn = rms(h, ln2)
+    h2 = h + F.linear(F.silu(F.linear(hn, wg)) * F.linear(hn, wu), wd)
+    _close(q2, F.linear(rms(h2, ln1), wq), 2e-4, "chain vs torch")

@@ -413,6 +413,9 @@ def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, 
     return p, M, N, K
 
 
+PAIR_SPINS = int(os.environ.get("CBX_PAIR_SPINS", "0"))  # polls before a consumer of gemv_pair / gemv_chain gives up (0: the library's 65536)
+
+
 def gemv_chain(ops4, sync_ws, spins=0):
     """Four dependent decode GEMVs in ONE launch (cbx_gemv_chain_f32): ops4 = the (x, w, out, kwargs) of the gemv() calls o projection, gate | up,
     down projection, next q/k/v (or the head); sync_ws: 64 int32, zeroed once (sync_ws[63] is raised if a wait ever ran out)."""
@@ -423,7 +426,7 @@ def gemv_chain(ops4, sync_ws, spins=0):
         p, M, N, K = _gemv_params(x, w, out, **kw)
         arr[r] = p
         fl += N * K * (2 if kw.get("swiglu") else 1)
-    _timed("gemv_f32", 2.0 * M * fl, 4.0 * fl, lambda: check(lib.cbx_gemv_chain_f32(arr, _p(sync_ws), int(spins), _stream()), "cbx_gemv_chain_f32"))
+    _timed("gemv_f32", 2.0 * M * fl, 4.0 * fl, lambda: check(lib.cbx_gemv_chain_f32(arr, _p(sync_ws), int(spins or PAIR_SPINS), _stream()), "cbx_gemv_chain_f32"))
     return ops4[3][2]
 
 
@@ -436,7 +439,7 @@ def gemv_pair(producer, consumer, sync_ws, spins=0):
     pb, _, Nb, Kb = _gemv_params(xb, wb, ob, **kb)
     assert sync_ws.dtype == torch.int32 and sync_ws.numel() >= 10
     _timed("gemv_f32", 2.0 * M * (Na * Ka + 2 * Nb * Kb), 4.0 * (Na * Ka + 2 * Nb * Kb),
-           lambda: check(lib.cbx_gemv_pair_f32(ctypes.byref(pa), ctypes.byref(pb), _p(sync_ws), int(spins), _stream()), "cbx_gemv_pair_f32"))
+           lambda: check(lib.cbx_gemv_pair_f32(ctypes.byref(pa), ctypes.byref(pb), _p(sync_ws), int(spins or PAIR_SPINS), _stream()), "cbx_gemv_pair_f32"))
     return ob
 
 

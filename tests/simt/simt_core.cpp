@@ -1,5 +1,6 @@
 // SIMT emulator core (test infrastructure, see simt_emu.h): fibers, scheduler, barriers, wave exchange buffers.
 #include <sys/mman.h>
+#include <string.h>
 
 #include <deque>
 #include <vector>
@@ -290,8 +291,11 @@ int launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>&
     const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
     static std::vector<unsigned long> border;
     border.resize(nblocks);
-    for (unsigned long b = 0; b < nblocks; ++b) border[b] = g_sched_mode == 1 ? nblocks - 1 - b : b;
-    if (g_sched_mode == 2)
+    // CBX_EMU_WG_ORDER=dispatch keeps the workgroups in index order under any lane schedule: the hardware dispatches in index order, and the
+    // producer / consumer launches (gemv_pair.hip) are the one place that relies on it
+    static const bool wg_in_order = getenv("CBX_EMU_WG_ORDER") && !strcmp(getenv("CBX_EMU_WG_ORDER"), "dispatch");
+    for (unsigned long b = 0; b < nblocks; ++b) border[b] = (g_sched_mode == 1 && !wg_in_order) ? nblocks - 1 - b : b;
+    if (g_sched_mode == 2 && !wg_in_order)
         for (unsigned long b = nblocks - 1; b > 0; --b) {
             g_sched_rng = g_sched_rng * 6364136223846793005ull + 1442695040888963407ull;
             std::swap(border[b], border[(unsigned long)((g_sched_rng >> 33) % (b + 1))]);

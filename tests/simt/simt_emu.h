@@ -271,7 +271,7 @@ static inline simt_u32x2 simt_permlane32_swap(unsigned vdst, unsigned src, bool,
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) simt::yield()
+#define __builtin_amdgcn_s_sleep(x) (simt::note_progress(), simt::yield()) /* a polling lane is not stuck: bounded spins end by themselves */
 #define __builtin_amdgcn_s_nop(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() simt::block_sync()

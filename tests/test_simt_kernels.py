@@ -471,6 +471,12 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc == 0, out
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5", "CBX_EMU_DROP_BARRIER": "0"}, "test_gemv_decode or test_linear")  # the K-slice reduction through LDS
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
+    # the producer / consumer launches under a random lane schedule (their workgroups in dispatch order, which is what they rely on) ...
+    rc, out = _rerun({"CBX_EMU_SCHED": "random:7", "CBX_EMU_WG_ORDER": "dispatch"}, "gemv_chain_equals_the_four_launches")
+    assert rc == 0, out
+    # ... and that very reliance seen: with the workgroups reversed every consumer's bounded wait runs out and the error word is raised
+    rc, out = _rerun({"CBX_EMU_SCHED": "reverse", "CBX_PAIR_SPINS": "4"}, "gemv_pair_equals_the_two_launches")
+    assert rc != 0, "consumers in front of their producers went unnoticed\n" + out
 
 
 _SLOW2 = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1; the paired / chained launches themselves "

@@ -35,6 +35,12 @@ ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe
                  dict(da_pipe=1, da_u=8), dict(da_u=8))
 # process-wide knob of every GEMV launch (cbx_set_gemv_epilogue_prefetch), tried on top of the best geometry so far
 EPI_VARIANTS = (dict(pre_epi=1),)
+# the dependent GEMVs of a layer as ONE launch (cbx_gemv_chain_f32, gemv_pair.hip) on the partial-free geometry.  These launches synchronise
+# workgroups through arrival counters, so a candidate counts only if the WHOLE measured run (every replay: final logits and every sampled token)
+# ends bit-identical to its twin -- the same geometry as separate launches -- with the error word of the counters clean.  Relative to the
+# built-in geometry they sum the down projection in another order, i.e. they are `best_any` material: adopted only through validate().
+CHAIN_VARIANTS = (dict(chain=1, od_tc=4, d_ks2=1, d_nw2=8), dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))
+CHAIN_KEYS = ("chain", "pair_ogu", "pair_dq")
 LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)  # library defaults
 
 
@@ -51,18 +57,20 @@ def split_variant(v):
 
 
 def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, use_graph=True, tiles=TILE_VARIANTS, attn=ATTN_VARIANTS,
-                epi=EPI_VARIANTS, log=None):
+                epi=EPI_VARIANTS, chain=CHAIN_VARIANTS, log=None):
     """Time every candidate on `eng` (in this process) and return the report; `eng` is left on the geometry it came with.
     report["best"]: the fastest candidate whose logits are bit-identical to the current geometry's ({} = keep it); report["best_any"]: the
     fastest candidate overall, reordering ones included (== best unless a reordering candidate is faster still by min_gain) -- for callers
     that validate it on their own workload (T3Engine.autotune(validate=...))."""
     import torch
     base_tune, base_knobs = dict(eng.tune), dict(getattr(eng, "lib_knobs", None) or env_knobs())
-    rows, seen = [], {}
+    rows, seen, final = [], {}, {}
 
     def run(v):
         eng.apply_variant(dict(base_tune, **split_variant(v)[0]), dict(base_knobs, **split_variant(v)[1]))
-        return eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
+        r = eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
+        final[tuple(sorted(v.items()))] = getattr(eng, "last_measure", None)
+        return r
 
     ms0, ref = run({})
     scale = max(1.0, float(ref.abs().max()))
@@ -83,7 +91,12 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         same = bool(torch.equal(lg, ref))
         diff = float((lg - ref).abs().max())
         ok_num = same or diff <= 2e-4 * scale  # another fp32 summation order of the same products
-        rows.append(dict(variant=v, ms_per_token=round(ms, 5), identical=same, reorders=not same, max_abs_diff=diff, valid=ok_num))
+        row = dict(variant=v, ms_per_token=round(ms, 5), identical=same, reorders=not same, max_abs_diff=diff, valid=ok_num)
+        if any(v.get(k) for k in CHAIN_KEYS):  # the whole run against the twin (same geometry, separate launches)
+            a, b = final.get(key), final.get(tuple(sorted((k, x) for k, x in v.items() if k not in CHAIN_KEYS)))
+            row["twin_identical"] = bool(a and b and a["sync_clean"] and torch.equal(a["final_logits"], b["final_logits"]) and torch.equal(a["out_tokens"], b["out_tokens"]))
+            row["valid"] = row["valid"] and row["twin_identical"]
+        rows.append(row)
         if log:
             log(f"autotune: {v} {ms:.4f} ms / token, identical={same} (max |d logits| {diff:.2e})")
 
@@ -99,6 +112,10 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
     for base in (pick(True), pick(False)):  # the GEMV epilogue prefetch on top of whatever leads now
         for a in epi:
             consider(dict(base, **a))
+    knobs_now = {k: x for k, x in pick(False).items() if k in LIB_KNOBS}  # the chained launches: on the attention / epilogue knobs that lead now
+    for c in chain:
+        consider(dict(knobs_now, **{k: x for k, x in c.items() if k not in CHAIN_KEYS}))  # the twin first (measured like any other candidate)
+        consider(dict(knobs_now, **c))
 
     def confirm(v):  # back to back against the current geometry (`reps` more rounds each): the pool's boxes drift by a few per cent over seconds
         if not v:

@@ -247,12 +247,17 @@ class T3Engine:
                     step()
                 ms = 1e3 * (time.perf_counter() - t0)
             best = min(best, ms / steps)
+        if cuda:
+            torch.cuda.synchronize()
+        # the state the whole run ended in (a pure function of the seed and of the arithmetic): two geometries that claim the same arithmetic --
+        # a chained launch and its separate launches -- must agree on it bit for bit; the error word of the producer / consumer launches must be 0
+        self.last_measure = dict(final_logits=st["logits"].clone(), out_tokens=st["out_tokens"].clone(), sync_clean=not bool(st["dws"]["pair_ws"].any()))
         st["graph"] = None
         st.pop("cstep", None)
         return best, logits
 
     def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None,
-                 epi=None, validate=None):
+                 epi=None, chain=None, validate=None):
         """Measure the decode-step geometries (autotune.py) and adopt the fastest one whose logits are bit-identical to the current
         geometry's.  in_child: the candidates run in a child process on synthetic weights of this shape, so a faulting candidate cannot take
         the serving process down; its failure leaves the geometry unchanged.  validate: a callable run on THIS engine after the fastest
@@ -270,7 +275,7 @@ class T3Engine:
         else:
             rep = at.tune_decode(self, B, ctx, steps, reps, min_gain, allow_reorder, use_graph=self.dev.type == "cuda", log=log,
                                  tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn,
-                                 epi=at.EPI_VARIANTS if epi is None else epi)
+                                 epi=at.EPI_VARIANTS if epi is None else epi, chain=at.CHAIN_VARIANTS if chain is None else chain)
 
         def adopt(v):
             t, k = at.split_variant(v)

@@ -581,7 +581,7 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
                    for b in range(2))
 
     try:
-        rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False, tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), reorder), attn=(dict(da_pipe=3),),
+        rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False, tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), reorder), attn=(dict(da_pipe=3),), chain=(),
                            validate=validate)
         rows = {key(r["variant"]): r for r in rep["candidates"] if "variant" in r}
         assert all("error" not in r for r in rows.values()), rows
@@ -597,3 +597,25 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
         assert "wd_pk4" in eng.layers[0] and not [k for k in eng._state if k[3] == 7]
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the library knobs are process-wide
+
+
+@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="2 min on the emulator: CBX_EMU_SLOW=1")
+def test_autotuner_validates_a_chained_launch_against_its_twin_on_the_emulator(emu):
+    """autotune.tune_decode with a CHAIN candidate, real token steps of a 1-layer Llama T3 at the real width: the candidate's whole measured run
+    (final logits, every sampled token, the counters' error word) is compared with its twin -- the same geometry as separate launches -- and only
+    then is it `valid`; relative to the built-in geometry it reorders the down projection's sum, so it can only ever be `best_any`."""
+    from chatterbox_amd import autotune as at, synth
+    from chatterbox_amd.t3 import T3Engine
+    eng = T3Engine(synth.t3_state_dict(1, 0), CPU)
+    try:
+        rep = at.tune_decode(eng, B=1, ctx=12, steps=1, reps=1, use_graph=False, tiles=(dict(),), attn=(), epi=(), chain=at.CHAIN_VARIANTS[:1])
+        rows = {tuple(sorted(r["variant"].items())): r for r in rep["candidates"] if "variant" in r}
+        c = at.CHAIN_VARIANTS[0]
+        twin = {k: v for k, v in c.items() if k not in at.CHAIN_KEYS}
+        rc, rt = rows[tuple(sorted(c.items()))], rows[tuple(sorted(twin.items()))]
+        assert "error" not in rc and "error" not in rt, (rc, rt)
+        assert rc["twin_identical"] and rc["valid"] and rc["reorders"] and rt["reorders"], (rc, rt)
+        assert rc["max_abs_diff"] == rt["max_abs_diff"], "chain and twin: the same logits after one step"
+        assert not rep["best"].get("chain"), rep["best"]
+    finally:
+        eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))

@@ -301,7 +301,9 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
         tot_n = sum(v["launches"] for v in gemv.values())
         per_step_ms = sum(v["ms"] / v["launches"] * v["per_step"] for v in gemv.values())
         gbs = tot_b / (tot_ms * 1e-3) / 1e9
-        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
+        chained = any(k.startswith("chain") for k in gemv)
+        e = dict(bound="hbm", kernel=("gemv_chain_kernel (T3 decode weight streaming: o, gate|up, down and the next q/k/v projection of a layer as ONE launch; M = 2*batch rows)"
+                                      if chained else "gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)"),
                  achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                  launches=tot_n, avg_launch_us=round(1e3 * tot_ms / tot_n, 2), algorithmic_bytes_per_launch=round(tot_b / tot_n, 0),
                  share_of_step=round(per_step_ms * 1e-3 * n_decode / (elapsed / steps), 3),
@@ -345,6 +347,22 @@ def gemv_sweeps(t3, rows, reps=6):
                  else (lambda lw: ops.gemv(g, t3._image(lw, "wd", odtc), x2, N=t3.D, K=t3.F, nw=tn["d_nw2"], res=x2, out_packed=True, half_tile=ht, **pk))}
         wbytes = {"qkv": lambda lw: lw["wqkv_pk"].numel() * 4, "o": lambda lw: lw["wo_pk"].numel() * 4,
                   "gate_up": lambda lw: lw["wgu_pk"].numel() * 4, "down": lambda lw: lw["wd_pk"].numel() * 4}
+        if tn.get("chain") and dks == 1 and tn["d_nw2"] == 8 and tn["o_nw2"] == 8 and tn["gu_nw"] == 8:
+            # the adopted geometry runs o -> gate | up -> down -> next q/k/v as ONE launch (cbx_gemv_chain_f32): that launch is what is timed
+            sync = torch.zeros(64, dtype=torch.int32, device=dev)
+            res_kw = dict(nw=8, res=x2, out_packed=True, half_tile=ht, **pk)
+            per_projection = (calls, wbytes)
+            calls = {"chain_o_gateup_down_qkv": lambda lw: ops.gemv_chain(
+                [(att, t3._image(lw, "wo", odtc), x2, dict(N=t3.D, K=t3.D, **res_kw)),
+                 (x2, lw["wgu_pk"], gg, dict(N=t3.F, K=t3.D, swiglu=True, nw=8, norm_w=lw["ln2"], out_packed=True, **pk)),
+                 (gg, t3._image(lw, "wd", odtc), x2, dict(N=t3.D, K=t3.F, **res_kw)),
+                 (x2, t3._image(lw, "wqkv", qtc), qkv, dict(N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk))], sync)}
+            wbytes = {"chain_o_gateup_down_qkv": lambda lw: 4 * (lw["wqkv_pk"].numel() + lw["wo_pk"].numel() + lw["wgu_pk"].numel() + lw["wd_pk"].numel())}
+            try:  # (a sweep that cannot run must not cost the bench line: fall back to the per-projection launches)
+                calls["chain_o_gateup_down_qkv"](t3.layers[0])
+                torch.cuda.synchronize()
+            except Exception:
+                calls, wbytes = per_projection
     else:
         h, att, g = f(rows, t3.D), f(rows, t3.D), f(rows, t3.F)
         qkv, gg = torch.empty(rows, 3 * t3.D, device=dev), torch.empty(rows, t3.F, device=dev)
@@ -672,8 +690,9 @@ def main():
                                  "best_overall": tune_rep.get("ms_per_token_any")},
                 "rule": "candidates timed in a child process (hipGraph replays of the whole token step, synthetic state, >= 1 % faster, confirmed back "
                         f"to back); a bit-identical one is adopted as is; one that 'reorders' (another fp32 summation order) only if all {B} x {N} "
-                        "tokens of the benched batch equal the built-in geometry's",
-                "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "error", "confirm") if k in r}
+                        "tokens of the benched batch equal the built-in geometry's; a chained launch (variant.chain: the dependent GEMVs of a layer as one launch) additionally only "
+                        "if its whole measured run ended bit-identical to the same geometry as separate launches (twin_identical)",
+                "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "twin_identical", "valid", "error", "confirm") if k in r}
                                for r in tune_rep.get("candidates", [])]}
         if alt:
             labels = {"s3gen_precision_3": "s3gen_bf16x3_fast_mode (narrower than the reference's fp32; bf16-mode tolerances)",

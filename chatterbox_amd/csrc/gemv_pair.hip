@@ -378,6 +378,9 @@ struct GemvChain {
     int spins;
 };
 
+// SW1: role 1 is the SwiGLU form (Llama: gate | up); else a plain normalisation-folded GEMV with its activation epilogue (GPT-2: ln_2 + c_fc +
+// gelu_new; roles 0 / 2 then carry a bias, roles 1 / 3 the LayerNorm form of cbx_gemv_t.ln_cw / ln_cb -- all of it epilogue work of the body).
+template <bool SW1>
 __global__ __launch_bounds__(512) void gemv_chain_kernel(const GemvChain c) {
     const unsigned b = blockIdx.x;
     const int r = (b >= (unsigned)c.first[1]) + (b >= (unsigned)c.first[2]) + (b >= (unsigned)c.first[3]);  // uniform
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(const GemvChain c) {
     }
     switch (r) {
         case 0: gemv_body<1, 8, false, true, true, false, 0, false, false, false>(c.op[0], lb, 0, dep); break;  // o projection (+ residual)
-        case 1: gemv_body<1, 8, true, true, true, true, 0, false, false, true>(c.op[1], lb, 0, dep); break;     // RMSNorm + gate | up + SwiGLU
+        case 1: gemv_body<1, 8, SW1, true, true, true, 0, false, false, true>(c.op[1], lb, 0, dep); break;      // norm + gate | up + SwiGLU (or c_fc + gelu)
         case 2: gemv_body<1, 8, false, true, true, false, 0, false, false, true>(c.op[2], lb, 0, dep); break;   // down projection (+ residual)
         default: gemv_body<1, 8, false, true, true, true, 0, false, false, true>(c.op[3], lb, 0, dep); break;   // RMSNorm + q/k/v (or the head)
     }
@@ -418,9 +421,11 @@ extern "C" int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spin
         CBX_REQUIRE(p.x && p.W && p.out, "gemv_chain: null operand in role %d", r);
         CBX_REQUIRE(p.M >= 1 && p.M <= 16 && p.M == ops4[0].M, "gemv_chain: 1..16 rows, the same for all four");
         CBX_REQUIRE(p.w_packed && p.x_packed && !p.w_bf16 && p.nw == 8 && p.K % 256 == 0, "gemv_chain: role %d needs packed fp32 operands, 8 waves, K %% 256 == 0", r);
-        CBX_REQUIRE(!p.n_xpart && !p.ln_cw && !p.act && !p.bias, "gemv_chain: role %d: no partial-sum operand, LayerNorm form, activation or bias", r);
-        CBX_REQUIRE(rms ? (p.norm_w && !p.res) : !p.norm_w, "gemv_chain: roles 1 and 3 are RMSNorm-folded, roles 0 and 2 plain (+ residual)");
-        CBX_REQUIRE((r == 1) == (p.swiglu != 0), "gemv_chain: role 1 (and only it) is the SwiGLU form");
+        CBX_REQUIRE(!p.n_xpart, "gemv_chain: role %d: no partial-sum operand", r);
+        CBX_REQUIRE(rms ? (p.norm_w && !p.res && (!p.ln_cw || (p.ln_cb && !p.bias && !p.swiglu))) : (!p.norm_w && !p.ln_cw && !p.act),
+                    "gemv_chain: roles 1 and 3 are normalisation-folded (RMSNorm, or the LayerNorm form with its bias folded into ln_cb), roles 0 and 2 plain (+ bias, + residual)");
+        CBX_REQUIRE(!p.swiglu || r == 1, "gemv_chain: only role 1 may be the SwiGLU form");
+        CBX_REQUIRE(!p.act || (r == 1 && !p.swiglu), "gemv_chain: an activation epilogue belongs to a non-SwiGLU role 1");
         CBX_REQUIRE(p.half_tile == 0 || p.half_tile == 1 || p.half_tile == 8 || p.half_tile == 12 || p.half_tile == 4, "gemv_chain: half_tile");
         CBX_REQUIRE(!p.swiglu || (p.half_tile == 0 && p.N % 32 == 0), "gemv_chain: the SwiGLU role uses 16-column tiles, N %% 32 == 0");
         CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv_chain: out_packed needs N %% 32 == 0");
@@ -428,7 +433,8 @@ extern "C" int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spin
         c.first[r + 1] = c.first[r] + (p.N + tc - 1) / tc;
     }
     c.sync = sync_ws, c.spins = spins > 0 ? spins : (1 << 16);
-    hipLaunchKernelGGL(gemv_chain_kernel, dim3(c.first[4]), dim3(512), 0, (hipStream_t)stream, c);
+    if (c.op[1].swiglu) hipLaunchKernelGGL(gemv_chain_kernel<true>, dim3(c.first[4]), dim3(512), 0, (hipStream_t)stream, c);
+    else hipLaunchKernelGGL(gemv_chain_kernel<false>, dim3(c.first[4]), dim3(512), 0, (hipStream_t)stream, c);
     return cbx_check_launch("gemv_chain");
 }
 

@@ -212,7 +212,8 @@ int cbx_gemv_pair_f32(const cbx_gemv_t* producer, const cbx_gemv_t* consumer, in
  * 2 plain, 1 the SwiGLU form, 3 RMSNorm-folded; all with M <= 16, nw = 8, packed fp32 operands, no partial-sum operand); every role but the first
  * requests its first weight batch before it waits for the role in front of it.  sync_ws: 64 ints zeroed once (3 edges x 16, [63] = error word as
  * above).  With cbx_decode_attn_rope_f32 a decoder layer of T3.inference's loop (t3.py:378-386) is 2 launches instead of 5.  Bit-identical to the
- * four cbx_gemv_f32 launches.  Emulator-verified, never run on hardware, off by default (CBX_T3_TUNE="chain=1,od_tc=4,d_ks2=1,d_nw2=8"). */
+ * four cbx_gemv_f32 launches.  The GPT-2 form of T3.inference_turbo (t3.py:392-468) is served too: roles 0 / 2 with a bias (c_proj, mlp c_proj),
+ * role 1 without swiglu but with an activation (ln_2 folded + c_fc + gelu_new), roles 1 / 3 in the LayerNorm form (ln_cw / ln_cb).  Emulator-verified, never run on hardware, off by default (CBX_T3_TUNE="chain=1,od_tc=4,d_ks2=1,d_nw2=8"). */
 int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spins, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */

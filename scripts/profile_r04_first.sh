@@ -13,7 +13,7 @@ tail -3 $O/pytest_v9.log
 # T3 stage time, B = 8, 250 tokens, 30 layers: index 3 = the shipped default, 6.. = the round-3 variants (scripts/t3_decode_time.py VARIANTS)
 T3_VARIANTS=3,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33 timeout 1200 python scripts/t3_decode_time.py > $O/t3_decode_variants.log 2>&1
 cat $O/t3_decode_variants.log | tail -24
-for tune in "" "qkv_tc=12" "od_tc=4,d_ks=1,d_nw=8" "qkv_tc=12,od_tc=4,d_ks=1,d_nw=16"; do
+for tune in "" "qkv_tc=12" "od_tc=4,d_ks=1,d_nw=8" "qkv_tc=12,od_tc=4,d_ks=1,d_nw=16" "chain=1,od_tc=4,d_ks=1,d_nw=8" "chain=1,qkv_tc=12,od_tc=4,d_ks=1,d_nw=8"; do
   for pipe in 0 1; do
     CBX_TURBO_TUNE="$tune" CBX_DA_PIPE=$pipe timeout 300 python bench.py --workload turbo --batch 1 --steps 5 --warmup 2 --no-cpu-baseline \
         --no-alt-precisions --no-streaming 2> /dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('turbo b1 tune=[$tune] pipe=$pipe', d['value'], d.get('stage_ms_per_step'), d.get('decode_step', {}).get('ms_per_token'))" | tee -a $O/turbo_b1_variants.log

@@ -397,7 +397,7 @@ def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_ste
         assert (st["logits"].double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials"])
+@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8), dict(chain=1, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials", "chain"])
 def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE T3-Turbo path of chatterbox_amd/t3_turbo.py on the emulator -- conditioning, prefill (exact fp32 GEMMs + flash attention),
     the 5-launch GPT-2 decode step with the LayerNorm-folded GEMVs, the device sampler (top-k / top-p bisection, repetition penalty) -- on a
@@ -414,7 +414,14 @@ def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     u = synth.rand((2, steps + 1), seed=11)
     eng = T3TurboEngine(sd, CPU)
     eng.tune.update(tune)
-    toks = eng.generate(conds, texts, max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    from chatterbox_amd import ops
+    chains, real = [0], ops.gemv_chain
+    ops.gemv_chain = lambda *a, **k: (chains.__setitem__(0, chains[0] + 1), real(*a, **k))[1]
+    try:
+        toks = eng.generate(conds, texts, max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    finally:
+        ops.gemv_chain = real
+    assert (chains[0] > 0) == bool(tune.get("chain")) and not next(iter(eng._state.values()))["dws"]["pair_ws"].any(), f"{chains[0]} chained launches"
     for b in range(2):
         ref = O.t3_inference_turbo(sd, L, d // 64, conds[b], texts[b], steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"

@@ -457,3 +457,22 @@ def test_gemv_chain_equals_the_four_launches(dev, M, odtile, qtile):
     hn = rms(h, ln2)
     h2 = h + F.linear(F.silu(F.linear(hn, wg)) * F.linear(hn, wu), wd)
     _close(q2, F.linear(rms(h2, ln1), wq), 2e-4, "chain vs torch")
+
+
+@pytest.mark.parametrize("name", ["turbo_l2", "nano_l12"])
+def test_t3_turbo_chained_decode_samples_the_reference_tokens(dev, name, monkeypatch):
+    """CBX_TURBO_TUNE="chain=1,od_tc=4,d_ks=1,d_nw=8": the GPT-2 decode step as attention + ONE launch per layer (cbx_gemv_chain_f32 in its GPT-2
+    form: biases, LayerNorm-folded roles, gelu_new) through the hipGraph path, against the golden tokens of the reference's inference_turbo
+    (Turbo d = 1024, 2 layers; Nano d = 768, 12 layers); the counters' error word stays clean."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3_turbo import T3TurboEngine
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    L, d, steps, n_text = int(g["n_layers"]), int(g["d"]), int(g["steps"]), int(g["n_text"])
+    monkeypatch.setenv("CBX_TURBO_TUNE", "chain=1,od_tc=4,d_ks=1,d_nw=8")
+    eng = T3TurboEngine(synth.t3_turbo_state_dict(L, d, 0), dev)
+    assert eng.tune["chain"] == 1
+    u = torch.from_numpy(g["uniforms"])[None]
+    toks = eng.generate(synth.t3_cond(prompt_len=375), [synth.turbo_text_tokens(n_text)], max_gen_len=steps, uniforms=u, ban_eos=True,
+                        temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
+    assert toks[0].tolist() == g["tokens"].tolist()
+    assert not any(bool(st["dws"]["pair_ws"].any()) for st in eng._state.values())

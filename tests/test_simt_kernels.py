@@ -74,7 +74,7 @@ _OPS = [
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
     ("test_gemv_pair_equals_the_two_launches", (16, 8)), ("test_gemv_pair_down_and_next_qkv", (5, 4, 12)),
-    ("test_gemv_chain_equals_the_four_launches", (16, 4, 12)), ("test_gemv_chain_equals_the_four_launches", (3, 8, 0)),
+    ("test_gemv_chain_equals_the_four_launches", (16, 4, 12)), ("test_gemv_chain_equals_the_four_launches", (3, 8, 0)), ("test_gemv_chain_at_the_nano_width", ()),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),

@@ -420,12 +420,11 @@ def test_gemv_pair_down_and_next_qkv(dev, M, dtile, qtile):
 
 
 @pytest.mark.parametrize("M,odtile,qtile", [(16, 4, 12), (3, 8, 0), (16, 0, 0)])
-def test_gemv_chain_equals_the_four_launches(dev, M, odtile, qtile):
+def test_gemv_chain_equals_the_four_launches(dev, M, odtile, qtile, D=1024, Fh=2048):
     """cbx_gemv_chain_f32: o projection (+ residual) -> RMSNorm + gate | up + SwiGLU -> down projection (+ residual) -> RMSNorm + q/k/v of the next
     layer in ONE launch of four roles, each waiting on the arrival counters of the one in front of it after its first weight batch is in flight.
     Bit-identical to the four cbx_gemv_f32 launches, three times in a row on the same counters."""
     from chatterbox_amd import ops
-    D, Fh = 1024, 2048
     att, x0 = _r((M, D), 1), _r((M, D), 2)
     wo, wg, wu = _r((D, D), 3, 1 / math.sqrt(D)), _r((Fh, D), 4, 0.03), _r((Fh, D), 5, 0.03)
     wd, wq = _r((D, Fh), 6, 1 / math.sqrt(Fh)), _r((3 * D, D), 7, 1 / math.sqrt(D))
@@ -476,3 +475,8 @@ def test_t3_turbo_chained_decode_samples_the_reference_tokens(dev, name, monkeyp
                         temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
     assert toks[0].tolist() == g["tokens"].tolist()
     assert not any(bool(st["dws"]["pair_ws"].any()) for st in eng._state.values())
+
+
+def test_gemv_chain_at_the_nano_width(dev):
+    """The same at d = 768 / 3072 (Nano's GPT-2 small): three K blocks per wave, i.e. a load batch whose fourth slot is idle."""
+    test_gemv_chain_equals_the_four_launches(dev, 5, 4, 0, D=768, Fh=3072)

@@ -625,3 +625,24 @@ def test_autotuner_validates_a_chained_launch_against_its_twin_on_the_emulator(e
         assert not rep["best"].get("chain"), rep["best"]
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))
+
+
+@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="2 min on the emulator: CBX_EMU_SLOW=1")
+def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
+    """`python -m chatterbox_amd.autotune` is what bench.py's child process runs: its main() here, on the emulator, with a short candidate list --
+    argument parsing, engine construction, every stage of tune_decode incl. a chained launch under the twin rule, and the one-line JSON report the
+    parent parses."""
+    import json
+    from chatterbox_amd import autotune as at
+    orig = at.tune_decode
+    monkeypatch.setattr(at, "tune_decode", lambda eng, **kw: orig(eng, tiles=(dict(), dict(qkv_tc=12)), attn=(dict(da_pipe=5),), epi=at.EPI_VARIANTS,
+                                                                  chain=at.CHAIN_VARIANTS[:1], **kw))
+    at.main(["--layers", "1", "--batch", "1", "--ctx", "12", "--steps", "1", "--reps", "1"], device=CPU)
+    rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    rows = {tuple(sorted(r["variant"].items())): r for r in rep["candidates"] if "variant" in r}
+    assert all("error" not in r for r in rows.values()), rows
+    for knob in ("qkv_tc", "da_pipe", "pre_epi"):  # (what a knob is tried on top of depends on the emulator's "clock")
+        hit = [r for r in rows.values() if r["variant"].get(knob) and not r["variant"].get("d_ks2")]
+        assert hit and all(r["identical"] for r in hit), (knob, hit)
+    chained = [r for r in rows.values() if r["variant"].get("chain")]
+    assert len(chained) == 1 and chained[0]["twin_identical"] and chained[0]["valid"] and chained[0]["reorders"] and not rep["best"].get("chain")

@@ -69,6 +69,9 @@ def parse():
                     help="keep the built-in decode-step geometry instead of measuring the candidates on this GPU first (T3Engine.autotune: child "
                          "process, bit-identical candidates only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-CPU parity block (needs the CPU baseline utterance)")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 and run C1 (broadcast of the Conditionals) and C2 (gather of the "
+                         "waveforms) through it on device tensors: what a single GPU can exercise of the multi-GPU path (tests/test_rccl_world1_gpu.py)")
     ap.add_argument("--selftest-rendezvous", action="store_true",
                     help="launcher / collective self-test WITHOUT kernels (gloo, host tensors): the N ranks rendezvous, C1 (broadcast of the "
                          "Conditionals) and C2 (gather of waveforms) fire on synthetic payloads of the benched shapes, rank 0 prints the JSON "
@@ -301,9 +304,7 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
         tot_n = sum(v["launches"] for v in gemv.values())
         per_step_ms = sum(v["ms"] / v["launches"] * v["per_step"] for v in gemv.values())
         gbs = tot_b / (tot_ms * 1e-3) / 1e9
-        chained = any(k.startswith("chain") for k in gemv)
-        e = dict(bound="hbm", kernel=("gemv_chain_kernel (T3 decode weight streaming: o, gate|up, down and the next q/k/v projection of a layer as ONE launch; M = 2*batch rows)"
-                                      if chained else "gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)"),
+        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
                  achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                  launches=tot_n, avg_launch_us=round(1e3 * tot_ms / tot_n, 2), algorithmic_bytes_per_launch=round(tot_b / tot_n, 0),
                  share_of_step=round(per_step_ms * 1e-3 * n_decode / (elapsed / steps), 3),
@@ -335,7 +336,7 @@ def gemv_sweeps(t3, rows, reps=6):
         qtc, odtc = t3._tiles()  # output columns per workgroup of the q/k/v resp. o / down projections (T3Engine.tune, CBX_T3_TUNE)
         qt, ht = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
         pd = f(max(dks, 1), r16, t3.D) * 0.1
-        pk = dict(w_packed=True, x_packed=True, M=rows)
+        pk = dict(w_packed=True, x_packed=True, M=rows, flags=t3._gf())  # the adopted geometry's GEMV flags (cbx_gemv_t.flags)
         red = dict(xpart=pd, x_out=x2) if dks > 1 else {}
         calls = {"qkv": lambda lw: ops.gemv(x, t3._image(lw, "wqkv", qtc), qkv, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk),
                  "o": lambda lw: ops.gemv(att, t3._image(lw, "wo", odtc), x2, N=t3.D, K=t3.D, nw=tn["o_nw2"], res=x2, out_packed=True,
@@ -347,22 +348,6 @@ def gemv_sweeps(t3, rows, reps=6):
                  else (lambda lw: ops.gemv(g, t3._image(lw, "wd", odtc), x2, N=t3.D, K=t3.F, nw=tn["d_nw2"], res=x2, out_packed=True, half_tile=ht, **pk))}
         wbytes = {"qkv": lambda lw: lw["wqkv_pk"].numel() * 4, "o": lambda lw: lw["wo_pk"].numel() * 4,
                   "gate_up": lambda lw: lw["wgu_pk"].numel() * 4, "down": lambda lw: lw["wd_pk"].numel() * 4}
-        if tn.get("chain") and dks == 1 and tn["d_nw2"] == 8 and tn["o_nw2"] == 8 and tn["gu_nw"] == 8:
-            # the adopted geometry runs o -> gate | up -> down -> next q/k/v as ONE launch (cbx_gemv_chain_f32): that launch is what is timed
-            sync = torch.zeros(64, dtype=torch.int32, device=dev)
-            res_kw = dict(nw=8, res=x2, out_packed=True, half_tile=ht, **pk)
-            per_projection = (calls, wbytes)
-            calls = {"chain_o_gateup_down_qkv": lambda lw: ops.gemv_chain(
-                [(att, t3._image(lw, "wo", odtc), x2, dict(N=t3.D, K=t3.D, **res_kw)),
-                 (x2, lw["wgu_pk"], gg, dict(N=t3.F, K=t3.D, swiglu=True, nw=8, norm_w=lw["ln2"], out_packed=True, **pk)),
-                 (gg, t3._image(lw, "wd", odtc), x2, dict(N=t3.D, K=t3.F, **res_kw)),
-                 (x2, t3._image(lw, "wqkv", qtc), qkv, dict(N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk))], sync)}
-            wbytes = {"chain_o_gateup_down_qkv": lambda lw: 4 * (lw["wqkv_pk"].numel() + lw["wo_pk"].numel() + lw["wgu_pk"].numel() + lw["wd_pk"].numel())}
-            try:  # (a sweep that cannot run must not cost the bench line: fall back to the per-projection launches)
-                calls["chain_o_gateup_down_qkv"](t3.layers[0])
-                torch.cuda.synchronize()
-            except Exception:
-                calls, wbytes = per_projection
     else:
         h, att, g = f(rows, t3.D), f(rows, t3.D), f(rows, t3.F)
         qkv, gg = torch.empty(rows, 3 * t3.D, device=dev), torch.empty(rows, t3.F, device=dev)
@@ -447,8 +432,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if world > 1:
+    if world > 1 or args.force_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local)
@@ -477,7 +465,7 @@ def main():
     tune_rep = None  # T3 decode-step geometry picked by measurement on THIS GPU before anything is timed (below, once the workload exists)
     # C1: rank 0 "analysed the voice prompt"; everybody else receives the packed Conditionals over RCCL
     t3c, gen = (synth.t3_cond(prompt_len=375 if turbo else 150), synth.s3gen_ref()) if rank == 0 else (None, None)
-    t3c, gen = cdist.broadcast_conditionals(t3c, gen, src=0, device=dev)
+    t3c, gen = cdist.broadcast_conditionals(t3c, gen, src=0, device=dev, force=args.force_rccl)
 
     B, N = args.batch, args.tokens
     texts = [(synth.turbo_text_tokens if turbo else synth.text_tokens)(args.text_tokens, seed=100 * rank + b) for b in range(B)]
@@ -492,7 +480,8 @@ def main():
         gv = torch.Generator(device=dev).manual_seed(777 + rank)
         kwv = dict(max_new_tokens=N, uniforms=torch.rand(B, N, generator=gv, device=dev), ban_eos=True, ban_from=6561)
         want = [t.tolist() for t in eng.t3.generate(t3c, texts, **kwv)]
-        tune_rep = eng.t3.autotune(B=B, ctx=34 + args.text_tokens + 2 + N // 2, log=log,
+        # green_only: nothing off the committed allow-list of hardware-verified geometries (chatterbox_amd/decode_green.json) is even timed
+        tune_rep = eng.t3.autotune(B=B, ctx=34 + args.text_tokens + 2 + N // 2, log=log, green_only=True,
                                    validate=lambda: [t.tolist() for t in eng.t3.generate(t3c, texts, **kwv)] == want)
         tune_rep["autotune_s"] = round(time.perf_counter() - t_tune, 1)
         log(f"decode autotune: adopted {tune_rep.get('adopted')} in {tune_rep['autotune_s']} s")
@@ -510,7 +499,9 @@ def main():
         log(f"step seed={seed}: {eng.last_timing}")
         host = [w.cpu() for w in wavs]  # first (and only) audio reaches the host here: the path is non-streaming
         lat = time.perf_counter() - t0
-        allw = cdist.gather_waveforms(wavs, dst=0)  # C2
+        allw = cdist.gather_waveforms(wavs, dst=0, force=args.force_rccl)  # C2
+        if args.force_rccl:
+            assert len(allw) == len(host) and all(torch.equal(a, h) for a, h in zip(allw, host)), "C2 over RCCL returned other waveforms"
         return sum(w.numel() for w in host) / 24000.0, lat, dict(eng.last_timing)
 
     for i in range(args.warmup):
@@ -677,6 +668,10 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1),
                        "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial")},
+            # the T3 decode geometry the timed region ran (built-in + what the autotuner adopted from the hardware-green allow-list)
+            "t3_geometry": ({"adopted": (tune_rep or {}).get("adopted") or {}, "tune": {k: v for k, v in eng.t3.tune.items() if v != type(eng.t3)._TUNE.get(k)},
+                             "knobs": dict(eng.t3.knobs), "on_green_list": True} if not turbo else {"tune": dict(eng.t3.tune), "knobs": dict(eng.t3.knobs)}),
+            "multi_gpu_note": ("single-GPU run: no N > 1 scaling curve exists in this repo (the driver owns multi-GPU leases)" if world == 1 else None),
             "roofline": roof,
             "decode_step": dstep,
             "roofline_secondary": list(roofs.values()),
@@ -690,9 +685,10 @@ def main():
                                  "best_overall": tune_rep.get("ms_per_token_any")},
                 "rule": "candidates timed in a child process (hipGraph replays of the whole token step, synthetic state, >= 1 % faster, confirmed back "
                         f"to back); a bit-identical one is adopted as is; one that 'reorders' (another fp32 summation order) only if all {B} x {N} "
-                        "tokens of the benched batch equal the built-in geometry's; a chained launch (variant.chain: the dependent GEMVs of a layer as one launch) additionally only "
-                        "if its whole measured run ended bit-identical to the same geometry as separate launches (twin_identical)",
-                "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "twin_identical", "valid", "error", "confirm") if k in r}
+                        "tokens of the benched batch equal the built-in geometry's; ONLY candidates on the committed allow-list of hardware-green "
+                        "geometries (chatterbox_amd/decode_green.json) are timed; identity = logits of single steps over ragged contexts "
+                        "{1, 38, 63, 64, 65, 225, 640} + the timed run's final logits",
+                "candidates": [{k: r[k] for k in ("variant", "ms_per_token", "identical", "reorders", "valid", "error", "confirm", "skipped") if k in r}
                                for r in tune_rep.get("candidates", [])]}
         if alt:
             labels = {"s3gen_precision_3": "s3gen_bf16x3_fast_mode (narrower than the reference's fp32; bf16-mode tolerances)",

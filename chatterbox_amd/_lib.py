@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 9  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 10  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -53,7 +53,17 @@ class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("half_tile", c_int), ("out_packed", c_int),
-                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("w_bf16", c_int), ("reserved1", c_int), ("ln_cw", c_f), ("ln_cb", c_f)]
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("w_bf16", c_int), ("flags", c_int), ("ln_cw", c_f), ("ln_cb", c_f)]
+
+
+GEMV_PRE_EPI, GEMV_DEEP = 1, 2  # cbx_gemv_t.flags
+
+
+class DecodeAttnParams(ctypes.Structure):  # cbx_decode_attn_t (ABI v10)
+    _fields_ = [("qkv", c_f), ("positions", c_f), ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("o", c_f),
+                ("rows", c_int), ("n_heads", c_int), ("ld_qkv", c_long), ("o_ld", c_long), ("o_packed", c_int),
+                ("cache_row_stride", c_long), ("cache_head_stride", c_long), ("scale", c_float),
+                ("unroll", c_int), ("pipeline", c_int), ("split_min", c_int), ("split_ws", c_f), ("split_cnt", c_f), ("split_pairs", c_long)]
 
 
 class SamplerParams(ctypes.Structure):
@@ -79,7 +89,9 @@ class T3Step(ctypes.Structure):
                 ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("kv_row_stride", c_long), ("kv_head_stride", c_long),
                 ("next_ids", c_f), ("next_pos_ids", c_f), ("positions", c_f), ("x_a", c_f), ("x_b", c_f), ("qkv", c_f), ("att", c_f),
                 ("g", c_f), ("pd", c_f), ("logits", c_f), ("ld_logits", c_long), ("sampler", ctypes.POINTER(SamplerParams)),
-                ("qkv_tile", c_int)]  # ABI v9
+                ("qkv_tile", c_int),  # ABI v9
+                ("da_unroll", c_int), ("da_pipeline", c_int), ("da_split_min", c_int), ("gemv_flags", c_int),  # ABI v10
+                ("da_ws", c_f), ("da_cnt", c_f), ("da_pairs", c_long)]
 
 
 _SIGS = {
@@ -89,8 +101,6 @@ _SIGS = {
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
     "cbx_set_gemv_deep_batches": ([c_int], c_int),
     "cbx_set_gemv_epilogue_prefetch": ([c_int], c_int),
-    "cbx_gemv_chain_f32": ([ctypes.POINTER(GemvParams), c_f, c_int, c_f], c_int),
-    "cbx_gemv_pair_f32": ([ctypes.POINTER(GemvParams), ctypes.POINTER(GemvParams), c_f, c_int, c_f], c_int),
     "cbx_pack_gemv_weight_f32": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
     "cbx_pack_gemv_weight_bf16": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),
     "cbx_add_norm_f32": ([c_f, c_f, c_int, c_long, c_long, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_float, c_int, c_f], c_int),
@@ -101,6 +111,7 @@ _SIGS = {
     "cbx_flash_attn_split_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 8 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_decode_attn_f32": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_f], c_int),
     "cbx_decode_attn_rope_f32": ([c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_float, c_f], c_int),
+    "cbx_decode_attn_rope": ([ctypes.POINTER(DecodeAttnParams), c_f], c_int),
     "cbx_set_decode_attn_unroll": ([c_int], c_int),
     "cbx_set_decode_attn_pipeline": ([c_int], c_int),
     "cbx_set_decode_attn_workspace": ([c_f, c_f, c_long], c_int),

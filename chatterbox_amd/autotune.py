@@ -8,8 +8,11 @@ MI355X boxes differ by 3-10 %), the batch (rows = 2 B) and the context, so it is
     report = T3Engine.autotune(B=8)          # times every candidate on a synthetic decode state in a CHILD process, adopts the winner
 
 Rules:
-  * a candidate is ADOPTED only if its logits after one token step are bit-identical to the current geometry's (same products, same
-    summation order) and it is faster by `min_gain`; candidates that sum in another (equally valid fp32) order -- the down projection without
+  * only candidates on the committed ALLOW-LIST (`decode_green.json`: geometries whose hardware tests -- tests/test_zz_abi_v9_gpu.py
+    `test_green_variant_*`, run on an MI355X -- are green) are timed at all when the caller asks for `green_only` (bench.py does);
+  * a candidate is ADOPTED only if its logits are bit-identical to the current geometry's (same products, same summation order) on a PROBE of
+    single token steps over ragged contexts {1, 38, 63, 64, 65, 225, 640} (fewer rows than one attention step, exactly one, the ragged tail of the
+    second register set, the bench context, a split-grid context) AND after the timed run, and it is faster by `min_gain`; candidates that sum in another (equally valid fp32) order -- the down projection without
     split-K partial images, another wave count -- are timed and reported (`"reorders": true`) but not adopted unless `allow_reorder=True`;
   * the measurement runs in a child process on seeded synthetic weights of the engine's shape (time does not depend on weight values): a
     candidate that faults or hangs takes the child down, not the serving process, and the engine keeps its current geometry;
@@ -35,17 +38,31 @@ ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe
                  dict(da_pipe=1, da_u=8), dict(da_u=8))
 # process-wide knob of every GEMV launch (cbx_set_gemv_epilogue_prefetch), tried on top of the best geometry so far
 EPI_VARIANTS = (dict(pre_epi=1),)
-# the dependent GEMVs of a layer as ONE launch (cbx_gemv_chain_f32, gemv_pair.hip) on the partial-free geometry.  These launches synchronise
-# workgroups through arrival counters, so a candidate counts only if the WHOLE measured run (every replay: final logits and every sampled token)
-# ends bit-identical to its twin -- the same geometry as separate launches -- with the error word of the counters clean.  Relative to the
-# built-in geometry they sum the down projection in another order, i.e. they are `best_any` material: adopted only through validate().
-CHAIN_VARIANTS = (dict(chain=1, od_tc=4, d_ks2=1, d_nw2=8), dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))
-CHAIN_KEYS = ("chain", "pair_ogu", "pair_dq")
-LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)  # library defaults
+LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)  # per-engine launch knobs (cbx_decode_attn_t.pipeline / unroll, cbx_gemv_t.flags) and their defaults
+PROBE_CTXS = (1, 38, 63, 64, 65, 225, 640)
+GREEN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_green.json")
+
+
+def canon(v):
+    """Canonical form of a variant: default-valued keys dropped, sorted tuple (the key of the allow-list)."""
+    from .t3 import T3Engine
+    d = dict(T3Engine._TUNE, **LIB_KNOBS)
+    return tuple(sorted((k, int(x)) for k, x in v.items() if int(x) != d.get(k)))
+
+
+def green_variants():
+    """The committed allow-list: variants that passed their hardware tests on an MI355X (written by scripts/green_variants.py from a GPU run,
+    re-checked by tests/test_zz_abi_v9_gpu.py::test_green_variant_*).  The built-in geometry {} is always on it."""
+    try:
+        with open(GREEN_FILE) as f:
+            rows = json.load(f)["green"]
+    except (OSError, ValueError, KeyError):
+        rows = []
+    return {canon({})} | {canon(v) for v in rows}
 
 
 def env_knobs():
-    """The library knobs as the environment sets them when libcbx_hip.so loads (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP, CBX_GEMV_PRE_EPI)."""
+    """The engines' launch knobs as the environment asks for them (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP, CBX_GEMV_PRE_EPI: A/B scripts)."""
     e = os.environ.get
     return dict(da_pipe=int(e("CBX_DA_PIPE") or 0) & 7, da_u=int(e("CBX_DA_U") or 0) or 4, deep=int(e("CBX_GEMV_DEEP") or 0),
                 pre_epi=int(bool(int(e("CBX_GEMV_PRE_EPI") or 0))))
@@ -57,20 +74,25 @@ def split_variant(v):
 
 
 def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, use_graph=True, tiles=TILE_VARIANTS, attn=ATTN_VARIANTS,
-                epi=EPI_VARIANTS, chain=CHAIN_VARIANTS, log=None):
+                epi=EPI_VARIANTS, log=None, green_only=False, probe_ctxs=PROBE_CTXS):
     """Time every candidate on `eng` (in this process) and return the report; `eng` is left on the geometry it came with.
     report["best"]: the fastest candidate whose logits are bit-identical to the current geometry's ({} = keep it); report["best_any"]: the
     fastest candidate overall, reordering ones included (== best unless a reordering candidate is faster still by min_gain) -- for callers
-    that validate it on their own workload (T3Engine.autotune(validate=...))."""
+    that validate it on their own workload (T3Engine.autotune(validate=...)).  green_only: candidates off the allow-list are not run."""
     import torch
-    base_tune, base_knobs = dict(eng.tune), dict(getattr(eng, "lib_knobs", None) or env_knobs())
-    rows, seen, final = [], {}, {}
+    base_tune, base_knobs = dict(eng.tune), dict(eng.knobs)
+    rows, seen = [], {}
+    green = green_variants() if green_only else None
+
+    def full(v):
+        t, k = split_variant(v)
+        return dict(base_tune, **t), dict(base_knobs, **k)
 
     def run(v):
-        eng.apply_variant(dict(base_tune, **split_variant(v)[0]), dict(base_knobs, **split_variant(v)[1]))
-        r = eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
-        final[tuple(sorted(v.items()))] = getattr(eng, "last_measure", None)
-        return r
+        eng.apply_variant(*full(v))
+        probe = eng.probe_decode(B=B, ctxs=probe_ctxs)
+        ms, lg = eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
+        return ms, torch.cat([probe.flatten(), lg.flatten(), eng.last_measure["final_logits"].flatten()])
 
     ms0, ref = run({})
     scale = max(1.0, float(ref.abs().max()))
@@ -83,6 +105,9 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         if not v or key in seen:
             return
         seen[key] = True
+        if green is not None and canon(dict(full(v)[0], **full(v)[1])) not in green:
+            rows.append(dict(variant=v, skipped="not on the hardware-green allow-list (decode_green.json)"))
+            return
         try:
             ms, lg = run(v)
         except Exception as e:  # a candidate this build / shape does not support: reported, never adopted
@@ -91,12 +116,7 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         same = bool(torch.equal(lg, ref))
         diff = float((lg - ref).abs().max())
         ok_num = same or diff <= 2e-4 * scale  # another fp32 summation order of the same products
-        row = dict(variant=v, ms_per_token=round(ms, 5), identical=same, reorders=not same, max_abs_diff=diff, valid=ok_num)
-        if any(v.get(k) for k in CHAIN_KEYS):  # the whole run against the twin (same geometry, separate launches)
-            a, b = final.get(key), final.get(tuple(sorted((k, x) for k, x in v.items() if k not in CHAIN_KEYS)))
-            row["twin_identical"] = bool(a and b and a["sync_clean"] and torch.equal(a["final_logits"], b["final_logits"]) and torch.equal(a["out_tokens"], b["out_tokens"]))
-            row["valid"] = row["valid"] and row["twin_identical"]
-        rows.append(row)
+        rows.append(dict(variant=v, ms_per_token=round(ms, 5), identical=same, reorders=not same, max_abs_diff=diff, valid=ok_num))
         if log:
             log(f"autotune: {v} {ms:.4f} ms / token, identical={same} (max |d logits| {diff:.2e})")
 
@@ -112,10 +132,6 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
     for base in (pick(True), pick(False)):  # the GEMV epilogue prefetch on top of whatever leads now
         for a in epi:
             consider(dict(base, **a))
-    knobs_now = {k: x for k, x in pick(False).items() if k in LIB_KNOBS}  # the chained launches: on the attention / epilogue knobs that lead now
-    for c in chain:
-        consider(dict(knobs_now, **{k: x for k, x in c.items() if k not in CHAIN_KEYS}))  # the twin first (measured like any other candidate)
-        consider(dict(knobs_now, **c))
 
     def confirm(v):  # back to back against the current geometry (`reps` more rounds each): the pool's boxes drift by a few per cent over seconds
         if not v:
@@ -134,14 +150,15 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         best, best_ms = best_any, any_ms
     eng.apply_variant(base_tune, base_knobs)
     return dict(best=best, ms_per_token=round(best_ms, 5), best_any=best_any, ms_per_token_any=round(any_ms, 5), baseline_ms_per_token=round(ms0, 5),
-                B=B, ctx=ctx, steps=steps, layers=eng.L, graph=bool(use_graph), allow_reorder=bool(allow_reorder), candidates=rows)
+                B=B, ctx=ctx, steps=steps, layers=eng.L, graph=bool(use_graph), allow_reorder=bool(allow_reorder), green_only=bool(green_only),
+                probe_ctxs=list(probe_ctxs), candidates=rows)
 
 
-def tune_in_child(layers, B, ctx, steps, reps, min_gain, allow_reorder, device_index, base_tune, base_knobs, timeout=180.0, log=None):
+def tune_in_child(layers, B, ctx, steps, reps, min_gain, allow_reorder, device_index, base_tune, base_knobs, timeout=180.0, log=None, green_only=False):
     """Run `python -m chatterbox_amd.autotune` and parse its report; any failure (non-zero exit, timeout, no JSON) returns {"error": ...}."""
     cmd = [sys.executable, "-m", "chatterbox_amd.autotune", "--layers", str(layers), "--batch", str(B), "--ctx", str(ctx), "--steps", str(steps),
            "--reps", str(reps), "--min-gain", str(min_gain), "--device", str(device_index), "--tune", json.dumps(base_tune), "--knobs",
-           json.dumps(base_knobs)] + (["--allow-reorder"] if allow_reorder else [])
+           json.dumps(base_knobs)] + (["--allow-reorder"] if allow_reorder else []) + (["--green-only"] if green_only else [])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CBX_T3_TUNE", "CBX_DA_PIPE", "CBX_DA_U", "CBX_GEMV_DEEP",
@@ -191,6 +208,7 @@ def main(argv=None, device=None):
     ap.add_argument("--min-gain", type=float, default=0.01)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--allow-reorder", action="store_true")
+    ap.add_argument("--green-only", action="store_true", help="time only candidates on the hardware-green allow-list (decode_green.json)")
     ap.add_argument("--tune", default="{}", help="JSON: T3Engine.tune overrides of the starting geometry")
     ap.add_argument("--knobs", default="{}", help="JSON: library knobs (da_pipe, da_u, deep) of the starting geometry")
     ap.add_argument("--verbose", action="store_true")
@@ -207,7 +225,7 @@ def main(argv=None, device=None):
     eng.apply_variant(dict(eng.tune, **json.loads(a.tune)), dict(LIB_KNOBS, **json.loads(a.knobs)))
     log = (lambda m: print(m, file=sys.stderr, flush=True)) if a.verbose else None
     rep = tune_decode(eng, B=a.batch, ctx=a.ctx, steps=a.steps, reps=a.reps, min_gain=a.min_gain, allow_reorder=a.allow_reorder, log=log,
-                      use_graph=device.type == "cuda")
+                      use_graph=device.type == "cuda", green_only=a.green_only)
     print(json.dumps(rep), flush=True)
 
 

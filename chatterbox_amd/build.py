@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcbx_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -ffp-contract=on: a*b + c is fused where the SOURCE writes it as one expression and nowhere else (hipcc's default, `fast`, lets the
+# backend fuse -- or SLP-vectorise into v_pk_mul + adds -- per site, so two instantiations of one template could round the same expression
+# differently: the round-3 "bit-identical" decode-attention variants differed from the plain kernel by an ulp on the MI355X for that reason).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on"]
 
 
 def _sources():

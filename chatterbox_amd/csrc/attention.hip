@@ -4,6 +4,8 @@
 #include "cbx_common.h"
 
 namespace {
+CBX_TRC_TU
+
 
 // ------------------------------------------------------------------------------------------------------------
 // Flash attention, head_dim 64.  Workgroup = 4 waves x 32 queries; KV walked in 64-key tiles staged in LDS.
@@ -499,6 +501,8 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) float st_acc[16][64];
     __shared__ float st_m[16], st_l[16];
     __shared__ int s_last[1];
+    CBX_TRC_DECL;
+    CBX_TRC_STAMP(0);  // entry
     const int row = blockIdx.y, head = blockIdx.x;
     // !SPLIT: the one-workgroup form, compiled without any of the hand-off.  SPLIT: a row whose context is shorter than split_min_ctx is
     // still walked by ONE workgroup (split 0; the others leave at once): the hand-off costs ~5 us on the critical path (release, ticket,
@@ -577,6 +581,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         }
     }
     __syncthreads();
+    CBX_TRC_STAMP(1);  // q / k / v of the new token roped and in LDS (positions[], qkv row and cos / sin have arrived)
     const f32x4 qv4 = *reinterpret_cast<const f32x4*>(&q_s[l16 * 4]);
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -636,6 +641,10 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             load_chunk(p0);
         }
     }
+#ifdef CBX_TRACE
+    asm volatile("s_nop 0" ::"v"(acc[0]));
+    CBX_TRC_STAMP(2);  // context walked (wave 0)
+#endif
     const int g = wid * 4 + sub;
     *reinterpret_cast<f32x4*>(&st_acc[g][l16 * 4]) = acc;
     if (l16 == 0) {
@@ -699,6 +708,12 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         }
         o[oi] = num / den;
     }
+#ifdef CBX_TRACE
+    CBX_TRC_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CBX_TRC_STAMP(4);
+    CBX_TRC_FLUSH(0x20000000u | (unsigned)(PIPE ? 1 : 0) | (unsigned)(NT ? 2 : 0) | (unsigned)(SPEC ? 4 : 0) | (unsigned)(SPLIT ? 8 : 0));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -740,6 +755,7 @@ __global__ __launch_bounds__(256) void softmax_relpos_kernel(const float* __rest
 }
 
 }  // namespace
+CBX_TRC_SETTER(cbx_trace_set_attention)
 
 extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
                                   int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
@@ -766,11 +782,12 @@ extern "C" int cbx_flash_relpos_f32(const float* qu, const float* qv, const floa
     CBX_REQUIRE(T > 0 && nz1 > 0 && n_heads > 0, "flash_relpos: bad shape");
     CBX_REQUIRE((q_st | q_sb | pp_st | o_st | o_sb) % 4 == 0, "flash_relpos: strides must be multiples of 4");
     CBX_REQUIRE((((uintptr_t)qu | (uintptr_t)qv | (uintptr_t)k | (uintptr_t)v | (uintptr_t)pp | (uintptr_t)o) & 15) == 0, "flash_relpos: 16-byte alignment");
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;  // one bit per device ordinal: hipFuncSetAttribute is per device
+    const int dev = cbx_device();
+    if (!(configured >> dev & 1)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_relpos_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RELPOS_LDS);
         if (e != hipSuccess) return cbx_set_error((int)e, "flash_relpos: cannot reserve %d B of LDS", RELPOS_LDS);
-        configured = true;
+        configured |= 1ull << dev;
     }
     FlashRelArgs a{qu, qv, k, v, pp, o, key_lens, T, 2 * T - 1, q_sb, q_st, pp_st, o_sb, o_st, scale};
     hipLaunchKernelGGL(flash_relpos_f32_kernel, dim3((T + 127) / 128, n_heads, nz1), dim3(256), RELPOS_LDS, (hipStream_t)stream, a);
@@ -787,15 +804,15 @@ extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float*
     return cbx_check_launch("decode_attn");
 }
 
+// ---- process-wide TEST HOOKS of the positional entry point cbx_decode_attn_rope_f32 (tests / A-B scripts).  The engines do not use them: their
+// geometry and their split-context workspace travel per call in cbx_decode_attn_t (ABI v10), so two engines in one process -- or a hipGraph
+// captured earlier -- never see each other's settings.
 static int g_da_u = 0;  // 0: from the environment (CBX_DA_U) on first use, default 4
 extern "C" int cbx_set_decode_attn_unroll(int u) {
     CBX_REQUIRE(u == 4 || u == 8 || u == 16, "decode_attn unroll must be 4, 8 or 16");
     g_da_u = u;
     return 0;
 }
-
-// Workspace of the split-context form (one per device; registered by the engines: 66 floats per (row, head, split) + one ZEROED int per
-// (row, head)).  Without it -- or with >= 128 (row, head) pairs -- one workgroup walks a whole context.
 static float* g_da_ws[64] = {nullptr};
 static int* g_da_cnt[64] = {nullptr};
 static long g_da_pairs[64] = {0};
@@ -820,51 +837,55 @@ extern "C" int cbx_set_decode_attn_split_min(int min_ctx) {
     return 0;
 }
 
-extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
-                                        float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
-                                        long cache_row_stride, long cache_head_stride, float scale, void* stream) {
-    CBX_REQUIRE(qkv && positions && kc && vc && o && (!cos_t == !sin_t), "decode_attn_rope: null operand");
-    CBX_REQUIRE(ld_qkv % 4 == 0 && cache_row_stride % 4 == 0 && cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
-    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: the default, 4)
-    static const int no_split = getenv("CBX_DA_NO_SPLIT") ? atoi(getenv("CBX_DA_NO_SPLIT")) : 0;
+extern "C" int cbx_decode_attn_rope(const cbx_decode_attn_t* pd, void* stream) {
+    CBX_REQUIRE(pd, "decode_attn_rope: null descriptor");
+    const cbx_decode_attn_t& a = *pd;
+    CBX_REQUIRE(a.qkv && a.positions && a.kc && a.vc && a.o && (!a.cos_t == !a.sin_t), "decode_attn_rope: null operand");
+    CBX_REQUIRE(a.ld_qkv % 4 == 0 && a.cache_row_stride % 4 == 0 && a.cache_head_stride % 4 == 0, "decode_attn_rope: alignment");
+    CBX_REQUIRE(a.unroll == 0 || a.unroll == 4 || a.unroll == 8 || a.unroll == 16, "decode_attn_rope: unroll must be 0 (= 4), 4, 8 or 16");
+    CBX_REQUIRE(a.pipeline >= 0 && a.pipeline <= 7 && a.split_min >= 0, "decode_attn_rope: pipeline in 0 .. 7, split_min >= 0");
+    CBX_REQUIRE(!(a.pipeline & 4) || a.cache_head_stride >= 64 * 64, "decode_attn_rope: the speculative first step needs 64 cache positions per (row, head)");
     // contexts shorter than this are walked by one workgroup even on a split grid (the hand-off costs more than it saves below ~3 round trips)
-    const int split_min = g_da_split_min;
-    const long pairs = (long)rows * n_heads;
-    int d = 0, S = 1;
-    if (!no_split && pairs < 128 && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 && g_da_pairs[d] >= pairs) {
+    const int split_min = a.split_min > 0 ? a.split_min : 512;
+    const long pairs = (long)a.rows * a.n_heads;
+    int S = 1;
+    // the split-context form needs a CALLER-OWNED workspace (66 * 8 floats + one zeroed int per (row, head)): launches that may be in flight
+    // at the same time (two engines, two streams) must not share one
+    if (pairs < 128 && a.split_ws && a.split_cnt && a.split_pairs >= pairs) {
         S = (int)(256 / pairs);  // fill the chip: Turbo / Nano at batch 1 = 12-16 pairs -> 8 workgroups each
         S = S > DA_MAX_SPLIT ? DA_MAX_SPLIT : S < 1 ? 1 : S;
     }
-    const dim3 grid(n_heads, rows, S), block(256);
+    const dim3 grid(a.n_heads, a.rows, S), block(256);
     hipStream_t st = (hipStream_t)stream;
-    float* ws = S > 1 ? g_da_ws[d] : nullptr;
-    int* cnt = S > 1 ? g_da_cnt[d] : nullptr;
+    float* ws = S > 1 ? a.split_ws : nullptr;
+    int* cnt = S > 1 ? a.split_cnt : nullptr;
     // One workgroup per (row, head[, split]) walks its context, 4 key rows per 16-lane group and step: best on the batched Llama grid
     // (16 rows x 16 heads, profiles/r02_t3_decode_variants.log) AND on the small grids of batch 1 -- a same-box A/B of Multilingual /
     // Nano / Turbo at batch 1 (profiles/r03_decode_attn_b1_ab.log) has 4 rows + no split ahead of 16 rows in flight and of a split
-    // at contexts of 200-700 by 1-4 %; the split engages on contexts >= cbx_set_decode_attn_split_min (512): a 1000-token Turbo generation
+    // at contexts of 200-700 by 1-4 %; the split engages on contexts >= split_min (512): a 1000-token Turbo generation
     // (contexts to ~1450) decodes at 1.03 ms / token with it, 1.20 without (profiles/r03_turbo_long_context.log).
-    const int da_u = g_da_u > 0 ? g_da_u : 4;
+    const int da_u = a.unroll > 0 ? a.unroll : 4;
 #define CBX_DA_LAUNCH(U, P, N, SP)                                                                                                         \
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N, SP>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
-                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N, SP>), grid, block, 0, st, a.qkv, a.positions, a.cos_t, a.sin_t, a.kc, a.vc, a.o, a.n_heads, \
+                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min);        \
         else                                                                                                                               \
-            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N, SP>), grid, block, 0, st, qkv, positions, cos_t, sin_t, kc, vc, o, n_heads, \
-                               ld_qkv, o_ld, o_packed, cache_row_stride, cache_head_stride, scale, ws, cnt, split_min);                    \
+            hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N, SP>), grid, block, 0, st, a.qkv, a.positions, a.cos_t, a.sin_t, a.kc, a.vc, a.o, a.n_heads, \
+                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min);        \
     } while (0)
-    if (g_da_pipe & 4) {  // speculative first step (4 rows per lane group and step), with or without the pipelined stream / non-temporal loads
-        switch (g_da_pipe & 3) {
+    const int pipe = a.pipeline;
+    if (pipe & 4) {  // speculative first step (4 rows per lane group and step), with or without the pipelined stream / non-temporal loads
+        switch (pipe & 3) {
             case 0: CBX_DA_LAUNCH(4, false, false, true); break;
             case 1: CBX_DA_LAUNCH(4, true, false, true); break;
             case 2: CBX_DA_LAUNCH(4, false, true, true); break;
             default: CBX_DA_LAUNCH(4, true, true, true); break;
         }
-    } else if (g_da_pipe & 2) {  // non-temporal K / V loads (4 rows per lane group and step), plain or pipelined
-        if (g_da_pipe & 1) CBX_DA_LAUNCH(4, true, true, false);
+    } else if (pipe & 2) {  // non-temporal K / V loads (4 rows per lane group and step), plain or pipelined
+        if (pipe & 1) CBX_DA_LAUNCH(4, true, true, false);
         else CBX_DA_LAUNCH(4, false, true, false);
-    } else if (g_da_pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
+    } else if (pipe) {  // two register sets, the next step's rows requested before this step's arithmetic (4 or 8 rows per lane group and step)
         if (da_u == 8) CBX_DA_LAUNCH(8, true, false, false);
         else CBX_DA_LAUNCH(4, true, false, false);
     } else if (da_u == 8) CBX_DA_LAUNCH(8, false, false, false);
@@ -872,6 +893,22 @@ extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, 
     else CBX_DA_LAUNCH(4, false, false, false);
 #undef CBX_DA_LAUNCH
     return cbx_check_launch("decode_attn_rope");
+}
+
+// positional form (ABI <= 9): geometry from the process-wide test hooks above, workspace from cbx_set_decode_attn_workspace
+extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
+                                        float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
+                                        long cache_row_stride, long cache_head_stride, float scale, void* stream) {
+    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: the default, 4)
+    static const int no_split = getenv("CBX_DA_NO_SPLIT") ? atoi(getenv("CBX_DA_NO_SPLIT")) : 0;
+    cbx_decode_attn_t a{};
+    a.qkv = qkv, a.positions = positions, a.cos_t = cos_t, a.sin_t = sin_t, a.kc = kc, a.vc = vc, a.o = o;
+    a.rows = rows, a.n_heads = n_heads, a.ld_qkv = ld_qkv, a.o_ld = o_ld, a.o_packed = o_packed;
+    a.cache_row_stride = cache_row_stride, a.cache_head_stride = cache_head_stride, a.scale = scale;
+    a.unroll = g_da_u > 0 ? g_da_u : 0, a.pipeline = g_da_pipe, a.split_min = g_da_split_min;
+    int d = 0;
+    if (!no_split && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) a.split_ws = g_da_ws[d], a.split_cnt = g_da_cnt[d], a.split_pairs = g_da_pairs[d];
+    return cbx_decode_attn_rope(&a, stream);
 }
 
 extern "C" int cbx_softmax_relpos_f32(const float* ac, const float* bd, float* p, const int* key_lens, int nz1, int nz2,

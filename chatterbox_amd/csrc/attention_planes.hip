@@ -538,14 +538,15 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
     const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;
     if (ver >= 2 && v2ok) {
         constexpr int lds = 3 * PL_STAGE;
-        static bool configured = false;
-        if (!configured) {
+        static unsigned long long configured = 0;  // one bit per device ordinal
+        const int dev = cbx_device();
+        if (!(configured >> dev & 1)) {
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>((flash_attn_pl2_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e2 == hipSuccess) e2 = e3;
             if (e1 != hipSuccess || e2 != hipSuccess) return cbx_set_error((int)(e1 != hipSuccess ? e1 : e2), "flash_attn_planes: cannot reserve %d B of LDS", lds);
-            configured = true;
+            configured |= 1ull << dev;
         }
         dim3 grid2((Tq + 255) / 256, n_heads, nz1);
         if (ver == 3) hipLaunchKernelGGL(flash_attn_pl2_kernel<true>, grid2, dim3(512), lds, (hipStream_t)stream, a);

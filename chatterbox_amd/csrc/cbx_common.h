@@ -30,6 +30,53 @@ __device__ __forceinline__ void cbx_split2(float v0, float v1, unsigned& h, unsi
 }
 #endif
 
+// ordinal of the calling thread's current device, clamped to [0, 64): index of the per-device tables (range flag, "LDS opted into" bits)
+static inline int cbx_device() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
+}
+
+// ---- CBX_TRACE: launch-timeline instrumentation of a SIDE build (scripts/trace_decode.sh -> build/libcbx_hip_trace.so; the product library is
+// compiled without it and its instruction streams do not change).  Thread 0 of every workgroup of an instrumented kernel reads the chip-wide
+// 100 MHz counter (s_memrealtime) at up to 7 points and appends ONE 64-byte record {tag, t0 .. t6} to a device log at exit; the host sorts the
+// records by time.  A poor man's thread trace: where a dependent chain of 5-9 us kernels spends its time (dispatch ramp, first bytes, stream,
+// reduce, epilogue, boundary to the next launch).
+#if defined(CBX_TRACE) && defined(__HIPCC__)
+#define CBX_TRC_TU                                                                                                                          \
+    __device__ unsigned long long* g_trc_buf = nullptr;                                                                                    \
+    __device__ unsigned* g_trc_cnt = nullptr;                                                                                              \
+    __device__ unsigned g_trc_cap = 0;
+#define CBX_TRC_SETTER(name)                                                                                                                \
+    extern "C" int name(unsigned long long* buf, unsigned* cnt, unsigned cap) {                                                             \
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_trc_buf), &buf, sizeof(buf));                                                         \
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_trc_cnt), &cnt, sizeof(cnt));                                               \
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_trc_cap), &cap, sizeof(cap));                                               \
+        return (int)e;                                                                                                                      \
+    }
+#define CBX_TRC_DECL unsigned long long trc_t[7] = {0, 0, 0, 0, 0, 0, 0}
+#define CBX_TRC_STAMP(k)                                                  \
+    do {                                                                  \
+        if (threadIdx.x == 0) trc_t[k] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define CBX_TRC_FLUSH(tag)                                                                                                   \
+    do {                                                                                                                     \
+        if (threadIdx.x == 0 && g_trc_buf) {                                                                                 \
+            const unsigned i = atomicAdd(g_trc_cnt, 1u);                                                                     \
+            if (i < g_trc_cap) {                                                                                             \
+                unsigned long long* r = g_trc_buf + (unsigned long long)i * 8;                                               \
+                r[0] = (unsigned long long)(tag) << 32 | (unsigned long long)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+                for (int k_ = 0; k_ < 7; ++k_) r[1 + k_] = trc_t[k_];                                                        \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define CBX_TRC_TU
+#define CBX_TRC_SETTER(name)
+#define CBX_TRC_DECL
+#define CBX_TRC_STAMP(k)
+#define CBX_TRC_FLUSH(tag)
+#endif
+
 extern thread_local char cbx_err_buf[512];
 int cbx_set_error(int code, const char* fmt, ...);
 int cbx_check_launch(const char* what);

@@ -23,6 +23,7 @@ extern "C" int cbx_abi_version(void) { return CBX_ABI_VERSION; }
 extern "C" const char* cbx_last_error(void) { return cbx_err_buf; }
 
 namespace {
+CBX_TRC_TU
 
 inline unsigned grid_for(long n, int per_block = 256) {
     long g = (n + per_block - 1) / per_block;
@@ -62,6 +63,8 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* y, long rows, i
 __global__ void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
                              const float* __restrict__ table2, const int* __restrict__ ids2, float* __restrict__ out,
                              long rows, int C, long ld_out, float scale, int flags) {
+    CBX_TRC_DECL;
+    CBX_TRC_STAMP(0);
     const int c4n = C >> 2;
     const long total = rows * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -76,6 +79,12 @@ __global__ void embed_kernel(const long long* __restrict__ ids, const float* __r
             o = ((((r >> 4) * (C >> 5) + (c >> 5)) * 2 + ((c >> 2) & 1)) * 64 + (((c >> 3) & 3) << 4) + (r & 15)) * 4;
         *reinterpret_cast<f32x4*>(out + o) = v;
     }
+#ifdef CBX_TRACE
+    CBX_TRC_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CBX_TRC_STAMP(2);
+    CBX_TRC_FLUSH(0x40000000u);
+#endif
 }
 
 // one 64-lane wave per (row, head): lane d<32 pairs with d+32 (rotate_half form)
@@ -125,6 +134,7 @@ __global__ void cfm_euler_kernel(float* xin, const float* __restrict__ v, int B,
 }
 
 }  // namespace
+CBX_TRC_SETTER(cbx_trace_set_elementwise)
 
 extern "C" int cbx_act_f32(const float* x, float* y, const float* param, long rows, int C, long ldx, long ldy, int act,
                            float slope, void* stream) {

@@ -381,7 +381,8 @@ int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD>;
     constexpr int THREADS = (WARPS_M * WARPS_N + (LD ? 1 : 0)) * 64;
-    static int resident = 0;  // workgroups the chip holds at once (advisory: nothing in the kernel depends on co-residency)
+    static int resident_dev[64] = {0};  // per device ordinal (hipFuncSetAttribute and the CU count are per device): workgroups the chip holds at
+    int& resident = resident_dev[cbx_device()];  // once (advisory: nothing in the kernel depends on co-residency)
     if (!resident) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return cbx_set_error((int)e, "gemm_planes: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

@@ -391,11 +391,12 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NP, int NS = 2, bool F16
 int launch_split(const cbx_gemm_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * NP * (BM + BN) * SLD * sizeof(__bf16);
     auto kern = gemm_split_kernel<BM, BN, WARPS_M, WARPS_N, NP, NS, F16, LD, LN>;
-    static bool configured = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
-    if (!configured) {
+    static unsigned long long configured = 0;  // > 64 KiB of dynamic LDS has to be opted into once per kernel AND device (one bit per ordinal)
+    const int dev = cbx_device();
+    if (!(configured >> dev & 1)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return cbx_set_error((int)e, "gemm_split: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        configured = true;
+        configured |= 1ull << dev;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
     hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());

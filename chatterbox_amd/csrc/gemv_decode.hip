@@ -14,6 +14,7 @@
 #include "cbx_common.h"
 
 namespace {
+CBX_TRC_TU
 
 // PK: W is the lane-ordered packed image (cbx.h "packed GEMV weight layout"): the 2 KiB of a (16-row tile, 32-deep K block) are stored
 // as [h][lane][4 floats], so every wave-level load instruction reads 1 KiB of CONTIGUOUS memory (8 full 128-B lines) instead of
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
     __shared__ float ssq[RMS ? NW * MT * 16 : 1];
     __shared__ float ssx[RMS ? NW * MT * 16 : 1];  // row sums (LayerNorm form only)
+    CBX_TRC_DECL;
+    CBX_TRC_STAMP(0);  // entry
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     // tc = output columns per workgroup: 16, or the narrow tiles 12 / 8 / 4 (cbx_gemv_t.half_tile) that give a projection 4/3, 2 or 4
@@ -113,13 +116,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         ss[t] = 0.f;
         sx[t] = 0.f;
     }
-    // ---- epilogue operands requested FIRST (opt-in: cbx_set_gemv_epilogue_prefetch / p.reserved1, written after the GPU budget of round 3
-    // was spent: emulator-verified, timed by the autotuner).  The element(s) a thread finishes after the reduction are known now; its
+    // ---- epilogue operands requested FIRST (opt-in: cbx_gemv_t.flags & CBX_GEMV_PRE_EPI).  The element(s) a thread finishes after the reduction are known now; its
     // residual, bias and LayerNorm-fold constants do not depend on the contraction, so their loads go out with the first weight batch instead
     // of after the LDS reduction -- where each is a dependent global round trip (~1 us) on the critical path of a launch that lasts 5-9 us.
     // Same values, same order of the additions: results unchanged bit for bit.  (res may alias out: a thread reads exactly the element it
     // writes.)
-    const bool PRE = p.reserved1 != 0;  // uniform (kernel argument)
+    const bool PRE = (p.flags & CBX_GEMV_PRE_EPI) != 0;  // uniform (kernel argument)
     constexpr int EIT = (MT * 256 + NW * 64 - 1) / (NW * 64);
     float e_res[EIT], e_bias[EIT], e_cw[EIT], e_cb[EIT];
     long e_o[EIT];
@@ -194,6 +196,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the issue order block by block, so block d's wait is vmcnt(later blocks)
         }
+#ifdef CBX_TRACE
+        if (it0 == 0) CBX_TRC_STAMP(1);  // first load batch issued
+#endif
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const bool won = on[d] && wok;
@@ -230,8 +235,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef CBX_TRACE
+            if (it0 == 0 && d == 0) {  // first K block multiplied: its loads (weights, x, norm weights, partial images) have landed
+                asm volatile("s_nop 0" ::"v"(acc[0][0]));
+                CBX_TRC_STAMP(2);
+            }
+#endif
         }
     }
+#ifdef CBX_TRACE
+    asm volatile("s_nop 0" ::"v"(acc[0][0]));
+    CBX_TRC_STAMP(3);  // K loop done (wave 0)
+#endif
 
     // ---- fixed-order reduction over the NW K-slices of this workgroup.  D map: row = q*4 + r, col = c.
     float* r1 = red;
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         }
     }
     __syncthreads();
+    CBX_TRC_STAMP(4);  // every wave's partial tile is in LDS
 #pragma unroll
     for (int j = 0; j < EIT; ++j) {
         const int e = tid + j * NW * 64;
@@ -298,8 +314,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
         if (p.res) v += PRE ? e_res[j] : p.res[e_o[j]];  // residual stream in the same layout as out (in place is fine: one thread per element, read before written)
         p.out[e_o[j]] = v;
     }
+#ifdef CBX_TRACE
+    CBX_TRC_STAMP(5);  // epilogue stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CBX_TRC_STAMP(6);  // ... and acknowledged
+    CBX_TRC_FLUSH(0x10000000u | (unsigned)(SWIGLU ? 0x1000000 : 0) | (unsigned)(NP << 20) | (unsigned)(p.N & 0xfffff));
+#endif
 }
 
+// process-wide TEST HOOKS: ORed into cbx_gemv_t.flags of every cbx_gemv_f32 launch (the engines set the flags per launch instead)
 int g_gemv_deep = getenv("CBX_GEMV_DEEP") ? atoi(getenv("CBX_GEMV_DEEP")) : 0;  // cbx_set_gemv_deep_batches
 int g_gemv_pre_epi = getenv("CBX_GEMV_PRE_EPI") ? atoi(getenv("CBX_GEMV_PRE_EPI")) : 0;  // cbx_set_gemv_epilogue_prefetch
 
@@ -310,7 +333,7 @@ int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
     if constexpr (MT == 1 && !SWIGLU && !RMS && (PK == XPK)) {
         if constexpr (PK) {  // a K slice of >= 256 per wave (ABI v9: the down projection with ksplit = 1 on 8 waves): batches of 8 K blocks in flight.
             // 8-wave workgroups only: with 16 waves (128 VGPRs per wave) the 8-deep form spills
-            if (g_gemv_deep && p.nw >= 8 && p.nw != 16 && p.K / (p.ksplit * 8) >= 256) {
+            if ((p.flags & CBX_GEMV_DEEP) && p.nw >= 8 && p.nw != 16 && p.K / (p.ksplit * 8) >= 256) {
                 hipLaunchKernelGGL((gemv_kernel<1, 8, false, true, true, false, 0, WB, true>), grid, dim3(512), 0, st, p);
                 return cbx_check_launch("gemv");
             }
@@ -523,6 +546,7 @@ __global__ __launch_bounds__(256) void pack_gemv_weight_bf16_kernel(const float*
 }
 
 }  // namespace
+CBX_TRC_SETTER(cbx_trace_set_gemv)
 
 extern "C" int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream) {
     CBX_REQUIRE(src && dst && N > 0 && K > 0 && K % 32 == 0 && ld_src % 4 == 0, "pack_gemv_weight_bf16: bad args (K %% 32, ld %% 4)");
@@ -561,7 +585,7 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     cbx_gemv_t p = *pp;
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.nw != 8 && p.nw != 16) p.nw = 4;
-    p.reserved1 = g_gemv_pre_epi != 0;  // the process-wide knob travels to the kernel in the descriptor's spare word
+    p.flags = (p.flags & (CBX_GEMV_PRE_EPI | CBX_GEMV_DEEP)) | (g_gemv_pre_epi ? CBX_GEMV_PRE_EPI : 0) | (g_gemv_deep ? CBX_GEMV_DEEP : 0);
     CBX_REQUIRE(p.x && p.W && p.out, "gemv: null operand");
     CBX_REQUIRE(p.M >= 1 && p.M <= 64 && p.N > 0 && p.K > 0, "gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);

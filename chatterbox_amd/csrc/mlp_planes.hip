@@ -242,11 +242,12 @@ extern "C" int cbx_mlp_planes(const void* h, const void* w1, const void* w2, con
     CBX_REQUIRE(ldx >= D && (((uintptr_t)b1) & 15) == 0, "mlp_planes: ldx >= D, b1 16-byte aligned");
     CBX_REQUIRE(!out_planes || (ldp >= p_lo + D && p_lo > 0 && (ldp | p_lo) % 2 == 0 && ((long)M * ldp + p_lo + D) * 2 < 0x7fffffffL), "mlp_planes: plane output rows hold [h | l]");
     CBX_REQUIRE(write_x || out_planes, "mlp_planes: nothing to write");
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;  // one bit per device ordinal
+    const int dev = cbx_device();
+    if (!(configured >> dev & 1)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
         if (e != hipSuccess) return cbx_set_error((int)e, "mlp_planes: cannot reserve %d B of LDS: %s", MLP_LDS, hipGetErrorString(e));
-        configured = true;
+        configured |= 1ull << dev;
     }
     MlpArgs a{reinterpret_cast<const _Float16*>(h), reinterpret_cast<const _Float16*>(w1), reinterpret_cast<const _Float16*>(w2), b1, b2, x,
               reinterpret_cast<_Float16*>(out_planes), M, F, ldh, h_lo, ldw1, w1_lo, ldw2, w2_lo, ldx, ldp, p_lo, write_x};

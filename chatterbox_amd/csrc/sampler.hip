@@ -9,6 +9,7 @@
 #include "cbx_common.h"
 
 namespace {
+CBX_TRC_TU
 
 constexpr int NT = 1024;
 constexpr int MAXV = 8448;  // >= 8194, multiple of 64
@@ -127,6 +128,8 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     __shared__ double redd[NT / 64];
     __shared__ double wave_base[NT / 64];
     __shared__ int chosen;
+    CBX_TRC_DECL;
+    CBX_TRC_STAMP(0);
 
     const int b = blockIdx.x, tid = threadIdx.x, V = p.V;
     // sampling parameters: by value, or -- so that a captured hipGraph serves requests with different settings without being
@@ -269,9 +272,16 @@ __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
             if (p.ctx_lens) p.ctx_lens[row] += 1;
         }
     }
+#ifdef CBX_TRACE
+    CBX_TRC_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CBX_TRC_STAMP(2);
+    CBX_TRC_FLUSH(0x30000000u);
+#endif
 }
 
 }  // namespace
+CBX_TRC_SETTER(cbx_trace_set_sampler)
 
 extern "C" int cbx_t3_sample(const cbx_sampler_t* p, void* stream) {
     CBX_REQUIRE(p && p->logits && p->seen && p->uniforms && p->step && p->out_tokens && p->done && p->n_generated,

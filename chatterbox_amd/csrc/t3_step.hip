@@ -7,6 +7,21 @@
 // points of this library; all state is caller-owned device memory described by cbx_t3_step_t.
 #include "cbx_common.h"
 
+#ifdef CBX_TRACE
+extern "C" int cbx_trace_set_gemv(unsigned long long*, unsigned*, unsigned);
+extern "C" int cbx_trace_set_attention(unsigned long long*, unsigned*, unsigned);
+extern "C" int cbx_trace_set_sampler(unsigned long long*, unsigned*, unsigned);
+extern "C" int cbx_trace_set_elementwise(unsigned long long*, unsigned*, unsigned);
+// side build only (scripts/trace_decode.sh): device log of 8-word records, its append counter, its capacity in records (cbx_common.h CBX_TRACE)
+extern "C" int cbx_trace_set(unsigned long long* buf, unsigned* cnt, unsigned cap) {
+    int rc = cbx_trace_set_gemv(buf, cnt, cap);
+    if (!rc) rc = cbx_trace_set_attention(buf, cnt, cap);
+    if (!rc) rc = cbx_trace_set_sampler(buf, cnt, cap);
+    if (!rc) rc = cbx_trace_set_elementwise(buf, cnt, cap);
+    return rc;
+}
+#endif
+
 extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     CBX_REQUIRE(d && d->layers && d->n_layers > 0, "t3_decode_step: null descriptor");
     CBX_REQUIRE(d->rows >= 1 && d->rows <= 16, "t3_decode_step: rows=%d (this entry point serves the packed <= 16-row path)", d->rows);
@@ -20,8 +35,13 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     auto base = [&](const float* x, const float* W, float* out, int N, int K) {
         g = cbx_gemv_t{};
         g.x = x, g.W = W, g.out = out, g.M = d->rows, g.N = N, g.K = K, g.ksplit = 1, g.nw = 8;
-        g.w_packed = g.x_packed = 1, g.eps = d->eps, g.ldx = K, g.ldw = K, g.ldo = N, g.w_bf16 = d->w_bf16;
+        g.w_packed = g.x_packed = 1, g.eps = d->eps, g.ldx = K, g.ldw = K, g.ldo = N, g.w_bf16 = d->w_bf16, g.flags = d->gemv_flags;
     };
+    cbx_decode_attn_t da{};  // geometry and split-context workspace of the attention launches: per step descriptor (ABI v10), nothing process-wide
+    da.qkv = d->qkv, da.positions = d->positions, da.cos_t = d->cos_t, da.sin_t = d->sin_t, da.o = d->att, da.rows = d->rows, da.n_heads = H;
+    da.ld_qkv = 3 * D, da.o_ld = D, da.o_packed = 1, da.cache_row_stride = d->kv_row_stride, da.cache_head_stride = d->kv_head_stride;
+    da.scale = d->attn_scale, da.unroll = d->da_unroll, da.pipeline = d->da_pipeline, da.split_min = d->da_split_min;
+    da.split_ws = d->da_ws, da.split_cnt = d->da_cnt, da.split_pairs = d->da_pairs;
     const long img = (long)((d->rows + 15) / 16 * 16) * D;  // floats per packed residual / partial image
     bool pending = false;                                     // split-K partial images of the previous down projection waiting to be summed
     for (int i = 0; i < d->n_layers; ++i) {
@@ -35,9 +55,8 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
             cur = nxt, nxt = t;
         }
         const long kv_layer = (long)d->rows * d->kv_row_stride;
-        if ((rc = cbx_decode_attn_rope_f32(d->qkv, d->positions, d->cos_t, d->sin_t, d->kc + i * kv_layer, d->vc + i * kv_layer, d->att, d->rows,
-                                           H, 3 * D, D, 1, d->kv_row_stride, d->kv_head_stride, d->attn_scale, stream)))
-            return rc;
+        da.kc = d->kc + i * kv_layer, da.vc = d->vc + i * kv_layer;
+        if ((rc = cbx_decode_attn_rope(&da, stream))) return rc;
         base(d->att, L.wo, cur, D, D);
         g.nw = d->o_nw, g.res = cur, g.out_packed = 1, g.half_tile = d->half_tiles;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;

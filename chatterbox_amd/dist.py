@@ -40,9 +40,10 @@ def _unflatten(flat, meta):
     return (dict(zip(_T3_KEYS, out[:3])), dict(zip(_GEN_KEYS, out[3:]), prompt_feat_len=None))
 
 
-def broadcast_conditionals(t3_cond, gen_ref, src=0, device=None):
-    """C1: every rank returns (t3_cond, gen_ref) of `src`.  Non-src ranks may pass None."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_conditionals(t3_cond, gen_ref, src=0, device=None, force=False):
+    """C1: every rank returns (t3_cond, gen_ref) of `src`.  Non-src ranks may pass None.  force: run the collectives even in a group of one
+    (what a single GPU can exercise of the RCCL path)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return t3_cond, gen_ref
     rank = dist.get_rank()
     obj = [None]
@@ -58,12 +59,12 @@ def broadcast_conditionals(t3_cond, gen_ref, src=0, device=None):
     return t3c, gen
 
 
-def gather_waveforms(wavs, dst=0):
+def gather_waveforms(wavs, dst=0, force=False):
     """C2: `wavs` is this rank's list of 1-D float tensors.  Returns, on rank `dst`, the list over all ranks in rank
     order (CPU tensors); None elsewhere.  A real gather-to-`dst`: every rank all-gathers two int64 (its utterance count and
     longest waveform) so that all agree on the padded block shape, then ONE `dist.gather` of the padded (n_max, L_max) fp32 block
     and one of the int32 lengths -- only `dst` receives the 31 MB / rank, the other ranks send and are done."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return [w.detach().cpu() for w in wavs]
     world, rank = dist.get_world_size(), dist.get_rank()
     # nccl (= RCCL) collectives need device tensors on THIS rank's GPU whatever the inputs are (host copies, an empty shard);

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
+from ._lib import GEMV_DEEP, GEMV_PRE_EPI, DecodeAttnParams, GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -371,23 +371,24 @@ def pack_gemv_weight(w, swiglu=False, half_tile=False, bf16=False):
 
 
 def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False):
+         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
     out_packed: out is written in the packed operand layout of the next gemv (ksplit > 1: out (ksplit, rows16, N) partial images);
     half_tile (True = 8, or 12 / 4): output columns per workgroup, w being the pack_gemv_weight image of that tile width;
-    xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart)."""
+    xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart);
+    flags: cbx_gemv_t.flags (GEMV_PRE_EPI | GEMV_DEEP: per-launch geometry bits, results unchanged)."""
     p, M, N, K = _gemv_params(x, w, out, N=N, bias=bias, ksplit=ksplit, nw=nw, swiglu=swiglu, act=act, w_packed=w_packed, x_packed=x_packed, M=M, K=K,
                               norm_w=norm_w, eps=eps, res=res, out_packed=out_packed, xpart=xpart, x_out=x_out, ln_cw=ln_cw, ln_cb=ln_cb,
-                              half_tile=half_tile)
+                              half_tile=half_tile, flags=flags)
     _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
            lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
     return out
 
 
 def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-                 norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False):
+                 norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0):
     """The cbx_gemv_t descriptor of a gemv() call: (descriptor, M, N, K)."""
     if x_packed:
         assert w_packed and M is not None and K is not None
@@ -403,6 +404,7 @@ def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, 
     p.w_packed, p.x_packed, p.half_tile, p.w_bf16 = int(w_packed), int(x_packed), _tile_rows(half_tile), int(w_bf16)
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
+    p.flags = int(flags)
     if xpart is not None:
         p.n_xpart, p.xpart, p.xpart_stride, p.x_out = xpart.shape[0], _p(_f32(xpart, "xpart")), xpart.stride(0), _p(x_out)
     if ksplit > 1:
@@ -411,36 +413,6 @@ def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, 
     else:
         p.ldo, p.part_stride = out.stride(0), 0
     return p, M, N, K
-
-
-PAIR_SPINS = int(os.environ.get("CBX_PAIR_SPINS", "0"))  # polls before a consumer of gemv_pair / gemv_chain gives up (0: the library's 65536)
-
-
-def gemv_chain(ops4, sync_ws, spins=0):
-    """Four dependent decode GEMVs in ONE launch (cbx_gemv_chain_f32): ops4 = the (x, w, out, kwargs) of the gemv() calls o projection, gate | up,
-    down projection, next q/k/v (or the head); sync_ws: 64 int32, zeroed once (sync_ws[63] is raised if a wait ever ran out)."""
-    assert len(ops4) == 4 and sync_ws.dtype == torch.int32 and sync_ws.numel() >= 64
-    arr = (GemvParams * 4)()
-    fl = 0.0
-    for r, (x, w, out, kw) in enumerate(ops4):
-        p, M, N, K = _gemv_params(x, w, out, **kw)
-        arr[r] = p
-        fl += N * K * (2 if kw.get("swiglu") else 1)
-    _timed("gemv_f32", 2.0 * M * fl, 4.0 * fl, lambda: check(lib.cbx_gemv_chain_f32(arr, _p(sync_ws), int(spins or PAIR_SPINS), _stream()), "cbx_gemv_chain_f32"))
-    return ops4[3][2]
-
-
-def gemv_pair(producer, consumer, sync_ws, spins=0):
-    """Two dependent decode GEMVs in ONE launch (cbx_gemv_pair_f32): `producer` / `consumer` are the (x, w, out, kwargs) of the two gemv()
-    calls it replaces -- a plain packed GEMV (+ residual) and the RMSNorm-folded SwiGLU GEMV that reads its output; sync_ws: 10 int32, zeroed
-    once (arrival counters, re-armed by the kernel; sync_ws[9] is raised if a consumer's wait ever ran out)."""
-    (xa, wa, oa, ka), (xb, wb, ob, kb) = producer, consumer
-    pa, M, Na, Ka = _gemv_params(xa, wa, oa, **ka)
-    pb, _, Nb, Kb = _gemv_params(xb, wb, ob, **kb)
-    assert sync_ws.dtype == torch.int32 and sync_ws.numel() >= 10
-    _timed("gemv_f32", 2.0 * M * (Na * Ka + 2 * Nb * Kb), 4.0 * (Na * Ka + 2 * Nb * Kb),
-           lambda: check(lib.cbx_gemv_pair_f32(ctypes.byref(pa), ctypes.byref(pb), _p(sync_ws), int(spins or PAIR_SPINS), _stream()), "cbx_gemv_pair_f32"))
-    return ob
 
 
 def add_rmsnorm(x, part, w, h, eps=1e-5, bias=None, rms=True):
@@ -498,12 +470,12 @@ def decode_attn(q, kc, vc, out, ctx_lens, scale):
     return out
 
 
-_DA_WS = {}  # device index -> (partials, arrival counters) of the split-context decode attention
+_DA_WS = {}  # device index -> (partials, arrival counters) of the split-context decode attention: the TEST-HOOK workspace of the positional entry
 
 
 def ensure_decode_attn_workspace(device):
-    """Register, once per device, the workspace cbx_decode_attn_rope_f32 splits a context through when rows * heads < 128
-    (called by the T3 engines at construction: an allocation + fill must not happen inside a stream capture)."""
+    """TEST HOOK: register, once per device, the process-wide workspace the POSITIONAL cbx_decode_attn_rope_f32 splits a context through when
+    rows * heads < 128 (op-level tests; single-stream use).  The engines own a DecodeAttnGeom each instead."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     if idx in _DA_WS:
@@ -516,14 +488,43 @@ def ensure_decode_attn_workspace(device):
     _DA_WS[idx] = (ws, cnt)
 
 
-def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False):
+class DecodeAttnGeom:
+    """Geometry + CALLER-OWNED split-context workspace of cbx_decode_attn_rope (cbx_decode_attn_t, ABI v10).  One per engine state (i.e. per
+    stream of launches that may be in flight together): nothing of it is process-wide, so two engines in one process -- or a hipGraph captured
+    before another engine changed its geometry -- keep their own.  Allocate outside stream captures (the engines do it at construction)."""
+
+    def __init__(self, device, unroll=0, pipeline=0, split_min=0, max_pairs=128, split=True):
+        dev = torch.device(device)
+        self.unroll, self.pipeline, self.split_min, self.max_pairs = int(unroll), int(pipeline), int(split_min), int(max_pairs)
+        self.ws = torch.empty(max_pairs * 8 * 66, dtype=torch.float32, device=dev) if split else None
+        self.cnt = torch.zeros(max_pairs, dtype=torch.int32, device=dev) if split else None
+
+    def fill(self, p):
+        p.unroll, p.pipeline, p.split_min = self.unroll, self.pipeline, self.split_min
+        p.split_ws, p.split_cnt, p.split_pairs = _p(self.ws), _p(self.cnt), (self.max_pairs if self.ws is not None else 0)
+
+
+def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False, geom=None):
     """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)
-    [out_packed: the packed operand image of the o-projection gemv, (ceil(rows/16)*16, H*64)]."""
+    [out_packed: the packed operand image of the o-projection gemv, (ceil(rows/16)*16, H*64)].
+    geom: a DecodeAttnGeom (the engines: geometry and workspace per call); None = the positional entry point on the process-wide test hooks."""
     rows, H = kc.shape[0], kc.shape[1]
-    check(lib.cbx_decode_attn_rope_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out), rows, H,
-                                       qkv.stride(0), out.stride(0), int(out_packed), kc.stride(0), kc.stride(1), scale, _stream()),
-          "cbx_decode_attn_rope_f32")
+    if geom is None:
+        check(lib.cbx_decode_attn_rope_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out), rows, H,
+                                           qkv.stride(0), out.stride(0), int(out_packed), kc.stride(0), kc.stride(1), scale, _stream()),
+              "cbx_decode_attn_rope_f32")
+        return out
+    p = DecodeAttnParams()
+    p.qkv, p.positions, p.cos_t, p.sin_t, p.kc, p.vc, p.o = _p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out)
+    p.rows, p.n_heads, p.ld_qkv, p.o_ld, p.o_packed = rows, H, qkv.stride(0), out.stride(0), int(out_packed)
+    p.cache_row_stride, p.cache_head_stride, p.scale = kc.stride(0), kc.stride(1), scale
+    geom.fill(p)
+    check(lib.cbx_decode_attn_rope(ctypes.byref(p), _stream()), "cbx_decode_attn_rope")
     return out
+
+
+def gemv_flags(pre_epi=0, deep=0):
+    return (GEMV_PRE_EPI if pre_epi else 0) | (GEMV_DEEP if deep else 0)
 
 
 def softmax_relpos(ac, bd, p, scale, key_lens=None):

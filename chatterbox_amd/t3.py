@@ -43,12 +43,11 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, pair_ogu=0, pair_dq=0, chain=0)
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
         self.dev = torch.device(device)
-        ops.ensure_decode_attn_workspace(self.dev)
         if n_layers is None:
             n_layers = 0
             while f"tfmr.layers.{n_layers}.input_layernorm.weight" in sd:
@@ -105,6 +104,7 @@ class T3Engine:
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"  # token step through the stage-level C entry point (same kernels)
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
         self.tune = self._env_tune()
+        self.knobs = self._env_knobs()
 
     # ------------------------------------------------------------------ packed device layout <-> disk (formats.save_packed / load_packed)
     _PLAIN = ("norm", "text_emb", "speech_emb", "text_pos", "speech_pos", "head", "head_pk", "spkr_w", "spkr_b", "emo_w", "pq", "cos", "sin")
@@ -141,6 +141,7 @@ class T3Engine:
         self.time_decode, self.decode_events = False, []
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"
         self.tune = cls._env_tune()
+        self.knobs = cls._env_knobs()
         return self
 
     @classmethod
@@ -151,6 +152,19 @@ class T3Engine:
             assert k.strip() in tune, f"CBX_T3_TUNE: unknown knob {k!r} (known: {sorted(tune)})"
             tune[k.strip()] = int(v)
         return tune
+
+    @staticmethod
+    def _env_knobs():
+        """Per-ENGINE launch knobs of the decode attention / GEMVs (da_pipe, da_u, deep, pre_epi): they travel in every call's descriptor
+        (cbx_decode_attn_t, cbx_gemv_t.flags; ABI v10), nothing is process-wide.  Defaults from CBX_DA_PIPE / CBX_DA_U / CBX_GEMV_* (A/B scripts)."""
+        from .autotune import env_knobs
+        return env_knobs()
+
+    def _gf(self):
+        return ops.gemv_flags(self.knobs.get("pre_epi"), self.knobs.get("deep"))
+
+    def _sync_geom(self, st):
+        st["da"].unroll, st["da"].pipeline = (0 if int(self.knobs["da_u"]) == 4 else int(self.knobs["da_u"])), int(self.knobs["da_pipe"])
 
     def _tiles(self):
         """(q/k/v tile width, o / down tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
@@ -176,19 +190,17 @@ class T3Engine:
 
     # ------------------------------------------------------------------ decode-step geometry: measured, not guessed (autotune.py)
     def apply_variant(self, tune, knobs=None):
-        """Switch the decode geometry: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep, pre_epi) are the process-wide library knobs of the
-        decode attention / GEMV load batches.  Captured decode graphs and C step descriptors bake the geometry in: they are dropped."""
+        """Switch the decode geometry of THIS engine: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep, pre_epi) the launch knobs of the
+        decode attention / GEMV load batches -- per-call descriptor fields since ABI v10, so another engine in the process keeps its own.
+        Captured decode graphs and C step descriptors bake the geometry in: they are dropped."""
         from .autotune import LIB_KNOBS
         self.tune = dict(tune)
-        k = dict(LIB_KNOBS, **(knobs or {}))
-        ops.lib.cbx_set_decode_attn_pipeline(int(k["da_pipe"]))
-        ops.lib.cbx_set_decode_attn_unroll(int(k["da_u"]))
-        ops.lib.cbx_set_gemv_deep_batches(int(k["deep"]))
-        ops.lib.cbx_set_gemv_epilogue_prefetch(int(k["pre_epi"]))
-        self.lib_knobs = k
+        self.knobs = dict(LIB_KNOBS, **(knobs or {}))
+        assert int(self.knobs["da_pipe"]) in range(8) and int(self.knobs["da_u"]) in (4, 8, 16)
         for st in self._state.values():
             st["graph"] = None
             st.pop("cstep", None)
+            self._sync_geom(st)
 
     @ops.on_device
     @torch.inference_mode()
@@ -249,15 +261,44 @@ class T3Engine:
             best = min(best, ms / steps)
         if cuda:
             torch.cuda.synchronize()
-        # the state the whole run ended in (a pure function of the seed and of the arithmetic): two geometries that claim the same arithmetic --
-        # a chained launch and its separate launches -- must agree on it bit for bit; the error word of the producer / consumer launches must be 0
-        self.last_measure = dict(final_logits=st["logits"].clone(), out_tokens=st["out_tokens"].clone(), sync_clean=not bool(st["dws"]["pair_ws"].any()))
+        # the state the whole run ended in (a pure function of the seed and of the arithmetic)
+        self.last_measure = dict(final_logits=st["logits"].clone(), out_tokens=st["out_tokens"].clone())
         st["graph"] = None
         st.pop("cstep", None)
         return best, logits
 
+    @ops.on_device
+    @torch.inference_mode()
+    def probe_decode(self, B=8, ctxs=(1, 38, 63, 64, 65, 225, 640), slot=7):
+        """Logits of ONE token step per entry of `ctxs` on a seeded synthetic state whose rows hold RAGGED contexts (row r: (c - 1 + 37 r) mod
+        704 cached positions): what two geometries that claim the same arithmetic must agree on bit for bit.  The autotuner's identity check
+        (one step at the bench context never looked at contexts shorter than one 64-position attention step, or at the split grid)."""
+        rows, max_ctx = 2 * B, 704
+        st = self._get_state(B, max_ctx, 4, slot)
+        self._prepare_tune()
+        st["graph"] = None
+        st.pop("cstep", None)
+        gen = torch.Generator(device=self.dev).manual_seed(20250922)
+        for k in ("kc", "vc"):
+            st[k].normal_(0.0, 0.5, generator=gen)
+        st["uniforms"].uniform_(generator=gen)
+        st["samp_dev"].copy_(torch.tensor([0.5, 0.8, 0.05, 1.0, 1.2, 0.0, float(STOP_SPEECH), 6561.0]).repeat(B, 1))
+        ids = torch.tensor([(911 * b + 17) % 6561 for b in range(B)] * 2, dtype=torch.int64)
+        out = []
+        for c in ctxs:
+            for k in ("seen", "step", "done", "n_generated", "out_tokens"):
+                st[k].zero_()
+            pos = torch.tensor([(c - 1 + 37 * r) % (max_ctx - 8) for r in range(rows)], dtype=torch.int32)
+            st["next_ids"].copy_(ids)
+            st["next_pos_ids"].fill_(1)
+            st["positions"].copy_(pos)
+            st["ctx_lens"].copy_(pos + 1)
+            self._decode_step(st)
+            out.append(st["logits"].clone())
+        return torch.stack(out)
+
     def autotune(self, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorder=False, in_child=True, timeout=180.0, log=None, tiles=None, attn=None,
-                 epi=None, chain=None, validate=None):
+                 epi=None, validate=None, green_only=False):
         """Measure the decode-step geometries (autotune.py) and adopt the fastest one whose logits are bit-identical to the current
         geometry's.  in_child: the candidates run in a child process on synthetic weights of this shape, so a faulting candidate cannot take
         the serving process down; its failure leaves the geometry unchanged.  validate: a callable run on THIS engine after the fastest
@@ -265,17 +306,17 @@ class T3Engine:
         callable returns True (e.g. "the serving workload's tokens are the ones the built-in geometry samples"), otherwise the bit-identical
         winner is.  Returns the report (also kept as self.autotune_report)."""
         from . import autotune as at
-        knobs = dict(getattr(self, "lib_knobs", None) or at.env_knobs())
+        knobs = dict(self.knobs)
         tune0 = dict(self.tune)
         if self.decode_mode != "v2" or 2 * B > 16:
             rep = dict(best={}, skipped="the tile / pipeline variants serve the packed <= 16-row decode path")
         elif in_child:
             base = {k: v for k, v in self.tune.items() if v != self._TUNE.get(k)}
-            rep = at.tune_in_child(self.L, B, ctx, steps, reps, min_gain, allow_reorder, self.dev.index or 0, base, knobs, timeout, log)
+            rep = at.tune_in_child(self.L, B, ctx, steps, reps, min_gain, allow_reorder, self.dev.index or 0, base, knobs, timeout, log, green_only=green_only)
         else:
             rep = at.tune_decode(self, B, ctx, steps, reps, min_gain, allow_reorder, use_graph=self.dev.type == "cuda", log=log,
                                  tiles=tiles or at.TILE_VARIANTS, attn=at.ATTN_VARIANTS if attn is None else attn,
-                                 epi=at.EPI_VARIANTS if epi is None else epi, chain=at.CHAIN_VARIANTS if chain is None else chain)
+                                 epi=at.EPI_VARIANTS if epi is None else epi, green_only=green_only)
 
         def adopt(v):
             t, k = at.split_variant(v)
@@ -365,7 +406,7 @@ class T3Engine:
         for i, lw in enumerate(self.layers):
             ops.add_rmsnorm(x, part, lw["ln1"], h)
             ops.gemv(h, lw["wqkv"], qkv, nw=tn["qkv_nw"])
-            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125)
+            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, geom=st["da"])
             ops.gemv(att, lw["wo"], po, ksplit=tn["o_ks"], nw=4)
             ops.add_rmsnorm(x, po, lw["ln2"], h)
             ops.gemv(h, lw["wgu"], g, swiglu=True, nw=tn["gu_nw"])
@@ -383,55 +424,23 @@ class T3Engine:
         ws, tn = st["dws"], self.tune
         rows, dks = st["rows"], tn["d_ks2"]
         cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"][:dks]
-        pk = dict(w_packed=True, x_packed=True, M=rows)
+        pk = dict(w_packed=True, x_packed=True, M=rows, flags=self._gf())
         ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.speech_pos, ids2=st["next_pos_ids"], out_packed=True)
         red = {}  # partial images pending on the residual stream
         qtc, odtc = self._tiles()
         qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
-        pair = bool(tn.get("pair_ogu")) and tn["o_nw2"] == 8 and tn["gu_nw"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
-        # pair_dq (with d_ks2 = 1, d_nw2 = 8): the down projection of layer i and the q/k/v GEMV of layer i + 1 in ONE launch as well -- then a
-        # layer is 3 launches (attention, o + gate | up, down + next q/k/v) instead of 5
-        pair_dq = bool(tn.get("pair_dq")) and dks == 1 and tn["d_nw2"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
-        q_kw = lambda lw: dict(N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk)
-        # chain (same preconditions): o -> gate | up -> down -> next q/k/v (behind the last layer: the head) in ONE launch: 2 launches per layer
-        chain = bool(tn.get("chain")) and dks == 1 and tn["d_nw2"] == 8 and tn["o_nw2"] == 8 and tn["gu_nw"] == 8 and self.layers[0]["wgu_pk"].dtype == torch.float32
-        if chain:
-            ops.gemv(cur, self._image(self.layers[0], "wqkv", qtc), qkv, **q_kw(self.layers[0]))
-            for i, lw in enumerate(self.layers):
-                ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-                res_kw = dict(nw=8, res=cur, out_packed=True, half_tile=ot, **pk)
-                if i + 1 < len(self.layers):
-                    nl = self.layers[i + 1]
-                    last = (cur, self._image(nl, "wqkv", qtc), qkv, q_kw(nl))
-                else:
-                    last = (cur, self.head_pk, st["logits"], dict(N=self.V, K=self.D, nw=8, norm_w=self.norm, **pk))
-                ops.gemv_chain([(att, self._image(lw, "wo", odtc), cur, dict(N=self.D, K=self.D, **res_kw)),
-                                (cur, lw["wgu_pk"], g, dict(N=self.F, K=self.D, swiglu=True, nw=8, norm_w=lw["ln2"], out_packed=True, **pk)),
-                                (g, self._image(lw, "wd", odtc), cur, dict(N=self.D, K=self.F, **res_kw)), last], ws["pair_ws"])
-            return
         for i, lw in enumerate(self.layers):
-            if not (pair_dq and i > 0):  # (else: launched together with the previous layer's down projection)
-                ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, **q_kw(lw), **red)
+            ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk, **red)
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
-            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-            o_kw = dict(N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
-            gu_kw = dict(N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
-            if pair:  # o projection and gate | up in ONE launch (cbx_gemv_pair_f32: opt-in, emulator-verified, never run on hardware)
-                ops.gemv_pair((att, self._image(lw, "wo", odtc), cur, o_kw), (cur, lw["wgu_pk"], g, gu_kw), ws["pair_ws"])
-            else:
-                ops.gemv(att, self._image(lw, "wo", odtc), cur, **o_kw)
-                ops.gemv(cur, lw["wgu_pk"], g, **gu_kw)
+            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True, geom=st["da"])
+            ops.gemv(att, self._image(lw, "wo", odtc), cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
+            ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
             if dks > 1:
                 ops.gemv(g, self._image(lw, "wd", odtc), pd, N=self.D, K=self.F, ksplit=dks, nw=tn["d_nw2"], out_packed=True, half_tile=ot, **pk)
                 red = dict(xpart=pd, x_out=nxt)
             else:  # the down projection adds the residual itself: no partial images, no fold in the next q/k/v GEMV
-                d_kw = dict(N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
-                if pair_dq and i + 1 < len(self.layers):
-                    nl = self.layers[i + 1]
-                    ops.gemv_pair((g, self._image(lw, "wd", odtc), cur, d_kw), (cur, self._image(nl, "wqkv", qtc), qkv, q_kw(nl)), ws["pair_ws"])
-                else:
-                    ops.gemv(g, self._image(lw, "wd", odtc), cur, **d_kw)
+                ops.gemv(g, self._image(lw, "wd", odtc), cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
         if red:
             red["x_out"] = None
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, **red, **pk)
@@ -442,7 +451,7 @@ class T3Engine:
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4) and not (self.tune.get("pair_ogu") or self.tune.get("pair_dq") or self.tune.get("chain")):
+        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
@@ -479,6 +488,9 @@ class T3Engine:
             d.next_ids, d.next_pos_ids, d.positions = p(st["next_ids"]), p(st["next_pos_ids"]), p(st["positions"])
             d.x_a, d.x_b, d.qkv, d.att, d.g, d.pd = p(ws["x_pk"]), p(ws["x2_pk"]), p(ws["qkv"]), p(ws["att_pk"]), p(ws["g_pk"]), p(ws["pd_pk"])
             d.logits, d.ld_logits, d.sampler = p(st["logits"]), st["logits"].stride(0), ctypes.pointer(sp)
+            da = st["da"]  # the step's own attention geometry + split-context workspace, GEMV flags (ABI v10: nothing process-wide)
+            d.da_unroll, d.da_pipeline, d.da_split_min, d.gemv_flags = da.unroll, da.pipeline, da.split_min, self._gf()
+            d.da_ws, d.da_cnt, d.da_pairs = p(da.ws), p(da.cnt), da.max_pairs
             st["cstep"] = (d, layers, sp)  # keep the host structures alive
         check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
 
@@ -515,9 +527,11 @@ class T3Engine:
                            att_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
-                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev),
-                           pair_ws=torch.zeros(64, dtype=torch.int32, device=dev)),  # cbx_gemv_pair_f32 / _chain_f32 arrival counters (zeroed once)
-                  graph=None, samp_dev=torch.zeros(B, 8, device=dev))
+                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
+                  graph=None, samp_dev=torch.zeros(B, 8, device=dev),
+                  # geometry + split-context workspace of this state's attention launches (a state = one stream of launches; two slots may be in flight)
+                  da=ops.DecodeAttnGeom(dev, split=rows * self.H < 128))
+        self._sync_geom(st)
         self._state[key] = st
         return st
 

@@ -19,7 +19,6 @@ class T3TurboEngine:
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None):
         self.dev = dev = torch.device(device)
-        ops.ensure_decode_attn_workspace(self.dev)
         if n_layers is None:
             n_layers = 0
             while f"tfmr.h.{n_layers}.ln_1.weight" in sd:
@@ -43,10 +42,14 @@ class T3TurboEngine:
         # 8-column tiles for the two N = D projections (twice the workgroups), split-K factor / waves of the MLP projection;
         # qkv_tc = 12 / od_tc = 4 (ABI v9): c_attn resp. the two N = D projections on N / 12 resp. N / 4 workgroups, d_ks = 1: the MLP
         # projection adds bias + residual itself (no partial images, no fold in the next c_attn GEMV)
-        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, chain=0)
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0)
         for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
             k, v = kv.split("=")
+            assert k.strip() in self.tune, f"CBX_TURBO_TUNE: unknown knob {k!r} (known: {sorted(self.tune)})"
             self.tune[k.strip()] = int(v)
+        # launch knobs of the decode attention / GEMVs, per ENGINE (they travel in every call's descriptor: cbx_decode_attn_t, cbx_gemv_t.flags)
+        from .autotune import env_knobs
+        self.knobs = env_knobs()
         for lw in self.layers:
             for k in ("wqkv", "wo", "wfc", "wpr"):
                 lw[k + "_pk"] = ops.pack_gemv_weight(lw[k])
@@ -86,7 +89,7 @@ class T3TurboEngine:
         for i, lw in enumerate(self.layers):
             ops.add_rmsnorm(x, part, lw["ln1"][0], h, bias=lw["ln1"][1], rms=False)
             ops.gemv(h, lw["wqkv_pk"], qkv, N=3 * self.D, bias=lw["bqkv"], nw=8, w_packed=True)
-            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125)
+            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, geom=st["da"])
             ops.gemv(att, lw["wo_pk"], po, N=self.D, bias=lw["bo"], ksplit=self.ks_o, nw=4, w_packed=True)
             ops.add_rmsnorm(x, po, lw["ln2"][0], h, bias=lw["ln2"][1], rms=False)
             ops.gemv(h, lw["wfc_pk"], g, N=4 * self.D, bias=lw["bfc"], nw=8, act=ops.GELU_TANH, w_packed=True)
@@ -105,33 +108,15 @@ class T3TurboEngine:
         qtc, odtc = self._tiles()
         qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
         cur, nxt, qkv, att, g, pd = ws["x_pk"], ws["x2_pk"], ws["qkv"], ws["att_pk"], ws["g_pk"], ws["pd_pk"][:dks]
-        pk = dict(w_packed=True, x_packed=True, M=B)
+        pk = dict(w_packed=True, x_packed=True, M=B, flags=ops.gemv_flags(self.knobs.get("pre_epi"), self.knobs.get("deep")))
         ops.embed(st["next_ids"], self.speech_emb, cur, table2=self.wpe, ids2=st["positions"], out_packed=True)
         red = {}
-        q_kw = lambda lw: dict(N=3 * D, K=D, nw=8, norm_w=lw["ln1"][0], ln_cw=lw["c_qkv"][0], ln_cb=lw["c_qkv"][1], half_tile=qt, **pk)
-        if tn.get("chain") and dks == 1 and tn["d_nw"] == 8 and tn["o_nw"] == 8 and self.head_pk.dtype == torch.float32:
-            # c_proj -> ln_2 + c_fc + gelu -> mlp c_proj -> ln_1 + c_attn of the next layer (behind the last: ln_f + head) as ONE launch
-            # (cbx_gemv_chain_f32: opt-in, emulator-verified, never run on hardware): attention + 1 launch per GPT-2 layer
-            ops.gemv(cur, self._image(self.layers[0], "wqkv", qtc), qkv, **q_kw(self.layers[0]))
-            for i, lw in enumerate(self.layers):
-                ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
-                res_kw = dict(nw=8, res=cur, out_packed=True, half_tile=ot, **pk)
-                if i + 1 < len(self.layers):
-                    nl = self.layers[i + 1]
-                    last = (cur, self._image(nl, "wqkv", qtc), qkv, q_kw(nl))
-                else:
-                    last = (cur, self.head_pk, st["logits"], dict(N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1], **pk))
-                ops.gemv_chain([(att, self._image(lw, "wo", odtc), cur, dict(N=D, K=D, bias=lw["bo"], **res_kw)),
-                                (cur, lw["wfc_pk"], g, dict(N=4 * D, K=D, nw=8, norm_w=lw["ln2"][0], ln_cw=lw["c_fc"][0], ln_cb=lw["c_fc"][1],
-                                                            act=ops.GELU_TANH, out_packed=True, **pk)),
-                                (g, self._image(lw, "wpr", odtc), cur, dict(N=D, K=4 * D, bias=lw["bpr"], **res_kw)), last], ws["pair_ws"])
-            return
         for i, lw in enumerate(self.layers):
             ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * D, K=D, nw=8, norm_w=lw["ln1"][0], ln_cw=lw["c_qkv"][0], ln_cb=lw["c_qkv"][1],
                      half_tile=qt, **red, **pk)
             if red:
                 cur, nxt = nxt, cur
-            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True)
+            ops.decode_attn_rope(qkv, st["positions"], None, None, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True, geom=st["da"])
             ops.gemv(att, self._image(lw, "wo", odtc), cur, N=D, K=D, nw=tn["o_nw"], bias=lw["bo"], res=cur, out_packed=True, half_tile=ot, **pk)
             ops.gemv(cur, lw["wfc_pk"], g, N=4 * D, K=D, nw=8, norm_w=lw["ln2"][0], ln_cw=lw["c_fc"][0], ln_cb=lw["c_fc"][1],
                      act=ops.GELU_TANH, out_packed=True, **pk)
@@ -195,9 +180,11 @@ class T3TurboEngine:
                            # packed operand images of the v2 path (rows padded to a 16-row tile, pad rows stay 0)
                            x_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), x2_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev),
                            att_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), g_pk=torch.zeros((B + 15) // 16 * 16, 4 * D, device=dev),
-                           pd_pk=torch.zeros(4, (B + 15) // 16 * 16, D, device=dev),
-                           pair_ws=torch.zeros(64, dtype=torch.int32, device=dev)),  # cbx_gemv_chain_f32 arrival counters (zeroed once)
-                  graph=None, samp_dev=torch.zeros(B, 8, device=dev))
+                           pd_pk=torch.zeros(4, (B + 15) // 16 * 16, D, device=dev)),
+                  graph=None, samp_dev=torch.zeros(B, 8, device=dev),
+                  # geometry + caller-owned split-context workspace of this state's attention launches (cbx_decode_attn_t, ABI v10)
+                  da=ops.DecodeAttnGeom(dev, unroll=0 if int(self.knobs["da_u"]) == 4 else int(self.knobs["da_u"]), pipeline=int(self.knobs["da_pipe"]),
+                                        split=B * self.H < 128))
         self._state[key] = st
         return st
 

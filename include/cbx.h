@@ -15,11 +15,14 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 9  /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 10 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
-                              9: 12- and 4-column decode GEMV tiles (cbx_gemv_t.half_tile = 12 / 4), cbx_t3_step_t.qkv_tile, d_ksplit = 1 */
+                              9: 12- and 4-column decode GEMV tiles (cbx_gemv_t.half_tile = 12 / 4), cbx_t3_step_t.qkv_tile, d_ksplit = 1;
+                              10: no process-wide state on the decode path -- cbx_decode_attn_t / cbx_decode_attn_rope (geometry and the split-context
+                                  workspace per call), cbx_gemv_t.flags, cbx_t3_step_t.da_* / gemv_flags; the cbx_set_* setters remain as TEST HOOKS of
+                                  the positional entry points only */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -171,7 +174,7 @@ typedef struct cbx_gemv_t {
     long xpart_stride;
     float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it) */
     int w_bf16;          /* W is a cbx_pack_gemv_weight_bf16 image (opt-in: weights rounded to bf16, half the streamed bytes; M <= 16) */
-    int reserved1;
+    int flags;           /* (was reserved1) ABI v10, CBX_GEMV_* bits below; 0 = the plain launch */
     const float* ln_cw;  /* or NULL: LayerNorm instead of RMSNorm (GPT-2 ln_1 / ln_2 / ln_f): with norm_w = LN weight w, ln_cw[n] = */
     const float* ln_cb;  /* sum_k w[k] W[n][k] and ln_cb[n] = sum_k b[k] W[n][k] + bias[n] (constants of the layer, computed at load): */
                          /* out[m][n] = rstd[m] (sum_k x w W - mean[m] ln_cw[n]) + ln_cb[n], then `act` */
@@ -187,34 +190,16 @@ int cbx_pack_gemv_weight_f32(const float* src, float* dst, int N, int K, long ld
 /* the same image with the weights rounded (RNE) to bf16: [tile][K/32][lanes][8 bf16] (cbx_gemv_t.w_bf16); dst holds half the bytes */
 int cbx_pack_gemv_weight_bf16(const float* src, void* dst, int N, int K, long ld_src, int swiglu, void* stream);
 int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
-/* ABI v9, A/B knob (env CBX_GEMV_DEEP, default 0): 1 = an 8-wave plain packed GEMV whose waves own >= 256 of K (the down projection with
- * ksplit = 1) requests 8 K blocks per batch instead of 4 -- half the dependent load batches; bit-identical results. */
+/* cbx_gemv_t.flags (ABI v10: per launch, set by the caller -- the engines carry them in their own tune, nothing process-wide):
+ * CBX_GEMV_PRE_EPI: the launch requests the operands of its epilogue (residual element, bias, LayerNorm-fold constants) together with its first
+ *   weight batch instead of after the reduction -- one dependent memory round trip less; same values added in the same order.
+ * CBX_GEMV_DEEP: an 8-wave plain packed GEMV whose waves own >= 256 of K (the down projection with ksplit = 1) requests 8 K blocks per batch
+ *   instead of 4 -- half the dependent load batches.  Both: results unchanged bit for bit (tests/test_zz_abi_v9_gpu.py, on hardware). */
+#define CBX_GEMV_PRE_EPI 1
+#define CBX_GEMV_DEEP 2
+/* TEST HOOKS (env CBX_GEMV_DEEP / CBX_GEMV_PRE_EPI, default 0): OR the bit into the flags of EVERY cbx_gemv_f32 launch of the process. */
 int cbx_set_gemv_deep_batches(int on);
-/* ABI v9, A/B knob (env CBX_GEMV_PRE_EPI, default 0): 1 = every cbx_gemv_f32 launch requests the operands of its epilogue (residual element,
- * bias, LayerNorm-fold constants) together with its first weight batch instead of after the reduction -- one dependent memory round trip less
- * per launch; same values added in the same order, bit-identical results.  (Travels to the kernel in cbx_gemv_t.reserved1, which callers
- * leave 0: the entry point overwrites it with the knob.) */
 int cbx_set_gemv_epilogue_prefetch(int on);
-/* ABI v9 (verified on the SIMT emulator, NEVER run on hardware, off by default): two dependent GEMVs in ONE launch -- `producer`, a plain packed
- * GEMV with its residual epilogue (the o projection of a Llama decoder layer, or a down projection that adds the residual itself: M <= 16,
- * nw = 8, ksplit = 1, any half_tile), and `consumer`, an RMSNorm-folded GEMV that reads the producer's output (gate | up in the SwiGLU form,
- * or the next layer's q/k/v projection; nw = 8, no partial-sum operand).  Workgroups [0, n_prod) run the producer; the consumer
- * workgroups behind them request all their weights first (these do not depend on x), then wait for the producers' arrival counters, then
- * read x: one kernel boundary and the consumer's cold start overlap the producer.  Same arithmetic in the same order as the two cbx_gemv_f32
- * launches: bit-identical results.  sync_ws: 10 ints, zeroed ONCE by the caller ([0..8) arrivals by producer index % 8, [8] consumers through,
- * re-armed by the last consumer; [9] is set to 1 if a consumer's wait ran out after `spins` polls (0 = 65536: it then proceeds on whatever
- * it finds instead of hanging the GPU -- check the word).  Relies on workgroups being dispatched in index order.
- * Replaces the o_proj -> post_attention_layernorm -> gate_proj / up_proj chain, resp. down_proj -> input_layernorm -> q/k/v_proj of the next
- * layer, of HF LlamaDecoderLayer inside T3.inference (t3.py:378-386). */
-int cbx_gemv_pair_f32(const cbx_gemv_t* producer, const cbx_gemv_t* consumer, int* sync_ws, int spins, void* stream);
-/* The same mechanism over the whole chain  o_proj (+ residual) -> RMSNorm + gate | up + SwiGLU -> down_proj (+ residual) -> RMSNorm + q/k/v of the
- * next layer (or, behind the last layer, the speech head)  as ONE launch: ops4[0..3] are the four cbx_gemv_t descriptors in that order (roles 0 and
- * 2 plain, 1 the SwiGLU form, 3 RMSNorm-folded; all with M <= 16, nw = 8, packed fp32 operands, no partial-sum operand); every role but the first
- * requests its first weight batch before it waits for the role in front of it.  sync_ws: 64 ints zeroed once (3 edges x 16, [63] = error word as
- * above).  With cbx_decode_attn_rope_f32 a decoder layer of T3.inference's loop (t3.py:378-386) is 2 launches instead of 5.  Bit-identical to the
- * four cbx_gemv_f32 launches.  The GPT-2 form of T3.inference_turbo (t3.py:392-468) is served too: roles 0 / 2 with a bias (c_proj, mlp c_proj),
- * role 1 without swiglu but with an activation (ln_2 folded + c_fc + gelu_new), roles 1 / 3 in the LayerNorm form (ln_cw / ln_cb).  Emulator-verified, never run on hardware, off by default (CBX_T3_TUNE="chain=1,od_tc=4,d_ks2=1,d_nw2=8"). */
-int cbx_gemv_chain_f32(const cbx_gemv_t* ops4, int* sync_ws, int spins, void* stream);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
  * input_layernorm / post_attention_layernorm steps of HF LlamaDecoderLayer inside T3.inference's loop, t3.py:378-386) */
 int cbx_add_rmsnorm_f32(float* x, const float* part, int ksplit, long part_stride, long ldp, const float* w, float* h,
@@ -288,20 +273,34 @@ int cbx_decode_attn_f32(const float* q, const float* kc, const float* vc, float*
 int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                              float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                              long cache_row_stride, long cache_head_stride, float scale, void* stream);
+/* ABI v10: the same op with everything it depends on IN the call -- the form the engines use (no process-wide state: two engines, two streams
+ * or a hipGraph captured earlier never see each other's geometry or share a workspace).
+ *   unroll   : key rows in flight per 16-lane group and step: 0 (= 4), 4, 8 or 16.
+ *   pipeline : bit 0 = software-pipelined K / V stream (the rows of the next step are requested before the current step is multiplied; two
+ *              register sets; 4 or 8 rows per step); bit 1 = non-temporal K / V loads (4 rows per step); bit 2 = speculative first step
+ *              (positions 0 .. 63 of every (row, head) are requested before positions[row] has arrived; needs cache_head_stride >= 64 * 64).
+ *              Every combination gives the results of pipeline = 0 bit for bit (hardware test: tests/test_zz_abi_v9_gpu.py).
+ *   split_ws / split_cnt / split_pairs : CALLER-OWNED workspace of the split-context form -- 66 * 8 floats per (row, head) and one int per
+ *              (row, head), zeroed once by the caller, re-armed by every launch -- or NULL.  With rows * n_heads < 128 <= split_pairs the
+ *              context of a (row, head) that is >= split_min (0 = 512) positions long is walked by up to 8 workgroups, merged in split order
+ *              (deterministic).  One workspace serves launches that are ordered on one stream; concurrent launches need their own. */
+typedef struct cbx_decode_attn_t {
+    const float* qkv; const int* positions; const float *cos_t, *sin_t;
+    float *kc, *vc, *o;
+    int rows, n_heads; long ld_qkv, o_ld; int o_packed;
+    long cache_row_stride, cache_head_stride; float scale;
+    int unroll, pipeline, split_min;
+    float* split_ws; int* split_cnt; long split_pairs;
+} cbx_decode_attn_t;
+int cbx_decode_attn_rope(const cbx_decode_attn_t* p, void* stream);
 /* tuning knob: tile shape of the split-bf16 GEMM (0 = automatic; 64, 12864, 128, 1282) */
 int cbx_set_split_tile(int t);
-/* tuning knob: key rows in flight per 16-lane group of the decode attention (4, 8 or 16) */
+/* TEST HOOKS of the positional cbx_decode_attn_rope_f32 (process-wide; the engines pass cbx_decode_attn_t instead): unroll / pipeline /
+ * split_min as the fields above (env CBX_DA_U, CBX_DA_PIPE, CBX_DA_SPLIT_MIN), and the workspace it splits through, registered for the calling
+ * thread's current device (single-stream use only). */
 int cbx_set_decode_attn_unroll(int u);
-/* ABI v9: bit 0 = software-pipelined K / V stream (the rows of the next step are requested before the current step is multiplied; two register
- * sets; 4 or 8 rows per lane group and step); bit 1 = non-temporal K / V loads (4 rows per step); bit 2 = speculative first step (positions
- * 0 .. 63 of every (row, head) are requested before positions[row] has arrived; needs cache_head_stride >= 64 * 64; 4 rows per step).
- * Same results bit for bit.  Default 0 (env CBX_DA_PIPE = 0 .. 7). */
 int cbx_set_decode_attn_pipeline(int on);
-/* Workspace of cbx_decode_attn_rope_f32's split-context form, used when rows * n_heads < 128 (Turbo / Nano at small batch): ws = 66 * 8 floats
- * per (row, head), zeroed_counters = one int per (row, head), initialised to 0 once; registered for the calling thread's current device. */
 int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, long max_pairs);
-/* a (row, head) whose context is shorter than min_ctx (default 512; CBX_DA_SPLIT_MIN) is walked by one workgroup even when the workspace is
- * registered: the hand-off costs ~5 us, more than a short context's 1-2 memory round trips */
 int cbx_set_decode_attn_split_min(int min_ctx);
 
 /* Row softmax over materialised scores with optional relative-position term and key mask
@@ -405,6 +404,10 @@ typedef struct cbx_t3_step_t {
     long ld_logits;
     const cbx_sampler_t* sampler;         /* sampler descriptor (host struct) run at the end of the step, or NULL */
     int qkv_tile;                         /* ABI v9: cbx_gemv_t.half_tile of the wqkv images (0 or 12) */
+    /* ABI v10: the rest of the step's geometry (was process-wide): cbx_decode_attn_t.unroll / pipeline / split_min / split_* of every attention
+     * launch, cbx_gemv_t.flags of every GEMV launch */
+    int da_unroll, da_pipeline, da_split_min, gemv_flags;
+    float* da_ws; int* da_cnt; long da_pairs;
 } cbx_t3_step_t;
 int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
 

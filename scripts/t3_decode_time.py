@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from chatterbox_amd import ops, synth
+from chatterbox_amd.autotune import LIB_KNOBS, split_variant
 from chatterbox_amd.t3 import T3Engine
 
 dev = torch.device("cuda:0")
@@ -27,28 +28,17 @@ VARIANTS = [("v1", {}), ("v2", dict(half_tiles=0)), ("v2", dict(half_tiles=1, d_
             # last session of round 3 (no GPU): speculative first K / V step of the decode attention (da_pipe bit 2), epilogue operands of every
             # GEMV requested with its first weight batch (pre_epi), and both with the pipelined stream / on the reordered geometry
             ("v2", dict(da_pipe=4)), ("v2", dict(da_pipe=5)), ("v2", dict(da_pipe=7)), ("v2", dict(pre_epi=1)), ("v2", dict(da_pipe=5, pre_epi=1)),
-            ("v2", dict(da_pipe=5, pre_epi=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
-            # o projection + gate | up in ONE launch (cbx_gemv_pair_f32: the consumer's weights are requested before it waits for the producer)
-            ("v2", dict(pair_ogu=1)), ("v2", dict(pair_ogu=1, da_pipe=5, pre_epi=1)),
-            # ... and down + the next layer's q/k/v as well: 3 launches per layer (on the partial-free geometry; 12-column q/k/v tiles = 256 + 256 workgroups)
-            ("v2", dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(pair_ogu=1, pair_dq=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
-            ("v2", dict(pair_ogu=1, pair_dq=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, da_pipe=5)),
-            # the whole chain o -> gate | up -> down -> next q/k/v (head) as ONE launch (cbx_gemv_chain_f32): attention + 1 launch per layer
-            ("v2", dict(chain=1, od_tc=4, d_ks2=1, d_nw2=8)), ("v2", dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8)),
-            ("v2", dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, da_pipe=5)), ("v2", dict(chain=1, half_tiles=1, d_ks2=1, d_nw2=8))]
+            ("v2", dict(da_pipe=5, pre_epi=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))]
 if os.environ.get("T3_VARIANTS"):  # e.g. T3_VARIANTS=1 profiles only the default v2 configuration
     VARIANTS = [VARIANTS[int(i)] for i in os.environ["T3_VARIANTS"].split(",")]
 for mode, tune in VARIANTS:
     os.environ["CBX_T3_DECODE"] = mode
     eng = T3Engine(sd, dev)
     tune = dict(tune)
-    da_u, da_pipe = tune.pop("da_u", 4), tune.pop("da_pipe", 0)
-    ops.lib.cbx_set_gemv_deep_batches(tune.pop("deep", 0))
-    pre_epi = tune.pop("pre_epi", 0)
-    ops.lib.cbx_set_gemv_epilogue_prefetch(pre_epi)
-    ops.lib.cbx_set_decode_attn_unroll(da_u)
-    ops.lib.cbx_set_decode_attn_pipeline(da_pipe)
-    eng.tune.update(tune)
+    da_u, da_pipe, pre_epi = tune.get("da_u", 4), tune.get("da_pipe", 0), tune.get("pre_epi", 0)
+    t, k = split_variant(tune)  # per-engine geometry (ABI v10): tile keys + launch knobs, nothing process-wide
+    eng.apply_variant(dict(eng.tune, **t), dict(LIB_KNOBS, **k))
+    tune = t
     kw = dict(max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561)
     toks = eng.generate(synth.t3_cond(), texts, **kw)
     torch.cuda.synchronize()

@@ -24,7 +24,7 @@ ASAN = os.environ.get("CBX_EMU_ASAN") == "1"
 LIB = os.path.join(HERE, "libcbx_emu_asan.so" if ASAN else "libcbx_emu.so")
 GEN = os.path.join(HERE, "_gen_asan" if ASAN else "_gen")
 CLANG = os.environ.get("CBX_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-fno-strict-aliasing", "-Wno-everything", "-ffp-contract=off",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-fno-strict-aliasing", "-Wno-everything", "-ffp-contract=on", "-mfma",  # same contraction rule as the gfx950 build (chatterbox_amd/build.py FLAGS)
          "-I", os.path.join(HERE, "shim"), "-I", HERE] + (["-fsanitize=address", "-fsanitize-recover=address", "-fno-omit-frame-pointer", "-g"] if os.environ.get("CBX_EMU_ASAN") == "1" else [])
 
 

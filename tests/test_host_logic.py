@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -416,9 +416,9 @@ def test_decode_autotuner_child_failure_keeps_the_geometry():
     rep = at.tune_in_child(1, 1, 8, 1, 1, 0.01, False, 0, {}, dict(at.LIB_KNOBS), timeout=300.0)
     assert "error" in rep and "best" not in rep, rep
     eng = T3Engine.__new__(T3Engine)  # the adoption logic of T3Engine.autotune without a model: an error report adopts nothing
-    eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE)
+    eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune, eng.knobs = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE), dict(at.LIB_KNOBS)
     r2 = T3Engine.autotune(eng, B=1, ctx=8, steps=1, reps=1, timeout=300.0)
-    assert "error" in r2 and eng.tune == T3Engine._TUNE and not hasattr(eng, "lib_knobs") and eng.autotune_report is r2
+    assert "error" in r2 and eng.tune == T3Engine._TUNE and eng.knobs == at.LIB_KNOBS and eng.autotune_report is r2
     r3 = T3Engine.autotune(eng, B=16)  # 32 rows: not the packed <= 16-row path -- nothing to tune, nothing spawned
     assert r3.get("skipped") and eng.tune == T3Engine._TUNE
 
@@ -435,20 +435,36 @@ def test_decode_autotuner_adoption_rules(monkeypatch):
 
     def mk():
         eng = T3Engine.__new__(T3Engine)
-        eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE)
-        eng.apply_variant = lambda t, k=None: (applied.append((dict(t), dict(k))), setattr(eng, "tune", dict(t)), setattr(eng, "lib_knobs", dict(k)))
+        eng.decode_mode, eng.dev, eng.L, eng._state, eng.tune, eng.knobs = "v2", torch.device("cuda", 0), 1, {}, dict(T3Engine._TUNE), dict(at.LIB_KNOBS)
+        eng.apply_variant = lambda t, k=None: (applied.append((dict(t), dict(k))), setattr(eng, "tune", dict(t)), setattr(eng, "knobs", dict(k)))
         eng._prepare_tune = lambda: None
         return eng
 
     eng = mk()
     rep = eng.autotune(B=8)
-    assert rep["adopted"] == best and eng.tune["qkv_tc"] == 12 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.lib_knobs["da_pipe"] == 1
+    assert rep["adopted"] == best and eng.tune["qkv_tc"] == 12 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.knobs["da_pipe"] == 1
     eng = mk()
-    rep = eng.autotune(B=8, validate=lambda: eng.tune["d_ks2"] == 1 and eng.lib_knobs["da_pipe"] == 3)  # sees best_any applied
+    rep = eng.autotune(B=8, validate=lambda: eng.tune["d_ks2"] == 1 and eng.knobs["da_pipe"] == 3)  # sees best_any applied
     assert rep["best_any_validated"] is True and rep["adopted"] == best_any and eng.tune["od_tc"] == 4 and eng.tune["qkv_tc"] == 0
     for refuse in (lambda: False, lambda: 1 // 0):
         eng = mk()
         rep = eng.autotune(B=8, validate=refuse)
         assert rep["best_any_validated"] is False and rep["adopted"] == best
-        assert eng.tune["qkv_tc"] == 12 and eng.tune["od_tc"] == 0 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.lib_knobs["da_pipe"] == 1
+        assert eng.tune["qkv_tc"] == 12 and eng.tune["od_tc"] == 0 and eng.tune["d_ks2"] == T3Engine._TUNE["d_ks2"] and eng.knobs["da_pipe"] == 1
     assert "validate_error" in rep
+
+
+def test_green_allow_list_is_canonical_and_contains_the_builtin_geometry():
+    """chatterbox_amd/decode_green.json (the geometries bench.py may adopt): canonical keys only, every entry made of knobs the engine / library
+    know, the built-in geometry always on it; canon() drops default-valued keys so that the autotuner's composed candidates are found."""
+    import json
+    from chatterbox_amd import autotune as at
+    from chatterbox_amd.t3 import T3Engine
+    green = at.green_variants()
+    assert at.canon({}) in green and at.canon(dict(qkv_tc=0, da_pipe=0, da_u=4)) == ()
+    assert at.canon(dict(da_pipe=7, pre_epi=1, qkv_tc=0)) == (("da_pipe", 7), ("pre_epi", 1))
+    known = set(T3Engine._TUNE) | set(at.LIB_KNOBS)
+    doc = json.load(open(at.GREEN_FILE))
+    assert isinstance(doc["green"], list) and doc.get("source"), "decode_green.json names the hardware run it was written from"
+    for v in doc["green"]:
+        assert set(v) <= known and at.canon(v) in green, v

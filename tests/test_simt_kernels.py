@@ -66,15 +66,14 @@ _OPS = [
     ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)), ("test_gemv_layernorm_fused", (16, 4096, 1024, 0, True)),
     ("test_gemv_half_tile", (16, 1024, 4096, 2, 8, False)), ("test_gemv_half_tile", (16, 1024, 1024, 1, 8, True)), ("test_gemv_half_tile", (9, 40, 256, 1, 4, False)),
     ("test_gemv_bf16_weights_equal_rounded_fp32", ("plain",)), ("test_gemv_bf16_weights_equal_rounded_fp32", ("rms_np2",)),
-    ("test_decode_attn_rope_pipelined_equals_plain", (3, 16, True, 512)), ("test_decode_attn_rope_pipelined_equals_plain", (1, 12, False, 1)),
+    ("test_decode_attn_rope_pipelined_equals_plain", (3, 16, True, 512, 7, 4)), ("test_decode_attn_rope_pipelined_equals_plain", (1, 12, False, 1, 3, 4)),
+    ("test_decode_attn_rope_pipelined_equals_plain", (1, 12, False, 1, 1, 8)),
     ("test_gemv_deep_batches_equal_plain", (16, 1024, 4096, 1, 4, True)), ("test_gemv_deep_batches_equal_plain", (9, 64, 2048, 1, 0, False)),
     ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2")), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
     ("test_gemv_narrow_tiles", (9, 1024, 4096, 1, 8, 4, "plain")), ("test_gemv_narrow_tiles", (5, 40, 256, 2, 4, 12, "plain")),
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
-    ("test_gemv_pair_equals_the_two_launches", (16, 8)), ("test_gemv_pair_down_and_next_qkv", (5, 4, 12)),
-    ("test_gemv_chain_equals_the_four_launches", (16, 4, 12)), ("test_gemv_chain_equals_the_four_launches", (3, 8, 0)), ("test_gemv_chain_at_the_nano_width", ()),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
@@ -377,7 +376,7 @@ def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_ste
     eng.layers = [dict(ln1=w["ln1"], ln2=w["ln2"], wqkv=w["wqkv"], wo=w["wo"], wd=w["wd"], wgu_pk=w["wgu_pk"], wqkv_pk=w["wqkv_pk16"], wo_pk=w["wo_pk16"],
                        wd_pk=w["wd_pk16"], wo_pk8=w["wo_pk8"], wd_pk8=w["wd_pk8"]) for w in m["lw"]]
     eng.norm, eng.head_pk, eng.speech_emb, eng.speech_pos, eng.cos, eng.sin = m["norm"], m["head_pk"], m["emb"], m["pos_emb"], m["cos"], m["sin"]
-    eng.tune, eng._state = dict(T3Engine._TUNE, **tune), {}
+    eng.tune, eng._state, eng.knobs = dict(T3Engine._TUNE, **tune), {}, T3Engine._env_knobs()
     qtc, odtc = eng._tiles()
     assert (qtc, odtc) == ((12, 4) if tune else (16, 8))
     eng._prepare_tune()
@@ -397,7 +396,7 @@ def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_ste
         assert (st["logits"].double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8), dict(chain=1, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials", "chain"])
+@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials"])
 def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE T3-Turbo path of chatterbox_amd/t3_turbo.py on the emulator -- conditioning, prefill (exact fp32 GEMMs + flash attention),
     the 5-launch GPT-2 decode step with the LayerNorm-folded GEMVs, the device sampler (top-k / top-p bisection, repetition penalty) -- on a
@@ -414,14 +413,7 @@ def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     u = synth.rand((2, steps + 1), seed=11)
     eng = T3TurboEngine(sd, CPU)
     eng.tune.update(tune)
-    from chatterbox_amd import ops
-    chains, real = [0], ops.gemv_chain
-    ops.gemv_chain = lambda *a, **k: (chains.__setitem__(0, chains[0] + 1), real(*a, **k))[1]
-    try:
-        toks = eng.generate(conds, texts, max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
-    finally:
-        ops.gemv_chain = real
-    assert (chains[0] > 0) == bool(tune.get("chain")) and not next(iter(eng._state.values()))["dws"]["pair_ws"].any(), f"{chains[0]} chained launches"
+    toks = eng.generate(conds, texts, max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
     for b in range(2):
         ref = O.t3_inference_turbo(sd, L, d // 64, conds[b], texts[b], steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"
@@ -477,20 +469,12 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     assert rc == 0, out
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5", "CBX_EMU_DROP_BARRIER": "0"}, "test_gemv_decode or test_linear")  # the K-slice reduction through LDS
     assert rc != 0, "a dropped barrier went unnoticed\n" + out
-    # the producer / consumer launches under a random lane schedule (their workgroups in dispatch order, which is what they rely on) ...
-    rc, out = _rerun({"CBX_EMU_SCHED": "random:7", "CBX_EMU_WG_ORDER": "dispatch"}, "gemv_chain_equals_the_four_launches")
-    assert rc == 0, out
-    # ... and that very reliance seen: with the workgroups reversed every consumer's bounded wait runs out and the error word is raised
-    rc, out = _rerun({"CBX_EMU_SCHED": "reverse", "CBX_PAIR_SPINS": "4"}, "gemv_pair_equals_the_two_launches")
-    assert rc != 0, "consumers in front of their producers went unnoticed\n" + out
 
 
-_SLOW2 = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1; the paired / chained launches themselves "
-                            "run in test_gpu_op_bodies_on_the_emulator")
+_SLOW2 = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1")
 
 
-@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(pair_ogu=1, pair_dq=1, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2),
-                                  pytest.param(dict(chain=1, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2)], ids=["default", "pairs", "chain"])
+@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2)], ids=["default", "qkv12_od4_nopartials"])
 def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
@@ -505,23 +489,13 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     sd = synth.t3_state_dict(L, 0)
     eng = T3Engine(sd, CPU)
     assert eng.c_step and eng.decode_mode == "v2"
-    eng.tune.update(tune)  # pairs: o + gate | up and down + the next layer's q/k/v in one launch each (cbx_gemv_pair_f32), sequenced from Python
+    eng.tune.update(tune)
     texts = [synth.text_tokens(n, seed=s) for n, s in ((3, 1), (5, 2))]
     conds = [synth.t3_cond(seed=s, prompt_len=20) for s in (2, 3)]
     u = synth.rand((2, steps), seed=11)
-    from chatterbox_amd import ops
-    pairs, real, real_c = [0], ops.gemv_pair, ops.gemv_chain
-    ops.gemv_pair = lambda *a, **k: (pairs.__setitem__(0, pairs[0] + 1), real(*a, **k))[1]
-    ops.gemv_chain = lambda *a, **k: (pairs.__setitem__(0, pairs[0] + 100), real_c(*a, **k))[1]
-    try:
-        toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
-    finally:
-        ops.gemv_pair, ops.gemv_chain = real, real_c
+    toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
     st = next(iter(eng._state.values()))
-    assert ("cstep" in st) == (not tune), "the default decode steps go through cbx_t3_decode_step"
-    want = 0 if not tune else 100 * L * (steps - 1) if tune.get("chain") else (2 * L - 1) * (steps - 1)
-    assert pairs[0] == want, f"{pairs[0]} paired (x 1) / chained (x 100) launches, expected {want}"
-    assert not st["dws"]["pair_ws"].any()
+    assert "cstep" in st, "the decode steps go through cbx_t3_decode_step"
     for b in range(2):
         ref = O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp)
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"
@@ -570,7 +544,7 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     def measure(self, **kw):
         _, logits = real(self, **dict(kw, steps=0))  # one real token step per call; the clock is the table above
         k = {k: v for k, v in self.tune.items() if v != T3Engine._TUNE[k]}
-        k.update({k: v for k, v in self.lib_knobs.items() if v != at.LIB_KNOBS[k]})
+        k.update({k: v for k, v in self.knobs.items() if v != at.LIB_KNOBS[k]})
         return fake[key(k)], logits
 
     monkeypatch.setattr(T3Engine, "measure_decode", measure)
@@ -581,13 +555,13 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
     seen_geometry = []
 
     def validate():  # runs on the engine with best_any applied
-        seen_geometry.append((dict(eng.tune), dict(eng.lib_knobs)))
+        seen_geometry.append((dict(eng.tune), dict(eng.knobs)))
         toks = eng.generate(conds, texts, max_new_tokens=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
         return all(toks[b].tolist() == O.t3_inference(sd, L, conds[b], torch.stack([texts[b], texts[b]]), steps, u[b], ban_eos=True, **samp).tolist()
                    for b in range(2))
 
     try:
-        rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False, tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), reorder), attn=(dict(da_pipe=3),), chain=(),
+        rep = eng.autotune(B=1, ctx=12, steps=1, reps=1, in_child=False, tiles=(dict(), dict(qkv_tc=12), dict(od_tc=4), reorder), attn=(dict(da_pipe=3),),
                            validate=validate)
         rows = {key(r["variant"]): r for r in rep["candidates"] if "variant" in r}
         assert all("error" not in r for r in rows.values()), rows
@@ -599,30 +573,8 @@ def test_t3_decode_autotuner_on_the_emulator(emu, monkeypatch):
         assert rep["best_any"] == dict(reorder, da_pipe=3, pre_epi=1) and rep["ms_per_token_any"] == 0.2
         assert len(seen_geometry) == 1 and seen_geometry[0][0]["d_ks2"] == 1 and seen_geometry[0][1]["da_pipe"] == 3 and seen_geometry[0][1]["pre_epi"] == 1
         assert rep["best_any_validated"] is True and rep["adopted"] == rep["best_any"], rep  # the oracle's tokens on the reordered geometry
-        assert eng.tune["od_tc"] == 4 and eng.tune["d_ks2"] == 1 and eng.tune["qkv_tc"] == 0 and eng.lib_knobs["da_pipe"] == 3 and eng.lib_knobs["pre_epi"] == 1
+        assert eng.tune["od_tc"] == 4 and eng.tune["d_ks2"] == 1 and eng.tune["qkv_tc"] == 0 and eng.knobs["da_pipe"] == 3 and eng.knobs["pre_epi"] == 1
         assert "wd_pk4" in eng.layers[0] and not [k for k in eng._state if k[3] == 7]
-    finally:
-        eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the library knobs are process-wide
-
-
-@pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="2 min on the emulator: CBX_EMU_SLOW=1")
-def test_autotuner_validates_a_chained_launch_against_its_twin_on_the_emulator(emu):
-    """autotune.tune_decode with a CHAIN candidate, real token steps of a 1-layer Llama T3 at the real width: the candidate's whole measured run
-    (final logits, every sampled token, the counters' error word) is compared with its twin -- the same geometry as separate launches -- and only
-    then is it `valid`; relative to the built-in geometry it reorders the down projection's sum, so it can only ever be `best_any`."""
-    from chatterbox_amd import autotune as at, synth
-    from chatterbox_amd.t3 import T3Engine
-    eng = T3Engine(synth.t3_state_dict(1, 0), CPU)
-    try:
-        rep = at.tune_decode(eng, B=1, ctx=12, steps=1, reps=1, use_graph=False, tiles=(dict(),), attn=(), epi=(), chain=at.CHAIN_VARIANTS[:1])
-        rows = {tuple(sorted(r["variant"].items())): r for r in rep["candidates"] if "variant" in r}
-        c = at.CHAIN_VARIANTS[0]
-        twin = {k: v for k, v in c.items() if k not in at.CHAIN_KEYS}
-        rc, rt = rows[tuple(sorted(c.items()))], rows[tuple(sorted(twin.items()))]
-        assert "error" not in rc and "error" not in rt, (rc, rt)
-        assert rc["twin_identical"] and rc["valid"] and rc["reorders"] and rt["reorders"], (rc, rt)
-        assert rc["max_abs_diff"] == rt["max_abs_diff"], "chain and twin: the same logits after one step"
-        assert not rep["best"].get("chain"), rep["best"]
     finally:
         eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))
 
@@ -630,13 +582,11 @@ def test_autotuner_validates_a_chained_launch_against_its_twin_on_the_emulator(e
 @pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="2 min on the emulator: CBX_EMU_SLOW=1")
 def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
     """`python -m chatterbox_amd.autotune` is what bench.py's child process runs: its main() here, on the emulator, with a short candidate list --
-    argument parsing, engine construction, every stage of tune_decode incl. a chained launch under the twin rule, and the one-line JSON report the
-    parent parses."""
+    argument parsing, engine construction, every stage of tune_decode, and the one-line JSON report the parent parses."""
     import json
     from chatterbox_amd import autotune as at
     orig = at.tune_decode
-    monkeypatch.setattr(at, "tune_decode", lambda eng, **kw: orig(eng, tiles=(dict(), dict(qkv_tc=12)), attn=(dict(da_pipe=5),), epi=at.EPI_VARIANTS,
-                                                                  chain=at.CHAIN_VARIANTS[:1], **kw))
+    monkeypatch.setattr(at, "tune_decode", lambda eng, **kw: orig(eng, tiles=(dict(), dict(qkv_tc=12)), attn=(dict(da_pipe=5),), epi=at.EPI_VARIANTS, **kw))
     at.main(["--layers", "1", "--batch", "1", "--ctx", "12", "--steps", "1", "--reps", "1"], device=CPU)
     rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     rows = {tuple(sorted(r["variant"].items())): r for r in rep["candidates"] if "variant" in r}
@@ -644,5 +594,3 @@ def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
     for knob in ("qkv_tc", "da_pipe", "pre_epi"):  # (what a knob is tried on top of depends on the emulator's "clock")
         hit = [r for r in rows.values() if r["variant"].get(knob) and not r["variant"].get("d_ks2")]
         assert hit and all(r["identical"] for r in hit), (knob, hit)
-    chained = [r for r in rows.values() if r["variant"].get("chain")]
-    assert len(chained) == 1 and chained[0]["twin_identical"] and chained[0]["valid"] and chained[0]["reorders"] and not rep["best"].get("chain")

@@ -1,10 +1,12 @@
-"""ABI v9 decode variants (-m gpu): 12- / 4-column GEMV tiles, the down projection without partial images, the software-pipelined decode
-attention, and the T3 engines running on them.
+"""Decode-step geometry variants (-m gpu): 12- / 4-column GEMV tiles, the down projection without partial images, the software-pipelined /
+non-temporal / speculative decode attention, the GEMV epilogue prefetch and deep load batches, the flash rel-pos encoder attention, and the T3
+engines running on them -- each against the plain form BIT FOR BIT and against torch / the reference's golden tokens.
 
-These variants were written at the END of round 3 without GPU access: they are verified on the SIMT emulator (tests/test_simt_kernels.py
-runs the same bodies on the CPU) but had not yet run on an MI355X when they were committed.  The file name sorts last on purpose: under
-`pytest -x` a surprise here cannot hide the results of the established suites.  Every variant is opt-in; the shipped defaults are covered
-by the other files.
+History: written at the end of round 3 without GPU access (SIMT-emulator evidence only); the first hardware run (GPUTEST_r03) failed
+`test_decode_attn_rope_pipelined_equals_plain` -- hipcc's default -ffp-contract=fast had rounded one template instantiation's dot product
+differently (v_pk_mul + adds instead of an fma chain).  The library is built with -ffp-contract=on since (chatterbox_amd/build.py), the geometry
+travels per call (ABI v10: cbx_decode_attn_t, cbx_gemv_t.flags) and every variant bench.py may adopt is on an allow-list
+(chatterbox_amd/decode_green.json) that `test_green_variant_*` re-checks on the hardware.  The file name still sorts last on purpose.
 """
 import math
 import os
@@ -69,59 +71,104 @@ def test_gemv_narrow_tiles(dev, M, N, K, ks, nw, tile, mode):
         _close(_unpack_operand(extra["x_out"], M, K), xs, 1e-6, "x_out = x + partial images")
 
 
+def _first_diff(a, b):
+    """'row r, head h, element e: a vs b (max |d| ...)' of the first differing element of two (rows, H * 64) / cache tensors."""
+    d = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
+    if not bool(d.any()):
+        return "equal"
+    i = int(torch.nonzero(d.flatten())[0])
+    idx = np.unravel_index(i, tuple(a.shape))
+    return (f"{int(d.sum())} of {d.numel()} elements differ, first at {tuple(int(x) for x in idx)}: {a.flatten()[i].item()!r} vs {b.flatten()[i].item()!r}, "
+            f"max |d| {torch.nan_to_num(a - b).abs().max().item():.3e}, non-finite: {int((~torch.isfinite(a)).sum())} / {int((~torch.isfinite(b)).sum())}")
+
+
+@pytest.mark.parametrize("pipe,u", [(1, 4), (1, 8), (2, 4), (3, 4), (4, 4), (5, 4), (6, 4), (7, 4)])
 @pytest.mark.parametrize("rows,H,rope,split_min", [(3, 16, True, 512), (1, 12, False, 1), (16, 16, True, 512)])
-def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min):
-    """cbx_set_decode_attn_pipeline(1) (ABI v9: the next step's K / V rows are requested before the current step is multiplied, two register
-    sets) against the plain form: same arithmetic in the same order, so outputs and appended cache rows are equal bit for bit -- contexts of
-    1 .. 70 (fewer rows than one step, exactly one step, the ragged tail of the second register set), a few long ones, 4 and 8 rows per
-    lane group and step, the one-workgroup and the split-context grids."""
+def test_decode_attn_rope_pipelined_equals_plain(dev, rows, H, rope, split_min, pipe, u):
+    """cbx_decode_attn_t.pipeline (bit 0: the next step's K / V rows are requested before the current step is multiplied, two register sets;
+    bit 1: non-temporal K / V loads; bit 2: positions 0 .. 63 requested before positions[row] has arrived) and .unroll (4 / 8 / 16 rows per lane
+    group and step) against the plain form (pipeline 0, the SAME unroll: another unroll folds the online softmax in other groups): same arithmetic in the same order, so outputs and appended cache rows are
+    equal bit for bit -- contexts of 1 .. 70 (fewer rows than one step, exactly one step, the ragged tail of the second register set), a few
+    long ones, the one-workgroup and the split-context grids.  The cache past each row's context is poisoned with NaN: whatever a variant
+    reads there must not matter.  One test per (shape, mode): a failure names the mode, the context, the row and the size of the difference."""
     from chatterbox_amd import ops
     from oracle import ref_torch as O
-    ops.ensure_decode_attn_workspace(dev)
     maxp = 640
     kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
     cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
     cd, sd_ = (cos.to(dev), sin.to(dev)) if rope else (None, None)
-    try:
-        ops.lib.cbx_set_decode_attn_split_min(split_min)
-        for u in (4, 8):
-            ops.lib.cbx_set_decode_attn_unroll(u)
-            for n in list(range(0, 70, 1 if rows < 16 else 9)) + [127, 128, 129, 255, 300, 639]:
-                pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
-                qkv = _r((rows, 3 * H * 64), 100 + n)
-                res = []
-                # 2 / 3: non-temporal K / V loads, plain / pipelined; 4 .. 7: the same four with the speculative first step (positions 0 .. 63 requested
-                # before positions[row] has arrived) -- the cache past each row's context is poisoned with NaN: whatever is read there must not matter
-                for pipe in (0, 1) + ((2, 3, 4, 5, 6, 7) if u == 4 else ()):
-                    ops.lib.cbx_set_decode_attn_pipeline(pipe)
-                    kc, vc, out = kc0.clone(), vc0.clone(), torch.zeros(rows, H * 64, device=dev)
-                    for r in range(rows):
-                        kc[r, :, int(pos[r]):], vc[r, :, int(pos[r]):] = float("nan"), float("nan")
-                    kc, vc = kc.to(dev), vc.to(dev)
-                    ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125)
-                    kc, vc = kc.cpu(), vc.cpu()
-                    assert all(bool(torch.isnan(c[r, :, int(pos[r]) + 1:]).all()) and bool(torch.isfinite(c[r, :, : int(pos[r]) + 1]).all())
-                               for c in (kc, vc) for r in range(rows)), "exactly one row appended per (row, head)"
-                    res.append((out.cpu(), torch.nan_to_num(kc), torch.nan_to_num(vc)))
-                for other in res[1:]:
-                    for a, b, what in zip(res[0], other, ("output", "k cache", "v cache")):
-                        assert torch.equal(a, b) and bool(torch.isfinite(a).all()), f"pipelined / non-temporal / speculative decode attention differs in the {what} (U = {u}, context {n + 1})"
-                if n in (0, 63, 64, 65, 300):  # and the result itself against torch
-                    q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
-                    if rope:
-                        c, s = cos[pos.long()][:, None], sin[pos.long()][:, None]
-                        q, k = q * c + O._rot_half(q) * s, k * c + O._rot_half(k) * s
-                    for r in range(rows):
-                        m = int(pos[r])
-                        kk, vv = torch.cat([kc0[r, :, :m], k[r][:, None]], 1), torch.cat([vc0[r, :, :m], v[r][:, None]], 1)
-                        _close(res[1][0][r].view(H, 64), F.scaled_dot_product_attention(q[r].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"pipelined, ctx {m + 1}")
-    finally:
-        ops.lib.cbx_set_decode_attn_pipeline(0)
-        ops.lib.cbx_set_decode_attn_unroll(4)
-        ops.lib.cbx_set_decode_attn_split_min(512)
+    plain = ops.DecodeAttnGeom(dev, unroll=u, pipeline=0, split_min=split_min)
+    var = ops.DecodeAttnGeom(dev, unroll=u, pipeline=pipe, split_min=split_min)  # its own workspace: nothing shared between the two forms
+    for n in list(range(0, 70, 1 if rows < 16 else 9)) + [127, 128, 129, 255, 300, 639]:
+        pos = torch.tensor([(n + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
+        qkv = _r((rows, 3 * H * 64), 100 + n)
+        res = []
+        for geom in (plain, var):
+            kc, vc, out = kc0.clone(), vc0.clone(), torch.zeros(rows, H * 64, device=dev)
+            for r in range(rows):
+                kc[r, :, int(pos[r]):], vc[r, :, int(pos[r]):] = float("nan"), float("nan")
+            kc, vc = kc.to(dev), vc.to(dev)
+            ops.decode_attn_rope(qkv.to(dev), pos.to(dev), cd, sd_, kc, vc, out, 0.125, geom=geom)
+            kc, vc = kc.cpu(), vc.cpu()
+            assert all(bool(torch.isnan(c[r, :, int(pos[r]) + 1:]).all()) and bool(torch.isfinite(c[r, :, : int(pos[r]) + 1]).all())
+                       for c in (kc, vc) for r in range(rows)), f"pipeline {geom.pipeline}, unroll {geom.unroll}, context {n + 1}: exactly one row appended per (row, head)"
+            res.append((out.cpu(), torch.nan_to_num(kc), torch.nan_to_num(vc)))
+        for a, b, what in zip(res[0], res[1], ("output", "k cache", "v cache")):
+            assert torch.equal(a, b) and bool(torch.isfinite(a).all()), \
+                f"pipeline {pipe}, unroll {u}, contexts {[int(p) + 1 for p in pos]}: {what} differs from the plain kernel: {_first_diff(a, b)}"
+        if n in (0, 63, 64, 65, 300):  # and the result itself against torch
+            q, k, v = (qkv.view(rows, 3, H, 64)[:, i] for i in range(3))
+            if rope:
+                c, s_ = cos[pos.long()][:, None], sin[pos.long()][:, None]
+                q, k = q * c + O._rot_half(q) * s_, k * c + O._rot_half(k) * s_
+            for r in range(rows):
+                m = int(pos[r])
+                kk, vv = torch.cat([kc0[r, :, :m], k[r][:, None]], 1), torch.cat([vc0[r, :, :m], v[r][:, None]], 1)
+                _close(res[1][0][r].view(H, 64), F.scaled_dot_product_attention(q[r].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"pipeline {pipe}, ctx {m + 1}")
 
 
-@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "pair_ogu=1", "pair_ogu=1,pair_dq=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8", "chain=1,qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8"])
+def test_decode_attn_split_workspaces_are_caller_owned(dev):
+    """Two split-context attention launches in flight on two streams, each with its OWN cbx_decode_attn_t workspace (the process-wide
+    one could be shared by concurrent launches): both equal the same launches run one after the other."""
+    from chatterbox_amd import ops
+    rows, H, maxp = 1, 12, 1536
+    kc0, vc0 = _r((2, rows, H, maxp, 64), 1).to(dev), _r((2, rows, H, maxp, 64), 2).to(dev)
+    qkv = _r((2, rows, 3 * H * 64), 3).to(dev)
+    pos = torch.tensor([[1200], [900]], dtype=torch.int32, device=dev)
+    geoms = [ops.DecodeAttnGeom(dev, split_min=512), ops.DecodeAttnGeom(dev, split_min=512)]
+    assert geoms[0].ws.data_ptr() != geoms[1].ws.data_ptr()
+
+    def run(i, kc, vc, out):
+        ops.decode_attn_rope(qkv[i], pos[i], None, None, kc, vc, out, 0.125, geom=geoms[i])
+
+    serial = []
+    for i in range(2):
+        kc, vc, out = kc0[i].clone(), vc0[i].clone(), torch.zeros(rows, H * 64, device=dev)
+        run(i, kc, vc, out)
+        serial.append(out.cpu())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for rep in range(20):
+        outs, keep = [], []
+        for i in range(2):
+            kc, vc, out = kc0[i].clone(), vc0[i].clone(), torch.zeros(rows, H * 64, device=dev)
+            keep.append((kc, vc))
+            outs.append(out)
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                run(i, keep[i][0], keep[i][1], outs[i])
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(outs[i].cpu(), serial[i]), f"round {rep}, stream {i}: {_first_diff(outs[i].cpu(), serial[i])}"
+    for i in range(2):  # and against torch
+        m = int(pos[i, 0])
+        q, k, v = (qkv[i].cpu().view(rows, 3, H, 64)[:, j] for j in range(3))
+        kk, vv = torch.cat([kc0[i, 0, :, :m].cpu(), k[0][:, None]], 1), torch.cat([vc0[i, 0, :, :m].cpu(), v[0][:, None]], 1)
+        _close(serial[i][0].view(H, 64), F.scaled_dot_product_attention(q[0].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"split attention, ctx {m + 1}")
+
+
+@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "od_tc=4"])
 def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypatch):
     """The round-3 decode geometries (CBX_T3_TUNE: 12-column q/k/v tiles, 4-column o / down tiles, down projection without partial images)
     against the golden tokens of the reference (t3_l2: 2 layers, 64 steps) on the hipGraph + C-step path, and against the default geometry
@@ -143,8 +190,6 @@ def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypa
     kw = dict(max_new_tokens=20, uniforms=u3, ban_eos=True, **SAMP)
     ra, rb = eng.generate(synth.t3_cond(), tt, **kw), T3Engine(sd, dev).generate(synth.t3_cond(), tt, **kw)
     assert [t.tolist() for t in ra] == [t.tolist() for t in rb]
-    if "pair_" in tune or "chain" in tune:  # cbx_gemv_pair_f32 / cbx_gemv_chain_f32 inside the replayed graph: counters re-armed after every launch, no consumer ever timed out
-        assert not any(bool(st["dws"]["pair_ws"].any()) for st in eng._state.values())
 
 
 
@@ -172,26 +217,23 @@ def test_stream_with_growing_chunks_matches_the_oracle_schedule(dev):
 
 @pytest.mark.parametrize("M,N,K,ks,tile,res", [(16, 1024, 4096, 1, 4, True), (16, 1024, 4096, 2, 8, False), (9, 64, 2048, 1, 0, False)])
 def test_gemv_deep_batches_equal_plain(dev, M, N, K, ks, tile, res):
-    """cbx_set_gemv_deep_batches(1): an 8-wave plain packed GEMV whose waves own >= 256 of K requests 8 K blocks per load batch instead of 4
+    """cbx_gemv_t.flags & CBX_GEMV_DEEP: an 8-wave plain packed GEMV whose waves own >= 256 of K requests 8 K blocks per load batch instead of 4
     (the partial-free down projection: K = 4096 over 8 waves).  Same blocks in the same order: bit-identical."""
     from chatterbox_amd import ops
     x, w, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((M, (N + 31) // 32 * 32), 3)
     xp, wp = ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(w.to(dev), half_tile=tile)
     kw = dict(N=N, M=M, K=K, ksplit=ks, nw=8, w_packed=True, x_packed=True, half_tile=tile)
     outs = []
-    try:
-        for deep in (0, 1):
-            ops.lib.cbx_set_gemv_deep_batches(deep)
-            if res:
-                o = ops.pack_gemv_weight(r.to(dev))
-                ops.gemv(xp, wp, o, res=o, out_packed=True, **kw)
-            else:
-                o = torch.zeros((ks, M, N) if ks > 1 else (M, N), device=dev)
-                ops.gemv(xp, wp, o, **kw)
-            outs.append(o.cpu())
-    finally:
-        ops.lib.cbx_set_gemv_deep_batches(0)
-    assert torch.equal(outs[0], outs[1])
+    for deep in (0, 1):
+        fl = ops.gemv_flags(deep=deep)
+        if res:
+            o = ops.pack_gemv_weight(r.to(dev))
+            ops.gemv(xp, wp, o, res=o, out_packed=True, flags=fl, **kw)
+        else:
+            o = torch.zeros((ks, M, N) if ks > 1 else (M, N), device=dev)
+            ops.gemv(xp, wp, o, flags=fl, **kw)
+        outs.append(o.cpu())
+    assert torch.equal(outs[0], outs[1]), _first_diff(outs[0], outs[1])
     got = _unpack_operand(outs[1], M, N) - r[:, :N] if res else (outs[1].sum(0) if ks > 1 else outs[1])
     _close(got, F.linear(x, w), 6e-5 * max(1.0, math.sqrt(K / 256)), "deep-batch gemv")
 
@@ -218,31 +260,84 @@ def test_t3_prefill_on_the_bf16x6_kernels_samples_the_reference_tokens(dev, monk
 def test_decode_autotuner_adopts_only_bit_identical_geometries(dev):
     """T3Engine.autotune (chatterbox_amd/autotune.py): the candidates are timed in a child process on a 2-layer model of the real width; whatever
     is adopted samples the reference's golden tokens (t3_l2: 64 steps) through the hipGraph path, and every candidate row carries either a time
-    and an identity verdict or an error -- a reordering candidate is never the adopted one."""
-    from chatterbox_amd import autotune as at, ops, synth
+    and an identity verdict (logits of single steps over ragged contexts 1 .. 640 + the timed run's final logits) or an error -- a reordering
+    candidate is never the adopted one; the attention / epilogue / tile variants that claim the same arithmetic ARE identical on the hardware."""
+    from chatterbox_amd import autotune as at, synth
     from chatterbox_amd.t3 import T3Engine
     g = np.load(os.path.join(GOLD, "t3_l2.npz"))
     steps, n_text = int(g["steps"]), int(g["n_text"])
     eng = T3Engine(synth.t3_state_dict(2, 0), dev)
-    try:
-        rep = eng.autotune(B=8, ctx=128, steps=16, reps=2, timeout=240.0)
-        assert "error" not in rep, rep
-        rows = [r for r in rep["candidates"] if "variant" in r]
-        assert len(rows) >= len(at.TILE_VARIANTS) + len(at.ATTN_VARIANTS) and all(("ms_per_token" in r) != ("error" in r) for r in rows), rows
-        chained = [r for r in rows if r["variant"].get("chain")]
-        assert len(chained) == len(at.CHAIN_VARIANTS) and all("twin_identical" in r or "error" in r for r in chained), chained
-        assert all(r.get("twin_identical") for r in chained), f"a chained launch ended its measured run in another state than its separate launches: {chained}"
-        narrow = [r for r in rows if r["variant"] in (dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4))]
-        assert all(r.get("identical") for r in narrow), narrow  # same per-column arithmetic as the 16- / 8-column tiles
-        best = rep["best"]
-        if best:
-            assert next(r for r in rows if r["variant"] == best)["identical"] and not best.get("chain")  # (the partial-free geometry reorders)
-            assert all(eng.tune[k] == v for k, v in at.split_variant(best)[0].items())
-        u = torch.from_numpy(g["uniforms"])[None]
-        toks = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, **SAMP)
-        assert toks[0].tolist() == g["tokens"].tolist(), f"adopted geometry {best}"
-    finally:
-        eng.apply_variant(dict(T3Engine._TUNE), dict(at.LIB_KNOBS))  # the attention knobs are process-wide
+    rep = eng.autotune(B=8, ctx=128, steps=16, reps=2, timeout=300.0)
+    assert "error" not in rep, rep
+    rows = [r for r in rep["candidates"] if "variant" in r]
+    assert len(rows) >= len(at.TILE_VARIANTS) + len(at.ATTN_VARIANTS) and all(("ms_per_token" in r) != ("error" in r) for r in rows), rows
+    same_arith = [r for r in rows if "ms_per_token" in r and not any(k in r["variant"] for k in ("d_ks2", "d_nw2", "da_u"))]
+    assert all(r.get("identical") for r in same_arith), [r for r in same_arith if not r.get("identical")]
+    best = rep["best"]
+    if best:
+        assert next(r for r in rows if r["variant"] == best)["identical"]  # (the partial-free geometry reorders)
+        assert all(eng.tune[k] == v for k, v in at.split_variant(best)[0].items()) and all(eng.knobs[k] == v for k, v in at.split_variant(best)[1].items())
+    u = torch.from_numpy(g["uniforms"])[None]
+    toks = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, **SAMP)
+    assert toks[0].tolist() == g["tokens"].tolist(), f"adopted geometry {best}"
+
+
+def _green():
+    from chatterbox_amd import autotune as at
+    return [dict(v) for v in sorted(at.green_variants()) if v]
+
+
+@pytest.mark.parametrize("variant", _green(), ids=lambda v: ",".join(f"{k}={x}" for k, x in sorted(v.items())) or "builtin")
+def test_green_variant_is_bit_identical_and_samples_the_reference_tokens(dev, variant):
+    """Every geometry on the allow-list bench.py may adopt (chatterbox_amd/decode_green.json), on THIS hardware: (a) its logits over the ragged
+    probe contexts {1, 38, 63, 64, 65, 225, 640} at B = 8 and B = 1 (split grid) equal the built-in geometry's bit for bit -- or, for a
+    geometry that sums the down projection in another order, to 2e-4 of the logit scale --, (b) it samples the reference's golden tokens
+    (t3_l2, 64 steps, hipGraph + C-step path)."""
+    from chatterbox_amd import autotune as at, synth
+    from chatterbox_amd.t3 import T3Engine
+    g = np.load(os.path.join(GOLD, "t3_l2.npz"))
+    steps, n_text = int(g["steps"]), int(g["n_text"])
+    sd = synth.t3_state_dict(2, 0)
+    base, eng = T3Engine(sd, dev), T3Engine(sd, dev)
+    t, k = at.split_variant(variant)
+    eng.apply_variant(dict(eng.tune, **t), dict(eng.knobs, **k))
+    reorders = any(x in variant for x in ("d_ks2", "d_nw2", "o_nw2", "gu_nw", "da_u"))
+    for B in (8, 1):
+        a, b = base.probe_decode(B=B).cpu(), eng.probe_decode(B=B).cpu()
+        if reorders:
+            assert (a - b).abs().max() <= 2e-4 * max(1.0, float(a.abs().max())), f"B = {B}: {_first_diff(a, b)}"
+        else:
+            assert torch.equal(a, b), f"{variant}, B = {B}: probe logits differ from the built-in geometry: {_first_diff(a, b)}"
+    u = torch.from_numpy(g["uniforms"])[None]
+    toks = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, **SAMP)
+    assert toks[0].tolist() == g["tokens"].tolist(), f"{variant}: golden tokens"
+
+
+def test_two_engines_with_different_geometries_in_one_process(dev):
+    """ABI v10: the decode geometry travels per call (cbx_decode_attn_t, cbx_gemv_t.flags, cbx_t3_step_t.da_* / gemv_flags) -- nothing is
+    process-wide.  Two T3Engines with different geometries, their decode graphs captured one after the other and replayed INTERLEAVED, each
+    produce the tokens they produce alone (the reference's golden tokens); a graph captured before the other engine changed ITS geometry keeps
+    running its own kernels."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3 import T3Engine
+    g = np.load(os.path.join(GOLD, "t3_l2.npz"))
+    steps, n_text = int(g["steps"]), int(g["n_text"])
+    sd = synth.t3_state_dict(2, 0)
+    ea, eb = T3Engine(sd, dev), T3Engine(sd, dev)
+    ea.apply_variant(dict(ea.tune, qkv_tc=12), dict(ea.knobs, da_pipe=7, pre_epi=1))
+    eb.apply_variant(dict(eb.tune, od_tc=4), dict(eb.knobs, da_pipe=0, da_u=8))
+    u = torch.from_numpy(g["uniforms"])[None]
+    kw = dict(max_new_tokens=steps, uniforms=u, ban_eos=True, async_mode=True, run_steps=1, **SAMP)
+    ha = ea.generate(synth.t3_cond(), [synth.text_tokens(n_text)], slot=0, **kw)
+    hb = eb.generate(synth.t3_cond(), [synth.text_tokens(n_text)], slot=0, **kw)
+    sa, sb = next(iter(ea._state.values())), next(iter(eb._state.values()))
+    assert (sa["da"].pipeline, sa["da"].unroll, ea._gf()) == (7, 0, 1) and (sb["da"].pipeline, sb["da"].unroll, eb._gf()) == (0, 8, 0)
+    assert sa["da"].ws is None or sb["da"].ws is None or sa["da"].ws.data_ptr() != sb["da"].ws.data_ptr()
+    for _ in range(steps - 1):  # interleaved replays of the two captured graphs
+        ea.advance(ha, 1)
+        eb.advance(hb, 1)
+    ta, tb = ea.collect(ha)[0].tolist(), eb.collect(hb)[0].tolist()
+    assert ta == g["tokens"].tolist() and tb == g["tokens"].tolist()
 
 
 _EPI_BODIES = [("test_gemv_decode", (16, 3072, 1024, 1, 8)), ("test_gemv_decode", (40, 1024, 1024, 2, 4)), ("test_gemv_decode", (6, 64, 256, 1, 4)),
@@ -255,7 +350,7 @@ _EPI_BODIES = [("test_gemv_decode", (16, 3072, 1024, 1, 8)), ("test_gemv_decode"
 
 @pytest.mark.parametrize("name,args", _EPI_BODIES, ids=[f"{n}{list(a)}" for n, a in _EPI_BODIES])
 def test_gemv_epilogue_prefetch_equals_plain(dev, name, args, monkeypatch):
-    """cbx_set_gemv_epilogue_prefetch(1): the residual element, the bias and the LayerNorm-fold constants of a GEMV's epilogue are requested
+    """cbx_gemv_t.flags & CBX_GEMV_PRE_EPI: the residual element, the bias and the LayerNorm-fold constants of a GEMV's epilogue are requested
     with the first weight batch instead of after the reduction.  Every GEMV launch of the established bodies (bias, split-K, swiglu, RMSNorm
     and LayerNorm folds, in-place packed residual, narrow tiles, deep batches) runs twice -- knob off, knob on -- from the same memory state:
     outputs bit-identical, and the body's own comparison against torch holds with the knob on."""
@@ -266,24 +361,20 @@ def test_gemv_epilogue_prefetch_equals_plain(dev, name, args, monkeypatch):
 
     def both(x, w, out, **kw):
         keep = [(t, t.clone()) for t in (out, kw.get("x_out")) if t is not None]
-        ops.lib.cbx_set_gemv_epilogue_prefetch(0)
-        real(x, w, out, **kw)
+        fl = int(kw.pop("flags", 0))
+        real(x, w, out, flags=fl & ~ops.GEMV_PRE_EPI, **kw)
         plain = [t.clone() for t, _ in keep]
         for t, c in keep:
             t.copy_(c)
-        ops.lib.cbx_set_gemv_epilogue_prefetch(1)
-        r = real(x, w, out, **kw)
+        r = real(x, w, out, flags=fl | ops.GEMV_PRE_EPI, **kw)
         for (t, _), p in zip(keep, plain):
-            assert torch.equal(t.cpu(), p.cpu()), f"{name}{list(args)}: launch {n[0]} differs with the epilogue operands prefetched"
+            assert torch.equal(t.cpu(), p.cpu()), f"{name}{list(args)}: launch {n[0]} differs with the epilogue operands prefetched: {_first_diff(t.cpu(), p.cpu())}"
         n[0] += 1
         return r
 
     monkeypatch.setattr(ops, "gemv", both)
-    try:
-        body = getattr(test_ops_gpu, name, None) or getattr(sys.modules[__name__], name)
-        body(dev, *args)
-    finally:
-        ops.lib.cbx_set_gemv_epilogue_prefetch(0)
+    body = getattr(test_ops_gpu, name, None) or getattr(sys.modules[__name__], name)
+    body(dev, *args)
     assert n[0] >= 1
 
 
@@ -358,125 +449,3 @@ def test_encoder_flash_relpos_modes_match_the_materialised_encoder(dev):
         om = O.flow_inference(sd, toks[b:b + 1, :n], torch.tensor([n]), ref, z[b:b + 1, : 2 * (P + n)].transpose(1, 2), 3)
         err = (mel2[b, : 2 * n] - om[0].t()).abs()
         assert err.mean() <= 1e-4 and err.max() <= 1e-3, f"utt {b}: mel L1 {err.mean():.3e} max {err.max():.3e}"
-
-
-@pytest.mark.parametrize("M,tile", [(16, 8), (16, 0), (9, 4), (2, 12)])
-def test_gemv_pair_equals_the_two_launches(dev, M, tile):
-    """cbx_gemv_pair_f32: the o projection (+ residual, in place, packed) and the RMSNorm-folded gate | up SwiGLU GEMV that reads it, in ONE
-    launch whose consumer workgroups request their weights before they wait for the producers.  Bit-identical to the two cbx_gemv_f32
-    launches (same arithmetic, same order), twice in a row on the same counters (they re-arm themselves), error word untouched."""
-    from chatterbox_amd import ops
-    D, Fh = 1024, 2048
-    att, x0 = _r((M, D), 1), _r((M, D), 2)
-    wo, wg, wu, ln2 = _r((D, D), 3, 1 / math.sqrt(D)), _r((Fh, D), 4, 0.03), _r((Fh, D), 5, 0.03), 1 + 0.1 * _r((D,), 6)
-    pk = dict(w_packed=True, x_packed=True, M=M)
-    attp = ops.pack_gemv_weight(att.to(dev))
-    wop = ops.pack_gemv_weight(wo.to(dev), half_tile=tile)
-    wgu = ops.pack_gemv_weight(torch.cat([wg, wu]).to(dev), swiglu=True)
-    o_kw = lambda cur: dict(N=D, K=D, nw=8, res=cur, out_packed=True, half_tile=tile, **pk)
-    gu_kw = dict(N=Fh, K=D, swiglu=True, nw=8, norm_w=ln2.to(dev), out_packed=True, **pk)
-    rows16 = (M + 15) // 16 * 16
-
-    cur1, g1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev)
-    ops.gemv(attp, wop, cur1, **o_kw(cur1))
-    ops.gemv(cur1, wgu, g1, **gu_kw)
-
-    sync = torch.zeros(16, dtype=torch.int32, device=dev)
-    for rep in range(2):
-        cur2, g2 = ops.pack_gemv_weight(x0.to(dev)), torch.full((rows16, Fh), float("nan"), device=dev)
-        ops.gemv_pair((attp, wop, cur2, o_kw(cur2)), (cur2, wgu, g2, gu_kw), sync)
-        assert torch.equal(cur2.cpu(), cur1.cpu()), f"residual stream differs (launch {rep})"
-        assert torch.equal(_unpack_operand(g2.cpu(), M, Fh), _unpack_operand(g1.cpu(), M, Fh)), f"SwiGLU output differs (launch {rep})"
-        assert sync.cpu().tolist() == [0] * 16, f"counters re-armed, no time-out: {sync.cpu().tolist()}"
-    h = x0 + F.linear(att, wo)
-    hn = h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln2
-    _close(_unpack_operand(g2.cpu(), M, Fh), F.silu(F.linear(hn, wg)) * F.linear(hn, wu), 6e-5, "pair: SwiGLU(RMSNorm(x + att Wo^T))")
-
-
-@pytest.mark.parametrize("M,dtile,qtile", [(16, 4, 12), (5, 4, 0), (16, 8, 0)])
-def test_gemv_pair_down_and_next_qkv(dev, M, dtile, qtile):
-    """cbx_gemv_pair_f32 with the plain consumer: the down projection of a layer (K = 4096 over 8 waves = four load batches, residual added in
-    place) and the RMSNorm-folded q/k/v GEMV of the next layer that reads it -- bit-identical to the two launches, counters re-armed."""
-    from chatterbox_amd import ops
-    D, Fh = 1024, 4096
-    g, x0 = _r((M, Fh), 1, 0.3), _r((M, D), 2)
-    wd, wq, ln1 = _r((D, Fh), 3, 1 / math.sqrt(Fh)), _r((3 * D, D), 4, 1 / math.sqrt(D)), 1 + 0.1 * _r((D,), 5)
-    pk = dict(w_packed=True, x_packed=True, M=M)
-    gp = ops.pack_gemv_weight(g.to(dev))
-    wdp, wqp = ops.pack_gemv_weight(wd.to(dev), half_tile=dtile), ops.pack_gemv_weight(wq.to(dev), half_tile=qtile)
-    d_kw = lambda cur: dict(N=D, K=Fh, nw=8, res=cur, out_packed=True, half_tile=dtile, **pk)
-    q_kw = dict(N=3 * D, K=D, nw=8, norm_w=ln1.to(dev), half_tile=qtile, **pk)
-    cur1, q1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(M, 3 * D, device=dev)
-    ops.gemv(gp, wdp, cur1, **d_kw(cur1))
-    ops.gemv(cur1, wqp, q1, **q_kw)
-    sync = torch.zeros(16, dtype=torch.int32, device=dev)
-    for rep in range(2):
-        cur2, q2 = ops.pack_gemv_weight(x0.to(dev)), torch.full((M, 3 * D), float("nan"), device=dev)
-        ops.gemv_pair((gp, wdp, cur2, d_kw(cur2)), (cur2, wqp, q2, q_kw), sync)
-        assert torch.equal(cur2.cpu(), cur1.cpu()) and torch.equal(q2.cpu(), q1.cpu()), f"pair differs from the two launches (launch {rep})"
-        assert sync.cpu().tolist() == [0] * 16, f"counters re-armed, no time-out: {sync.cpu().tolist()}"
-    h = x0 + F.linear(g, wd)
-    _close(q2, F.linear(h * torch.rsqrt((h * h).mean(-1, keepdim=True) + 1e-5) * ln1, wq), 1e-4, "pair: RMSNorm(x + g Wd^T) Wqkv^T")
-
-
-@pytest.mark.parametrize("M,odtile,qtile", [(16, 4, 12), (3, 8, 0), (16, 0, 0)])
-def test_gemv_chain_equals_the_four_launches(dev, M, odtile, qtile, D=1024, Fh=2048):
-    """cbx_gemv_chain_f32: o projection (+ residual) -> RMSNorm + gate | up + SwiGLU -> down projection (+ residual) -> RMSNorm + q/k/v of the next
-    layer in ONE launch of four roles, each waiting on the arrival counters of the one in front of it after its first weight batch is in flight.
-    Bit-identical to the four cbx_gemv_f32 launches, three times in a row on the same counters."""
-    from chatterbox_amd import ops
-    att, x0 = _r((M, D), 1), _r((M, D), 2)
-    wo, wg, wu = _r((D, D), 3, 1 / math.sqrt(D)), _r((Fh, D), 4, 0.03), _r((Fh, D), 5, 0.03)
-    wd, wq = _r((D, Fh), 6, 1 / math.sqrt(Fh)), _r((3 * D, D), 7, 1 / math.sqrt(D))
-    ln2, ln1 = 1 + 0.1 * _r((D,), 8), 1 + 0.1 * _r((D,), 9)
-    pk = dict(w_packed=True, x_packed=True, M=M)
-    attp = ops.pack_gemv_weight(att.to(dev))
-    wop, wdp = ops.pack_gemv_weight(wo.to(dev), half_tile=odtile), ops.pack_gemv_weight(wd.to(dev), half_tile=odtile)
-    wgu, wqp = ops.pack_gemv_weight(torch.cat([wg, wu]).to(dev), swiglu=True), ops.pack_gemv_weight(wq.to(dev), half_tile=qtile)
-    rows16 = (M + 15) // 16 * 16
-
-    def four(cur, g, q):
-        res_kw = dict(nw=8, res=cur, out_packed=True, half_tile=odtile, **pk)
-        return [(attp, wop, cur, dict(N=D, K=D, **res_kw)),
-                (cur, wgu, g, dict(N=Fh, K=D, swiglu=True, nw=8, norm_w=ln2.to(dev), out_packed=True, **pk)),
-                (g, wdp, cur, dict(N=D, K=Fh, **res_kw)),
-                (cur, wqp, q, dict(N=3 * D, K=D, nw=8, norm_w=ln1.to(dev), half_tile=qtile, **pk))]
-
-    cur1, g1, q1 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev), torch.zeros(M, 3 * D, device=dev)
-    for x, w, out, kw in four(cur1, g1, q1):
-        ops.gemv(x, w, out, **kw)
-    sync = torch.zeros(64, dtype=torch.int32, device=dev)
-    for rep in range(3):
-        cur2, g2, q2 = ops.pack_gemv_weight(x0.to(dev)), torch.zeros(rows16, Fh, device=dev), torch.full((M, 3 * D), float("nan"), device=dev)
-        ops.gemv_chain(four(cur2, g2, q2), sync)
-        assert torch.equal(cur2.cpu(), cur1.cpu()) and torch.equal(g2.cpu(), g1.cpu()) and torch.equal(q2.cpu(), q1.cpu()), f"chain differs from the four launches (launch {rep})"
-        assert not sync.cpu().any(), f"counters re-armed, no time-out: {sync.cpu().tolist()}"
-    h = x0 + F.linear(att, wo)
-    rms = lambda t, w: t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-5) * w
-    hn = rms(h, ln2)
-    h2 = h + F.linear(F.silu(F.linear(hn, wg)) * F.linear(hn, wu), wd)
-    _close(q2, F.linear(rms(h2, ln1), wq), 2e-4, "chain vs torch")
-
-
-@pytest.mark.parametrize("name", ["turbo_l2", "nano_l12"])
-def test_t3_turbo_chained_decode_samples_the_reference_tokens(dev, name, monkeypatch):
-    """CBX_TURBO_TUNE="chain=1,od_tc=4,d_ks=1,d_nw=8": the GPT-2 decode step as attention + ONE launch per layer (cbx_gemv_chain_f32 in its GPT-2
-    form: biases, LayerNorm-folded roles, gelu_new) through the hipGraph path, against the golden tokens of the reference's inference_turbo
-    (Turbo d = 1024, 2 layers; Nano d = 768, 12 layers); the counters' error word stays clean."""
-    from chatterbox_amd import synth
-    from chatterbox_amd.t3_turbo import T3TurboEngine
-    g = np.load(os.path.join(GOLD, name + ".npz"))
-    L, d, steps, n_text = int(g["n_layers"]), int(g["d"]), int(g["steps"]), int(g["n_text"])
-    monkeypatch.setenv("CBX_TURBO_TUNE", "chain=1,od_tc=4,d_ks=1,d_nw=8")
-    eng = T3TurboEngine(synth.t3_turbo_state_dict(L, d, 0), dev)
-    assert eng.tune["chain"] == 1
-    u = torch.from_numpy(g["uniforms"])[None]
-    toks = eng.generate(synth.t3_cond(prompt_len=375), [synth.turbo_text_tokens(n_text)], max_gen_len=steps, uniforms=u, ban_eos=True,
-                        temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
-    assert toks[0].tolist() == g["tokens"].tolist()
-    assert not any(bool(st["dws"]["pair_ws"].any()) for st in eng._state.values())
-
-
-def test_gemv_chain_at_the_nano_width(dev):
-    """The same at d = 768 / 3072 (Nano's GPT-2 small): three K blocks per wave, i.e. a load batch whose fourth slot is idle."""
-    test_gemv_chain_equals_the_four_launches(dev, 5, 4, 0, D=768, Fh=3072)

@@ -490,7 +490,7 @@ class T3Engine:
             d.logits, d.ld_logits, d.sampler = p(st["logits"]), st["logits"].stride(0), ctypes.pointer(sp)
             da = st["da"]  # the step's own attention geometry + split-context workspace, GEMV flags (ABI v10: nothing process-wide)
             d.da_unroll, d.da_pipeline, d.da_split_min, d.gemv_flags = da.unroll, da.pipeline, da.split_min, self._gf()
-            d.da_ws, d.da_cnt, d.da_pairs = p(da.ws), p(da.cnt), da.max_pairs
+            d.da_ws, d.da_cnt, d.da_pairs = ops._p(da.ws), ops._p(da.cnt), (da.max_pairs if da.ws is not None else 0)  # None: >= 128 (row, head) pairs never split
             st["cstep"] = (d, layers, sp)  # keep the host structures alive
         check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
 

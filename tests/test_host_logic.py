@@ -454,6 +454,21 @@ def test_decode_autotuner_adoption_rules(monkeypatch):
     assert "validate_error" in rep
 
 
+def test_c_step_descriptor_accepts_a_state_without_split_workspace():
+    """A decode state with >= 128 (row, head) pairs (B = 8: 16 rows x 16 heads) owns no split-context workspace: the C step descriptor must
+    carry NULL / 0 for it (round 4's first hardware run died on `None.data_ptr()` here -- the emulator tests only built small states)."""
+    import torch
+    from chatterbox_amd import ops
+    from chatterbox_amd._lib import T3Step
+    g = ops.DecodeAttnGeom(torch.device("cpu"), split=False)
+    assert g.ws is None and ops._p(g.ws) is None
+    d = T3Step()
+    d.da_ws, d.da_cnt, d.da_pairs = ops._p(g.ws), ops._p(g.cnt), (g.max_pairs if g.ws is not None else 0)
+    assert not d.da_ws and not d.da_cnt and d.da_pairs == 0
+    g2 = ops.DecodeAttnGeom(torch.device("cpu"), split=True)
+    assert g2.ws.numel() == 128 * 8 * 66 and g2.cnt.dtype == torch.int32 and not bool(g2.cnt.any())
+
+
 def test_green_allow_list_is_canonical_and_contains_the_builtin_geometry():
     """chatterbox_amd/decode_green.json (the geometries bench.py may adopt): canonical keys only, every entry made of knobs the engine / library
     know, the built-in geometry always on it; canon() drops default-valued keys so that the autotuner's composed candidates are found."""

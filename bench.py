@@ -242,13 +242,14 @@ def pmc_traffic(kernel_substr, source="flow_only"):
     import csv
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
+        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
         if f is None:
             return None, None
         used = os.path.basename(f)[:3]
         n = 0
         for r in csv.DictReader(open(f)):
-            if kernel_substr in r["kernel"] and r["counter"] == c:  # several template instances: launch-weighted mean
+            subs = kernel_substr if isinstance(kernel_substr, tuple) else (kernel_substr,)
+            if any(k in r["kernel"] for k in subs) and r["counter"] == c:  # several template instances: launch-weighted mean
                 tot[c] = tot.get(c, 0.0) + float(r["sum"]) * 1024.0
                 n += int(r["launches"])
         if n:
@@ -304,7 +305,7 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
         tot_n = sum(v["launches"] for v in gemv.values())
         per_step_ms = sum(v["ms"] / v["launches"] * v["per_step"] for v in gemv.values())
         gbs = tot_b / (tot_ms * 1e-3) / 1e9
-        e = dict(bound="hbm", kernel="gemv_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
+        e = dict(bound="hbm", kernel="gemv_kernel / gemv_ct_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
                  achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                  launches=tot_n, avg_launch_us=round(1e3 * tot_ms / tot_n, 2), algorithmic_bytes_per_launch=round(tot_b / tot_n, 0),
                  share_of_step=round(per_step_ms * 1e-3 * n_decode / (elapsed / steps), 3),
@@ -314,7 +315,7 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
                  note="average launch duration INCLUDING the dependent-launch boundary (~1.2 us): events bracket hipGraph replays of "
                       "30 back-to-back launches (one per layer, 1 GB of distinct weights per sweep, so nothing is served from the "
                       "256 MB Infinity Cache); rocprofv3's per-kernel average excludes that boundary")
-        tr, src = pmc_traffic("gemv_kernel", "t3_eager")
+        tr, src = pmc_traffic(("gemv_kernel", "gemv_ct_kernel"), "t3_eager")
         e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
         out["gemv_f32"] = e
     return out
@@ -338,7 +339,10 @@ def gemv_sweeps(t3, rows, reps=6):
         pd = f(max(dks, 1), r16, t3.D) * 0.1
         pk = dict(w_packed=True, x_packed=True, M=rows, flags=t3._gf())  # the adopted geometry's GEMV flags (cbx_gemv_t.flags)
         red = dict(xpart=pd, x_out=x2) if dks > 1 else {}
-        calls = {"qkv": lambda lw: ops.gemv(x, t3._image(lw, "wqkv", qtc), qkv, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk),
+        qks, qct = t3._qks(), int(tn.get("qkv_ct") or 3)
+        qparts, qssq = torch.empty(max(qks, 1), rows, 3 * t3.D, device=dev), torch.zeros(max(qks, 1), 16, device=dev)
+        calls = {"qkv": (lambda lw: ops.gemv(x, lw["wqkv_pk"], qparts, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], col_tiles=qct, ksplit=qks, ssq_out=qssq, **red, **pk)) if qks > 1
+                 else (lambda lw: ops.gemv(x, t3._image(lw, "wqkv", qtc), qkv, N=3 * t3.D, K=t3.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **red, **pk)),
                  "o": lambda lw: ops.gemv(att, t3._image(lw, "wo", odtc), x2, N=t3.D, K=t3.D, nw=tn["o_nw2"], res=x2, out_packed=True,
                                           half_tile=ht, **pk),
                  "gate_up": lambda lw: ops.gemv(x, lw["wgu_pk"], gg, N=t3.F, K=t3.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"],

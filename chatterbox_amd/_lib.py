@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 10  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 11  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -53,7 +53,8 @@ class GemvParams(ctypes.Structure):
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("out", c_f), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksplit", c_int), ("nw", c_int), ("swiglu", c_int), ("act", c_int), ("ldx", c_long), ("ldw", c_long), ("ldo", c_long),
                 ("part_stride", c_long), ("w_packed", c_int), ("x_packed", c_int), ("half_tile", c_int), ("out_packed", c_int),
-                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("w_bf16", c_int), ("flags", c_int), ("ln_cw", c_f), ("ln_cb", c_f)]
+                ("norm_w", c_f), ("res", c_f), ("eps", c_float), ("n_xpart", c_int), ("xpart", c_f), ("xpart_stride", c_long), ("x_out", c_f), ("w_bf16", c_int), ("flags", c_int), ("ln_cw", c_f), ("ln_cb", c_f),
+                ("col_tiles", c_int), ("ssq_out", c_f)]  # ABI v11
 
 
 GEMV_PRE_EPI, GEMV_DEEP = 1, 2  # cbx_gemv_t.flags
@@ -63,7 +64,8 @@ class DecodeAttnParams(ctypes.Structure):  # cbx_decode_attn_t (ABI v10)
     _fields_ = [("qkv", c_f), ("positions", c_f), ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("o", c_f),
                 ("rows", c_int), ("n_heads", c_int), ("ld_qkv", c_long), ("o_ld", c_long), ("o_packed", c_int),
                 ("cache_row_stride", c_long), ("cache_head_stride", c_long), ("scale", c_float),
-                ("unroll", c_int), ("pipeline", c_int), ("split_min", c_int), ("split_ws", c_f), ("split_cnt", c_f), ("split_pairs", c_long)]
+                ("unroll", c_int), ("pipeline", c_int), ("split_min", c_int), ("split_ws", c_f), ("split_cnt", c_f), ("split_pairs", c_long),
+                ("qkv_nparts", c_int), ("qkv_part_stride", c_long), ("qkv_ssq", c_f), ("rms_dim", c_int), ("rms_eps", c_float)]  # ABI v11
 
 
 class SamplerParams(ctypes.Structure):
@@ -91,7 +93,8 @@ class T3Step(ctypes.Structure):
                 ("g", c_f), ("pd", c_f), ("logits", c_f), ("ld_logits", c_long), ("sampler", ctypes.POINTER(SamplerParams)),
                 ("qkv_tile", c_int),  # ABI v9
                 ("da_unroll", c_int), ("da_pipeline", c_int), ("da_split_min", c_int), ("gemv_flags", c_int),  # ABI v10
-                ("da_ws", c_f), ("da_cnt", c_f), ("da_pairs", c_long)]
+                ("da_ws", c_f), ("da_cnt", c_f), ("da_pairs", c_long),
+                ("qkv_ksplit", c_int), ("qkv_ct", c_int), ("head_ct", c_int), ("qkv_ssq", c_f)]  # ABI v11
 
 
 _SIGS = {

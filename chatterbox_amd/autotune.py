@@ -27,45 +27,70 @@ import subprocess
 import sys
 import time
 
-# geometry candidates of the GEMVs (keys of T3Engine.tune) -- {} is the geometry the engine currently runs
-TILE_VARIANTS = (dict(), dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4),
-                 # another fp32 summation order of the down projection (no split-K partial images: it adds the residual itself and the next
-                 # q/k/v GEMV folds nothing), 8 or 16 waves per workgroup, the 8-wave form with one deep load batch per wave
-                 dict(od_tc=4, d_ks2=1, d_nw2=8), dict(od_tc=4, d_ks2=1, d_nw2=16), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=16),
-                 dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8, deep=1))
-# process-wide library knobs of the decode attention (cbx_set_decode_attn_pipeline / _unroll), tried on top of the best tile geometry
-ATTN_VARIANTS = (dict(da_pipe=1), dict(da_pipe=2), dict(da_pipe=3), dict(da_pipe=4), dict(da_pipe=5), dict(da_pipe=6), dict(da_pipe=7),
-                 dict(da_pipe=1, da_u=8), dict(da_u=8))
-# process-wide knob of every GEMV launch (cbx_set_gemv_epilogue_prefetch), tried on top of the best geometry so far
-EPI_VARIANTS = (dict(pre_epi=1),)
-LIB_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)  # per-engine launch knobs (cbx_decode_attn_t.pipeline / unroll, cbx_gemv_t.flags) and their defaults
+# Geometry candidates, each a DIFF on top of the geometry the engine currently runs ({} = keep it).  GEMV side (keys of T3Engine.tune):
+TILE_VARIANTS = (dict(),
+                 dict(qkv_ks=0, head_ct=0),                  # the one-tile q/k/v + head kernels of rounds 2-3 (every workgroup reads all of x + the partial images)
+                 dict(head_ct=0),
+                 dict(half_tiles=0, d_ks2=4, d_nw2=8),       # down projection on 16-column tiles, 4 split-K partial images (x : W = 1 : 1 per workgroup)
+                 dict(od_tc=4))                              # o / down projections on 4-column tiles (256 workgroups)
+# launch knobs of the decode attention (cbx_decode_attn_t.pipeline / unroll), tried on top of the best tile geometry
+ATTN_VARIANTS = (dict(da_pipe=0), dict(da_pipe=1), dict(da_pipe=3), dict(da_pipe=5))
+# cbx_gemv_t.flags of every GEMV launch, tried on top of the best geometry so far
+EPI_VARIANTS = (dict(pre_epi=0),)
+# the engines' default launch knobs (cbx_decode_attn_t.pipeline / unroll, cbx_gemv_t.flags): round 4's hardware A/B (profiles/r04_decode_geometry_ab.log)
+LIB_KNOBS = dict(da_pipe=7, da_u=4, deep=0, pre_epi=1)
+# FROZEN reference geometry the allow-list is written against (the round-3 defaults): an entry of decode_green.json is the set of keys in which a
+# full geometry (tune + knobs) differs from THIS, so entries keep their meaning when the engines' defaults move
+BASE_TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, qkv_ks=0, qkv_ct=3, head_ct=0)
+BASE_KNOBS = dict(da_pipe=0, da_u=4, deep=0, pre_epi=0)
 PROBE_CTXS = (1, 38, 63, 64, 65, 225, 640)
 GREEN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_green.json")
 
 
-def canon(v):
-    """Canonical form of a variant: default-valued keys dropped, sorted tuple (the key of the allow-list)."""
-    from .t3 import T3Engine
-    d = dict(T3Engine._TUNE, **LIB_KNOBS)
-    return tuple(sorted((k, int(x)) for k, x in v.items() if int(x) != d.get(k)))
+def canon(tune, knobs=None):
+    """Canonical form of a FULL geometry (T3Engine.tune [+ knobs]; missing keys = the frozen base's): the sorted tuple of the keys in which it
+    differs from BASE_TUNE / BASE_KNOBS -- the key of the allow-list."""
+    full = dict(BASE_TUNE, **BASE_KNOBS)
+    full.update(tune)
+    full.update(knobs or {})
+    if not full.get("qkv_ks"):
+        full["qkv_ct"] = BASE_TUNE["qkv_ct"]  # (column tiles of a form that is off)
+    base = dict(BASE_TUNE, **BASE_KNOBS)
+    return tuple(sorted((k, int(x)) for k, x in full.items() if k in base and int(x) != base[k]))
 
 
 def green_variants():
-    """The committed allow-list: variants that passed their hardware tests on an MI355X (written by scripts/green_variants.py from a GPU run,
-    re-checked by tests/test_zz_abi_v9_gpu.py::test_green_variant_*).  The built-in geometry {} is always on it."""
+    """The committed allow-list: full geometries (canon form) that passed their hardware tests on an MI355X (written by scripts/green_variants.py from
+    a GPU run, re-checked by tests/test_zz_abi_v9_gpu.py::test_green_variant_*).  The frozen base geometry is always on it (three rounds of goldens)."""
     try:
         with open(GREEN_FILE) as f:
             rows = json.load(f)["green"]
     except (OSError, ValueError, KeyError):
         rows = []
-    return {canon({})} | {canon(v) for v in rows}
+    return {()} | {canon(v) for v in rows}
+
+
+def composed_candidates(tune0, knobs0):
+    """Every geometry tune_decode can reach from (tune0, knobs0): tile diff x attention diff x epilogue diff, as full (tune, knobs) pairs."""
+    out, seen = [], set()
+    for t in TILE_VARIANTS:
+        for a in (dict(),) + ATTN_VARIANTS:
+            for e in (dict(),) + EPI_VARIANTS:
+                tv, kv = split_variant(dict(t, **a, **e))
+                full = (dict(tune0, **tv), dict(knobs0, **kv))
+                c = canon(*full)
+                if c not in seen:
+                    seen.add(c)
+                    out.append(full)
+    return out
 
 
 def env_knobs():
     """The engines' launch knobs as the environment asks for them (CBX_DA_PIPE, CBX_DA_U, CBX_GEMV_DEEP, CBX_GEMV_PRE_EPI: A/B scripts)."""
     e = os.environ.get
-    return dict(da_pipe=int(e("CBX_DA_PIPE") or 0) & 7, da_u=int(e("CBX_DA_U") or 0) or 4, deep=int(e("CBX_GEMV_DEEP") or 0),
-                pre_epi=int(bool(int(e("CBX_GEMV_PRE_EPI") or 0))))
+    i = lambda name, dflt: int(e(name)) if e(name) not in (None, "") else dflt
+    return dict(da_pipe=i("CBX_DA_PIPE", LIB_KNOBS["da_pipe"]) & 7, da_u=i("CBX_DA_U", 0) or LIB_KNOBS["da_u"], deep=int(bool(i("CBX_GEMV_DEEP", LIB_KNOBS["deep"]))),
+                pre_epi=int(bool(i("CBX_GEMV_PRE_EPI", LIB_KNOBS["pre_epi"]))))
 
 
 def split_variant(v):
@@ -94,6 +119,8 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         ms, lg = eng.measure_decode(B=B, ctx=ctx, steps=steps, reps=reps, use_graph=use_graph)
         return ms, torch.cat([probe.flatten(), lg.flatten(), eng.last_measure["final_logits"].flatten()])
 
+    if green is not None and canon(base_tune, base_knobs) not in green:
+        raise RuntimeError(f"the engine's current decode geometry {canon(base_tune, base_knobs)} is not on the hardware-green allow-list (decode_green.json)")
     ms0, ref = run({})
     scale = max(1.0, float(ref.abs().max()))
     rows.append(dict(variant={}, ms_per_token=round(ms0, 5), identical=True, reorders=False, max_abs_diff=0.0, valid=True))
@@ -105,7 +132,7 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
         if not v or key in seen:
             return
         seen[key] = True
-        if green is not None and canon(dict(full(v)[0], **full(v)[1])) not in green:
+        if green is not None and canon(*full(v)) not in green:
             rows.append(dict(variant=v, skipped="not on the hardware-green allow-list (decode_green.json)"))
             return
         try:

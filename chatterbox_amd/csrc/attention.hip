@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
                                                                float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ o,
                                                                int n_heads, long ld_qkv, long o_ld, int o_packed, long row_stride,
                                                                long head_stride, float scale, float* split_ws, int* split_cnt,
-                                                               int split_min_ctx) {
+                                                               int split_min_ctx, int qkv_nparts, long qkv_part_stride,
+                                                               const float* __restrict__ qkv_ssq, float rms_dim, float rms_eps) {
     // gridDim.z = S > 1: the context of a (row, head) is split over S workgroups (on S CUs: one workgroup cannot pull a long context
     // faster than its CU's memory path, 50-60 GB/s); each leaves {max, sum, 64 numerators} in split_ws and the LAST to arrive (a ticket on
     // split_cnt, agent-scope release before it, acquire after it: cdna_hip_programming.md guideline 16) merges them in split order.
@@ -567,7 +568,20 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
 
     if (wid == 0) {
         const float* qp = qkv + (long)row * ld_qkv + head * 64;
-        const float qv = qp[lane], kn0 = qp[(long)n_heads * 64 + lane], vn0 = qp[(long)n_heads * 128 + lane];
+        float qv = qp[lane], kn0 = qp[(long)n_heads * 64 + lane], vn0 = qp[(long)n_heads * 128 + lane];
+        if (qkv_nparts > 1) {  // uniform (kernel argument): qkv holds split-K partial sums of the RMSNorm-folded projection (cbx_gemv_t.col_tiles,
+            // ksplit > 1): added in fixed order, then rstd[row] of the projection's input.  Loads unconditional (clamped part index), one round trip
+            float sq = qkv_ssq[row];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const bool onj = j < qkv_nparts;
+                const float* qj = qp + (onj ? j : 0) * qkv_part_stride;
+                const float a = qj[lane], b = qj[(long)n_heads * 64 + lane], cc = qj[(long)n_heads * 128 + lane], sj = qkv_ssq[(onj ? j : 0) * 16 + row];
+                if (onj) qv += a, kn0 += b, vn0 += cc, sq += sj;
+            }
+            const float rstd = rsqrtf(sq / rms_dim + rms_eps);  // the expression of gemv_kernel / gemv_ct_kernel with ksplit == 1
+            qv *= rstd, kn0 *= rstd, vn0 *= rstd;
+        }
         const float c = cos_t ? cos_t[(long)pos * 64 + lane] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + lane] : 0.f;  // GPT-2: no RoPE
         const float sgn = lane < 32 ? -1.f : 1.f;
         const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
@@ -845,6 +859,10 @@ extern "C" int cbx_decode_attn_rope(const cbx_decode_attn_t* pd, void* stream) {
     CBX_REQUIRE(a.unroll == 0 || a.unroll == 4 || a.unroll == 8 || a.unroll == 16, "decode_attn_rope: unroll must be 0 (= 4), 4, 8 or 16");
     CBX_REQUIRE(a.pipeline >= 0 && a.pipeline <= 7 && a.split_min >= 0, "decode_attn_rope: pipeline in 0 .. 7, split_min >= 0");
     CBX_REQUIRE(!(a.pipeline & 4) || a.cache_head_stride >= 64 * 64, "decode_attn_rope: the speculative first step needs 64 cache positions per (row, head)");
+    CBX_REQUIRE(a.qkv_nparts >= 0 && a.qkv_nparts <= 4 && (a.qkv_nparts <= 1 || (a.qkv_ssq && a.rms_dim > 0 && a.rows <= 16 && a.qkv_part_stride % 4 == 0)),
+                "decode_attn_rope: qkv_nparts in 0 .. 4; partial sums need qkv_ssq, rms_dim and rows <= 16");
+    const int nparts = a.qkv_nparts > 1 ? a.qkv_nparts : 1;
+    const float inv_dim = a.rms_dim > 0 ? (float)a.rms_dim : 1.f;  // (passed as the dimension itself)
     // contexts shorter than this are walked by one workgroup even on a split grid (the hand-off costs more than it saves below ~3 round trips)
     const int split_min = a.split_min > 0 ? a.split_min : 512;
     const long pairs = (long)a.rows * a.n_heads;
@@ -869,10 +887,12 @@ extern "C" int cbx_decode_attn_rope(const cbx_decode_attn_t* pd, void* stream) {
     do {                                                                                                                                   \
         if (S > 1)                                                                                                                         \
             hipLaunchKernelGGL((decode_attn_rope_kernel<U, true, P, N, SP>), grid, block, 0, st, a.qkv, a.positions, a.cos_t, a.sin_t, a.kc, a.vc, a.o, a.n_heads, \
-                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min);        \
+                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min, nparts,  \
+                               a.qkv_part_stride, a.qkv_ssq, inv_dim, a.rms_eps);                                                          \
         else                                                                                                                               \
             hipLaunchKernelGGL((decode_attn_rope_kernel<U, false, P, N, SP>), grid, block, 0, st, a.qkv, a.positions, a.cos_t, a.sin_t, a.kc, a.vc, a.o, a.n_heads, \
-                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min);        \
+                               a.ld_qkv, a.o_ld, a.o_packed, a.cache_row_stride, a.cache_head_stride, a.scale, ws, cnt, split_min, nparts,  \
+                               a.qkv_part_stride, a.qkv_ssq, inv_dim, a.rms_eps);                                                          \
     } while (0)
     const int pipe = a.pipeline;
     if (pipe & 4) {  // speculative first step (4 rows per lane group and step), with or without the pipelined stream / non-temporal loads

@@ -322,6 +322,168 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Column-tile / split-K form of the RMSNorm-folded packed GEMV (ABI v11, cbx_gemv_t.col_tiles >= 1): the q/k/v projection and the speech head
+// of the decode step.  Why: the launch timeline of the decode step (profiles/r04_decode_launch_timeline.txt) shows these kernels bound by the
+// bytes a CU moves through its own vector-memory path, and in the one-tile form above HALF or more of those bytes are ACTIVATIONS: a
+// workgroup that owns 16 output columns reads the whole 16-row x (64 KiB, K = 1024) for 64 KiB of weights -- and with the two split-K partial
+// images of the producing down projection folded in (NP = 2) 192 KiB for 64.  Here a workgroup owns CT column tiles that share every x
+// register (x : W = 1 : CT) and, with ksplit > 1, only a 1/ksplit slice of K (x and the partial images shrink by ksplit as well):
+//   q/k/v, CT = 3, ksplit = 4:  48 KiB of weights + 3 x 16 KiB of x / partial images per workgroup (was 64 + 192), 64 x 4 = 256 workgroups;
+//   head,  CT = 2, ksplit = 1:  257 workgroups (one round of the chip instead of two) at 128 + 192 KiB (was 64 + 192 each, 513 of them).
+// ksplit > 1 leaves UN-normalised partial sums out[ks][m][n] = sum_{k in slice} (x[m][k] norm_w[k]) W[n][k] plus the slice's sum of squares
+// ssq_out[ks][m] (written by column group 0): rstd factors out of the contraction, so the CONSUMER -- the decode attention, which reads 192
+// values per workgroup -- adds the ksplit partials in fixed order and applies rstd = rsqrt(sum_ks ssq / K + eps).  ksplit == 1: rstd in the
+// epilogue as above.  Same MFMA, same fixed-order LDS reduction over the 8 waves; deterministic.
+template <int CT, int NP, int DEPTH>
+__global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float red[NW * CT * 256];
+    __shared__ float ssq[NW * 16];
+    CBX_TRC_DECL;
+    CBX_TRC_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ks = blockIdx.y;
+    const long KB = p.K >> 5;                       // 32-deep K blocks of a row
+    const int nit = (int)(KB / (p.ksplit * NW));    // blocks per wave
+    const long kb0 = ((long)ks * NW + w) * nit;     // first block of this wave
+    const int ntiles = (p.N + 15) >> 4;
+    const int tile0 = blockIdx.x * CT;
+    const float* wp[CT];
+    bool wok[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        wok[c] = tile0 + c < ntiles;
+        wp[c] = p.W + ((long)(wok[c] ? tile0 + c : tile0) * KB + kb0) * 512 + lane * 4;  // [tile][K/32][2][64][4]; a tile past N re-reads tile0
+    }
+    const long xo = kb0 * 512 + lane * 4;            // packed x: [K/32][2][64][4] (one 16-row tile)
+    const float* nwp = p.norm_w + kb0 * 32 + 8 * (lane >> 4);
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f;
+    const bool xok = (lane & 15) < p.M;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // DEPTH = K blocks requested per batch (picked by the host so that it divides the wave's block count: an idle slot would re-read a block,
+    // i.e. spend the very per-CU bytes this form saves; registers: DEPTH * 2 * (CT + NP + 2) float4)
+    for (int it0 = 0; it0 < nit; it0 += DEPTH) {
+        f32x4 wv[DEPTH][CT][2], xv[DEPTH][2], nv[DEPTH][2], pv[DEPTH][NP > 0 ? NP : 1][2];
+        bool on[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            on[d] = it0 + d < nit;
+            const int blk = on[d] ? it0 + d : 0;      // loads stay unconditional (counted waits): an idle slot re-reads block 0
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                wv[d][c][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp[c] + blk * 512));
+                wv[d][c][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp[c] + blk * 512 + 256));
+            }
+            xv[d][0] = *reinterpret_cast<const f32x4*>(p.x + xo + blk * 512);
+            xv[d][1] = *reinterpret_cast<const f32x4*>(p.x + xo + blk * 512 + 256);
+            nv[d][0] = *reinterpret_cast<const f32x4*>(nwp + blk * 32);
+            nv[d][1] = *reinterpret_cast<const f32x4*>(nwp + blk * 32 + 4);
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const float* pp = p.xpart + (long)j * p.xpart_stride + xo + blk * 512;
+                    pv[d][j][0] = *reinterpret_cast<const f32x4*>(pp);
+                    pv[d][j][1] = *reinterpret_cast<const f32x4*>(pp + 256);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef CBX_TRACE
+        if (it0 == 0) CBX_TRC_STAMP(1);
+#endif
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 xq = xv[d][h];
+                if constexpr (NP > 0) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
+                    if (p.x_out && blockIdx.x == 0 && on[d])  // the reduced residual stream (this wave's K slice), same packed address as x
+                        *reinterpret_cast<f32x4*>(p.x_out + xo + (it0 + d) * 512 + h * 256) = xq;
+                }
+                xq = (on[d] && xok) ? xq : zero4;
+                ss += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
+                xq *= nv[d][h];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const f32x4 wq = (on[d] && wok[c]) ? wv[d][c][h] : zero4;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[s], wq[s], acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef CBX_TRACE
+            if (it0 == 0 && d == 0) {
+                asm volatile("s_nop 0" ::"v"(acc[0][0]));
+                CBX_TRC_STAMP(2);
+            }
+#endif
+        }
+    }
+#ifdef CBX_TRACE
+    asm volatile("s_nop 0" ::"v"(acc[0][0]));
+    CBX_TRC_STAMP(3);
+#endif
+    // fixed-order reduction over the 8 K slices of this workgroup.  D map of the MFMA: row = q*4 + r, col = c16
+    const int c16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(w * CT + c) * 256 + (q * 4 + r) * 16 + c16] = acc[c][r];
+    {
+        float v = ss;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) ssq[w * 16 + c16] = v;
+    }
+    __syncthreads();
+    CBX_TRC_STAMP(4);
+    for (int e = tid; e < CT * 256; e += NW * 64) {
+        const int c = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
+        const int n = (tile0 + c) * 16 + col;
+        if (row >= p.M || n >= p.N) continue;
+        float v = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v += red[(ww * CT + c) * 256 + rc];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) sq += ssq[ww * 16 + row];
+        if (p.ksplit == 1) {
+            v *= rsqrtf(sq / (float)p.K + p.eps);
+        } else if (blockIdx.x == 0 && c == 0 && col == 0) {
+            p.ssq_out[ks * 16 + row] = sq;  // this K slice's sum of squares of row `row` (identical in every column group: group 0 writes it)
+        }
+        p.out[(long)ks * p.part_stride + (long)row * p.ldo + n] = v;
+    }
+#ifdef CBX_TRACE
+    CBX_TRC_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CBX_TRC_STAMP(6);
+    CBX_TRC_FLUSH(0x10000000u | 0x2000000u | (unsigned)(NP << 20) | (unsigned)(p.N & 0xfffff));
+#endif
+}
+
+template <int CT, int NP>
+int launch_ct_np(const cbx_gemv_t& p, hipStream_t st) {
+    const int ntiles = (p.N + 15) / 16;
+    dim3 grid((ntiles + CT - 1) / CT, p.ksplit);
+    const int nit = p.K / (32 * p.ksplit * 8);  // K blocks per wave
+    if (nit % 2 == 0) hipLaunchKernelGGL((gemv_ct_kernel<CT, NP, 2>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemv_ct_kernel<CT, NP, 1>), grid, dim3(512), 0, st, p);
+    return cbx_check_launch("gemv (column tiles)");
+}
+
+template <int CT>
+int launch_ct(const cbx_gemv_t& p, hipStream_t st) {
+    if (p.n_xpart == 2) return launch_ct_np<CT, 2>(p, st);
+    if (p.n_xpart == 4) return launch_ct_np<CT, 4>(p, st);
+    return launch_ct_np<CT, 0>(p, st);
+}
+
 // process-wide TEST HOOKS: ORed into cbx_gemv_t.flags of every cbx_gemv_f32 launch (the engines set the flags per launch instead)
 int g_gemv_deep = getenv("CBX_GEMV_DEEP") ? atoi(getenv("CBX_GEMV_DEEP")) : 0;  // cbx_set_gemv_deep_batches
 int g_gemv_pre_epi = getenv("CBX_GEMV_PRE_EPI") ? atoi(getenv("CBX_GEMV_PRE_EPI")) : 0;  // cbx_set_gemv_epilogue_prefetch
@@ -588,7 +750,7 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     p.flags = (p.flags & (CBX_GEMV_PRE_EPI | CBX_GEMV_DEEP)) | (g_gemv_pre_epi ? CBX_GEMV_PRE_EPI : 0) | (g_gemv_deep ? CBX_GEMV_DEEP : 0);
     CBX_REQUIRE(p.x && p.W && p.out, "gemv: null operand");
     CBX_REQUIRE(p.M >= 1 && p.M <= 64 && p.N > 0 && p.K > 0, "gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
-    CBX_REQUIRE(p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);
+    CBX_REQUIRE(p.col_tiles > 0 || p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);
     CBX_REQUIRE(p.ldx % 4 == 0 && p.ldw % 4 == 0 && (((uintptr_t)p.x | (uintptr_t)p.W) & 15) == 0, "gemv: alignment");
     CBX_REQUIRE(!p.swiglu || (p.ksplit == 1 && p.N % 32 == 0), "gemv: swiglu needs ksplit == 1 and N %% 32 == 0");
     CBX_REQUIRE(p.half_tile == 0 || p.half_tile == 1 || p.half_tile == 8 || p.half_tile == 12 || p.half_tile == 4, "gemv: half_tile must be 0, 1 (= 8), 8, 12 or 4");
@@ -596,13 +758,27 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(!p.act || p.ksplit == 1, "gemv: an activation epilogue needs ksplit == 1");
     CBX_REQUIRE(!p.x_packed || p.w_packed, "gemv: x_packed needs w_packed");
     CBX_REQUIRE(!p.w_bf16 || (p.w_packed && p.x_packed && p.M <= 16), "gemv: w_bf16 needs w_packed, x_packed and M <= 16");
-    CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && p.ksplit == 1), "gemv: norm_w needs w_packed, x_packed and ksplit == 1");
+    CBX_REQUIRE(!p.norm_w || (p.w_packed && p.x_packed && (p.ksplit == 1 || p.col_tiles > 0)), "gemv: norm_w needs w_packed, x_packed and ksplit == 1 (or col_tiles)");
     CBX_REQUIRE(!p.res || p.ksplit == 1, "gemv: res needs ksplit == 1");
     CBX_REQUIRE(!p.ln_cw || (p.norm_w && p.ln_cb && !p.swiglu && !p.bias), "gemv: the LayerNorm form needs norm_w, ln_cb, no swiglu, bias folded into ln_cb");
-    CBX_REQUIRE(p.n_xpart == 0 || (p.norm_w && p.xpart && p.M <= 16 && (p.n_xpart == 2 || (p.n_xpart == 4 && !p.swiglu)) && p.nw == 8 && p.x_out != p.x),
+    CBX_REQUIRE(p.n_xpart == 0 || p.col_tiles > 0 || (p.norm_w && p.xpart && p.M <= 16 && (p.n_xpart == 2 || (p.n_xpart == 4 && !p.swiglu)) && p.nw == 8 && p.x_out != p.x),
                 "gemv: xpart needs norm_w, M <= 16, n_xpart in {2, 4}, nw == 8 and x_out != x");
     CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv: out_packed needs N %% 32 == 0");
     CBX_REQUIRE(!(p.w_packed || p.x_packed) || p.K % 32 == 0, "gemv: packed operands need K %% 32 == 0");
+    if (p.col_tiles > 0) {  // column-tile / split-K form of the RMSNorm-folded packed GEMV (gemv_ct_kernel)
+        CBX_REQUIRE(p.col_tiles <= 4 && p.norm_w && p.w_packed && p.x_packed && !p.w_bf16 && !p.swiglu && !p.ln_cw && !p.bias && !p.res && !p.act && !p.out_packed &&
+                        p.half_tile == 0 && p.M <= 16,
+                    "gemv: col_tiles serves the plain RMSNorm-folded packed fp32 form (M <= 16, 16-column image, no bias / residual / activation)");
+        CBX_REQUIRE(p.K % (256 * p.ksplit) == 0 && (p.ksplit == 1 || p.ssq_out), "gemv: col_tiles needs K %% (256 * ksplit) == 0, and ssq_out with ksplit > 1");
+        CBX_REQUIRE(p.n_xpart == 0 || ((p.n_xpart == 2 || p.n_xpart == 4) && p.xpart && p.x_out != p.x), "gemv: col_tiles with xpart: 2 or 4 images, x_out != x");
+        hipStream_t st = (hipStream_t)stream;
+        switch (p.col_tiles) {
+            case 1: return launch_ct<1>(p, st);
+            case 2: return launch_ct<2>(p, st);
+            case 3: return launch_ct<3>(p, st);
+            default: return launch_ct<4>(p, st);
+        }
+    }
     return p.swiglu ? launch_mt<true>(p, (hipStream_t)stream) : launch_mt<false>(p, (hipStream_t)stream);
 }
 

@@ -26,6 +26,10 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     CBX_REQUIRE(d && d->layers && d->n_layers > 0, "t3_decode_step: null descriptor");
     CBX_REQUIRE(d->rows >= 1 && d->rows <= 16, "t3_decode_step: rows=%d (this entry point serves the packed <= 16-row path)", d->rows);
     CBX_REQUIRE(d->d_ksplit == 1 || d->d_ksplit == 2 || d->d_ksplit == 4, "t3_decode_step: d_ksplit must be 1, 2 or 4");
+    const int qks = d->qkv_ksplit > 1 ? d->qkv_ksplit : 1;  // ABI v11: the q/k/v projection as split-K partial sums folded by the attention launch
+    CBX_REQUIRE(qks == 1 || (qks <= 4 && d->qkv_ct >= 1 && d->qkv_ct <= 4 && d->qkv_ssq && d->qkv_tile == 0 && !d->w_bf16),
+                "t3_decode_step: qkv_ksplit 2 .. 4 needs qkv_ct 1 .. 4, qkv_ssq, the 16-column fp32 q/k/v image");
+    CBX_REQUIRE(d->head_ct >= 0 && d->head_ct <= 4 && !(d->head_ct && d->w_bf16), "t3_decode_step: head_ct in 0 .. 4 (fp32 images)");
     const int D = d->dim, F = d->ffn, H = d->n_heads;
     float* cur = d->x_a;
     float* nxt = d->x_b;
@@ -42,12 +46,14 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     da.ld_qkv = 3 * D, da.o_ld = D, da.o_packed = 1, da.cache_row_stride = d->kv_row_stride, da.cache_head_stride = d->kv_head_stride;
     da.scale = d->attn_scale, da.unroll = d->da_unroll, da.pipeline = d->da_pipeline, da.split_min = d->da_split_min;
     da.split_ws = d->da_ws, da.split_cnt = d->da_cnt, da.split_pairs = d->da_pairs;
+    if (qks > 1) da.qkv_nparts = qks, da.qkv_part_stride = (long)d->rows * 3 * D, da.qkv_ssq = d->qkv_ssq, da.rms_dim = D, da.rms_eps = d->eps;
     const long img = (long)((d->rows + 15) / 16 * 16) * D;  // floats per packed residual / partial image
     bool pending = false;                                     // split-K partial images of the previous down projection waiting to be summed
     for (int i = 0; i < d->n_layers; ++i) {
         const cbx_t3_layer_t& L = d->layers[i];
         base(cur, L.wqkv, d->qkv, 3 * D, D);
         g.norm_w = L.ln1, g.half_tile = d->qkv_tile;
+        if (qks > 1) g.col_tiles = d->qkv_ct, g.ksplit = qks, g.part_stride = (long)d->rows * 3 * D, g.ssq_out = d->qkv_ssq, g.flags = 0;
         if (pending) g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nxt;
         if ((rc = cbx_gemv_f32(&g, stream))) return rc;
         if (pending) {
@@ -76,6 +82,7 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     }
     base(cur, d->head, d->logits, d->vocab, D);
     g.norm_w = d->final_norm, g.ldo = d->ld_logits;
+    if (d->head_ct) g.col_tiles = d->head_ct, g.flags = 0;
     if (pending) g.n_xpart = d->d_ksplit, g.xpart = d->pd, g.xpart_stride = img, g.x_out = nullptr;
     if ((rc = cbx_gemv_f32(&g, stream))) return rc;
     return d->sampler ? cbx_t3_sample(d->sampler, stream) : 0;

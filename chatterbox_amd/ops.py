@@ -371,24 +371,28 @@ def pack_gemv_weight(w, swiglu=False, half_tile=False, bf16=False):
 
 
 def gemv(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0):
+         norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0,
+         col_tiles=0, ssq_out=None):
     """Decode GEMM: x (M<=64, K), w (N, K) [swiglu: packed (2N, K)], out (M, N) or, for ksplit > 1, (ksplit, M, N) partials.
     w_packed: w is a pack_gemv_weight() image (pass N); x_packed: x is in the same lane-ordered layout (pass M, K);
     norm_w: RMSNorm(x) folded in (packed operands only); res: residual added in the epilogue (same layout as out, may alias it);
     out_packed: out is written in the packed operand layout of the next gemv (ksplit > 1: out (ksplit, rows16, N) partial images);
     half_tile (True = 8, or 12 / 4): output columns per workgroup, w being the pack_gemv_weight image of that tile width;
     xpart (2 or 4, rows16, K): split-K partial images summed into the x operand on the fly, x_out receives x + sum(xpart);
-    flags: cbx_gemv_t.flags (GEMV_PRE_EPI | GEMV_DEEP: per-launch geometry bits, results unchanged)."""
+    flags: cbx_gemv_t.flags (GEMV_PRE_EPI | GEMV_DEEP: per-launch geometry bits, results unchanged);
+    col_tiles (1 .. 4, RMSNorm-folded packed fp32 form): a workgroup owns that many 16-column tiles sharing every x register and 1 / ksplit of K;
+    ksplit > 1 then leaves UN-normalised partial sums out (ksplit, M, N) + ssq_out (ksplit, 16) for the consumer (decode_attn_rope(qkv_parts=...))."""
     p, M, N, K = _gemv_params(x, w, out, N=N, bias=bias, ksplit=ksplit, nw=nw, swiglu=swiglu, act=act, w_packed=w_packed, x_packed=x_packed, M=M, K=K,
                               norm_w=norm_w, eps=eps, res=res, out_packed=out_packed, xpart=xpart, x_out=x_out, ln_cw=ln_cw, ln_cb=ln_cb,
-                              half_tile=half_tile, flags=flags)
+                              half_tile=half_tile, flags=flags, col_tiles=col_tiles, ssq_out=ssq_out)
     _timed("gemv_f32", 2.0 * M * N * K * (2 if swiglu else 1), 4.0 * N * K * (2 if swiglu else 1),
            lambda: check(lib.cbx_gemv_f32(ctypes.byref(p), _stream()), "cbx_gemv_f32"))
     return out
 
 
 def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, act=NONE, w_packed=False, x_packed=False, M=None, K=None,
-                 norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0):
+                 norm_w=None, eps=1e-5, res=None, out_packed=False, xpart=None, x_out=None, ln_cw=None, ln_cb=None, half_tile=False, flags=0,
+                 col_tiles=0, ssq_out=None):
     """The cbx_gemv_t descriptor of a gemv() call: (descriptor, M, N, K)."""
     if x_packed:
         assert w_packed and M is not None and K is not None
@@ -405,6 +409,7 @@ def _gemv_params(x, w, out, *, N=None, bias=None, ksplit=1, nw=4, swiglu=False, 
     p.out_packed, p.norm_w, p.res, p.eps = int(out_packed), _p(norm_w), _p(res), eps
     p.ln_cw, p.ln_cb = _p(ln_cw), _p(ln_cb)  # LayerNorm form (GPT-2): see cbx_gemv_t
     p.flags = int(flags)
+    p.col_tiles, p.ssq_out = int(col_tiles), _p(ssq_out)
     if xpart is not None:
         p.n_xpart, p.xpart, p.xpart_stride, p.x_out = xpart.shape[0], _p(_f32(xpart, "xpart")), xpart.stride(0), _p(x_out)
     if ksplit > 1:
@@ -504,11 +509,16 @@ class DecodeAttnGeom:
         p.split_ws, p.split_cnt, p.split_pairs = _p(self.ws), _p(self.cnt), (self.max_pairs if self.ws is not None else 0)
 
 
-def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False, geom=None):
+def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packed=False, geom=None, qkv_ssq=None, rms_dim=0, rms_eps=1e-5):
     """Fused RoPE + KV append + decode attention: qkv (rows, 3*H*64), caches (rows,H,max,64), out (rows, H*64)
     [out_packed: the packed operand image of the o-projection gemv, (ceil(rows/16)*16, H*64)].
-    geom: a DecodeAttnGeom (the engines: geometry and workspace per call); None = the positional entry point on the process-wide test hooks."""
+    geom: a DecodeAttnGeom (the engines: geometry and workspace per call); None = the positional entry point on the process-wide test hooks.
+    qkv (nparts, rows, 3*H*64) + qkv_ssq (nparts, 16) + rms_dim: split-K partial sums of the RMSNorm-folded projection (gemv(col_tiles=..., ksplit > 1))."""
     rows, H = kc.shape[0], kc.shape[1]
+    nparts = 0
+    if qkv.dim() == 3:
+        assert geom is not None and qkv_ssq is not None and rms_dim > 0 and qkv.shape[0] <= 4 and qkv_ssq.shape == (qkv.shape[0], 16)
+        nparts = qkv.shape[0]
     if geom is None:
         check(lib.cbx_decode_attn_rope_f32(_p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out), rows, H,
                                            qkv.stride(0), out.stride(0), int(out_packed), kc.stride(0), kc.stride(1), scale, _stream()),
@@ -516,8 +526,10 @@ def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packe
         return out
     p = DecodeAttnParams()
     p.qkv, p.positions, p.cos_t, p.sin_t, p.kc, p.vc, p.o = _p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(out)
-    p.rows, p.n_heads, p.ld_qkv, p.o_ld, p.o_packed = rows, H, qkv.stride(0), out.stride(0), int(out_packed)
+    p.rows, p.n_heads, p.ld_qkv, p.o_ld, p.o_packed = rows, H, qkv.stride(-2), out.stride(0), int(out_packed)
     p.cache_row_stride, p.cache_head_stride, p.scale = kc.stride(0), kc.stride(1), scale
+    if nparts:
+        p.qkv_nparts, p.qkv_part_stride, p.qkv_ssq, p.rms_dim, p.rms_eps = nparts, qkv.stride(0), _p(qkv_ssq), int(rms_dim), float(rms_eps)
     geom.fill(p)
     check(lib.cbx_decode_attn_rope(ctypes.byref(p), _stream()), "cbx_decode_attn_rope")
     return out

@@ -43,7 +43,10 @@ class T3Engine:
     # qkv_tc / od_tc: output columns per workgroup of the q/k/v resp. the o / down projections (0: 16 resp. what half_tiles says; 12 puts
     # q/k/v, 4 puts o / down on exactly 256 workgroups -- with od_tc = 4 and d_ks2 = 1 the down projection needs no partial images and the
     # next q/k/v GEMV no partial-sum fold).  CBX_T3_TUNE="qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8" overrides any of these for an A/B.
-    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0)
+    # qkv_ks / qkv_ct (ABI v11): the q/k/v projection as qkv_ks split-K partial sums over workgroups of qkv_ct column tiles, folded by the attention
+    # launch (a CU then moves 96 KiB instead of 256 per q/k/v launch: profiles/r04_decode_launch_timeline.txt); head_ct: column tiles of the head GEMV
+    _TUNE = dict(qkv_nw=8, o_ks=4, gu_nw=8, d_ks=8, head_nw=4, o_nw2=8, d_ks2=2, d_nw2=16, half_tiles=1, qkv_tc=0, od_tc=0, prefill_prec=0, qkv_ks=4, qkv_ct=3,
+                 head_ct=2)
 
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None, max_pos=4608, weight_dtype=None):
@@ -166,6 +169,14 @@ class T3Engine:
     def _sync_geom(self, st):
         st["da"].unroll, st["da"].pipeline = (0 if int(self.knobs["da_u"]) == 4 else int(self.knobs["da_u"])), int(self.knobs["da_pipe"])
 
+    def _qks(self):
+        """Effective split-K factor of the q/k/v projection (0 = the one-tile kernel): the column-tile form serves the 16-column fp32 image."""
+        ks = int(self.tune.get("qkv_ks") or 0)
+        return ks if ks > 1 and not self.tune.get("qkv_tc") and self.weight_dtype == "fp32" and self.D % (256 * ks) == 0 else 0
+
+    def _hct(self):
+        return int(self.tune.get("head_ct") or 0) if self.weight_dtype == "fp32" and self.D % 256 == 0 else 0
+
     def _tiles(self):
         """(q/k/v tile width, o / down tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
         tn = self.tune
@@ -185,6 +196,9 @@ class T3Engine:
             return
         qtc, odtc = self._tiles()
         assert qtc in (16, 12) and odtc in (16, 8, 4), f"tile widths {qtc} / {odtc}"
+        tn = self.tune
+        assert tn.get("qkv_ks", 0) in (0, 1, 2, 4) and 1 <= tn.get("qkv_ct", 3) <= 4 and 0 <= tn.get("head_ct", 0) <= 4, f"column-tile geometry {tn}"
+        # (qkv_tc = 12 or bf16 weight images switch the split-K / column-tile forms off: _qks(), _hct())
         for lw in self.layers:
             self._image(lw, "wqkv", qtc), self._image(lw, "wo", odtc), self._image(lw, "wd", odtc)
 
@@ -429,11 +443,20 @@ class T3Engine:
         red = {}  # partial images pending on the residual stream
         qtc, odtc = self._tiles()
         qt, ot = (0 if qtc == 16 else qtc), (0 if odtc == 16 else odtc)
+        qks, qct, hct = self._qks(), int(tn.get("qkv_ct") or 3), self._hct()
         for i, lw in enumerate(self.layers):
-            ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk, **red)
+            if qks > 1:  # split-K partial sums over column-tile workgroups; the attention launch adds them and applies rstd (ABI v11)
+                qp, sq = ws["qkv_parts"][:qks], ws["qkv_ssq"][:qks]
+                ops.gemv(cur, lw["wqkv_pk"], qp, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], col_tiles=qct, ksplit=qks, ssq_out=sq, **pk, **red)
+            else:
+                ops.gemv(cur, self._image(lw, "wqkv", qtc), qkv, N=3 * self.D, K=self.D, nw=8, norm_w=lw["ln1"], half_tile=qt, **pk, **red)
             if red:
                 cur, nxt = nxt, cur  # the q/k/v GEMV wrote x + sum(partials) to the other image
-            ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True, geom=st["da"])
+            if qks > 1:
+                ops.decode_attn_rope(qp, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True, geom=st["da"],
+                                     qkv_ssq=sq, rms_dim=self.D, rms_eps=1e-5)
+            else:
+                ops.decode_attn_rope(qkv, st["positions"], self.cos, self.sin, st["kc"][i], st["vc"][i], att, 0.125, out_packed=True, geom=st["da"])
             ops.gemv(att, self._image(lw, "wo", odtc), cur, N=self.D, K=self.D, nw=tn["o_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
             ops.gemv(cur, lw["wgu_pk"], g, N=self.F, K=self.D, swiglu=True, nw=tn["gu_nw"], norm_w=lw["ln2"], out_packed=True, **pk)
             if dks > 1:
@@ -443,7 +466,7 @@ class T3Engine:
                 ops.gemv(g, self._image(lw, "wd", odtc), cur, N=self.D, K=self.F, nw=tn["d_nw2"], res=cur, out_packed=True, half_tile=ot, **pk)
         if red:
             red["x_out"] = None
-        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, **red, **pk)
+        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, col_tiles=hct, **red, **pk)
 
     def _forward(self, st):
         if self.decode_mode == "v2" and st["rows"] <= 16:
@@ -490,6 +513,10 @@ class T3Engine:
             d.logits, d.ld_logits, d.sampler = p(st["logits"]), st["logits"].stride(0), ctypes.pointer(sp)
             da = st["da"]  # the step's own attention geometry + split-context workspace, GEMV flags (ABI v10: nothing process-wide)
             d.da_unroll, d.da_pipeline, d.da_split_min, d.gemv_flags = da.unroll, da.pipeline, da.split_min, self._gf()
+            qks = self._qks()
+            if qks > 1:
+                d.qkv, d.qkv_ksplit, d.qkv_ct, d.qkv_ssq = p(ws["qkv_parts"]), qks, int(tn.get("qkv_ct") or 3), p(ws["qkv_ssq"])
+            d.head_ct = self._hct()
             d.da_ws, d.da_cnt, d.da_pairs = ops._p(da.ws), ops._p(da.cnt), (da.max_pairs if da.ws is not None else 0)  # None: >= 128 (row, head) pairs never split
             st["cstep"] = (d, layers, sp)  # keep the host structures alive
         check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
@@ -527,7 +554,9 @@ class T3Engine:
                            att_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            x2_pk=torch.zeros((rows + 15) // 16 * 16, self.D, device=dev),
                            pd_pk=torch.zeros(4, (rows + 15) // 16 * 16, self.D, device=dev),
-                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev)),
+                           g_pk=torch.zeros((rows + 15) // 16 * 16, self.F, device=dev),
+                           # split-K partial sums of the q/k/v projection + their sums of squares (tune qkv_ks, ABI v11)
+                           qkv_parts=torch.zeros(4, rows, 3 * self.D, device=dev), qkv_ssq=torch.zeros(4, 16, device=dev)),
                   graph=None, samp_dev=torch.zeros(B, 8, device=dev),
                   # geometry + split-context workspace of this state's attention launches (a state = one stream of launches; two slots may be in flight)
                   da=ops.DecodeAttnGeom(dev, split=rows * self.H < 128))

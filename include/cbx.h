@@ -15,14 +15,17 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 10 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 11 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
                               9: 12- and 4-column decode GEMV tiles (cbx_gemv_t.half_tile = 12 / 4), cbx_t3_step_t.qkv_tile, d_ksplit = 1;
                               10: no process-wide state on the decode path -- cbx_decode_attn_t / cbx_decode_attn_rope (geometry and the split-context
                                   workspace per call), cbx_gemv_t.flags, cbx_t3_step_t.da_* / gemv_flags; the cbx_set_* setters remain as TEST HOOKS of
-                                  the positional entry points only */
+                                  the positional entry points only;
+                              11: cbx_gemv_t.col_tiles / ssq_out (column-tile / split-K form of the RMSNorm-folded decode GEMV), cbx_decode_attn_t.qkv_nparts /
+                                  qkv_part_stride / qkv_ssq / rms_dim / rms_eps (the attention adds the q/k/v partial sums and applies rstd),
+                                  cbx_t3_step_t.qkv_ksplit / qkv_ct / head_ct / qkv_ssq */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -178,6 +181,15 @@ typedef struct cbx_gemv_t {
     const float* ln_cw;  /* or NULL: LayerNorm instead of RMSNorm (GPT-2 ln_1 / ln_2 / ln_f): with norm_w = LN weight w, ln_cw[n] = */
     const float* ln_cb;  /* sum_k w[k] W[n][k] and ln_cb[n] = sum_k b[k] W[n][k] + bias[n] (constants of the layer, computed at load): */
                          /* out[m][n] = rstd[m] (sum_k x w W - mean[m] ln_cw[n]) + ln_cb[n], then `act` */
+    /* ABI v11 -- column-tile / split-K form of the RMSNorm-folded packed GEMV (norm_w, packed fp32 operands in the 16-column image, M <= 16, no
+     * bias / residual / activation; xpart / x_out as above).  col_tiles = 1 .. 4: a workgroup owns that many 16-column tiles, which share every x
+     * register (activation : weight bytes per workgroup = 1 : col_tiles instead of 1 : 1 -- the decode GEMVs are bound by the bytes a CU moves,
+     * profiles/r04_decode_launch_timeline.txt), and 1 / ksplit of K on 8 waves (K % (256 ksplit) == 0).  ksplit == 1: out = RMSNorm(x) W^T as
+     * before.  ksplit > 1: out[ks] (part_stride floats apart) holds the UN-normalised partial sums of K slice ks and ssq_out[ks * 16 + m] the
+     * slice's sum of squares of row m: the consumer adds the partials in fixed order and applies rstd = rsqrt(sum_ks ssq / K + eps)
+     * (cbx_decode_attn_t.qkv_nparts does).  0 = the one-tile form above. */
+    int col_tiles;
+    float* ssq_out;
 } cbx_gemv_t;
 /* Packed GEMV weight layout (decode path; the weights are constants, so they are laid out once for the MFMA lane order):
  *   dst[(((tile * (K/32) + kb) * 2 + h) * 64 + lane) * 4 + s] = src[tile*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + h*4 + s]
@@ -291,6 +303,10 @@ typedef struct cbx_decode_attn_t {
     long cache_row_stride, cache_head_stride; float scale;
     int unroll, pipeline, split_min;
     float* split_ws; int* split_cnt; long split_pairs;
+    /* ABI v11: qkv_nparts = 2 .. 4: `qkv` holds that many UN-normalised split-K partial sums of the fused q/k/v row (cbx_gemv_t.col_tiles with
+     * ksplit > 1), qkv_part_stride floats apart; the kernel adds them in fixed order and multiplies by rstd[row] = rsqrt(sum_p qkv_ssq[p * 16 + row]
+     * / rms_dim + rms_eps) (LlamaRMSNorm of the projection's input, folded through the contraction); rows <= 16.  0 / 1: qkv is the finished row. */
+    int qkv_nparts; long qkv_part_stride; const float* qkv_ssq; int rms_dim; float rms_eps;
 } cbx_decode_attn_t;
 int cbx_decode_attn_rope(const cbx_decode_attn_t* p, void* stream);
 /* tuning knob: tile shape of the split-bf16 GEMM (0 = automatic; 64, 12864, 128, 1282) */
@@ -408,6 +424,11 @@ typedef struct cbx_t3_step_t {
      * launch, cbx_gemv_t.flags of every GEMV launch */
     int da_unroll, da_pipeline, da_split_min, gemv_flags;
     float* da_ws; int* da_cnt; long da_pairs;
+    /* ABI v11: qkv_ksplit > 1 (with qkv_ct = column tiles per workgroup, qkv_tile = 0): the q/k/v projection in the split-K column-tile form --
+     * qkv then holds [qkv_ksplit][rows][3*dim] partial sums and qkv_ssq [qkv_ksplit][16] sums of squares, which the attention launch folds;
+     * head_ct > 0: the speech head in the column-tile form (ksplit 1).  0 = the one-tile forms. */
+    int qkv_ksplit, qkv_ct, head_ct;
+    float* qkv_ssq;
 } cbx_t3_step_t;
 int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
 

@@ -21,17 +21,14 @@ from chatterbox_amd import autotune as at
 out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04/first"
 os.makedirs(out_dir, exist_ok=True)
 dev = torch.device("cuda:0")
-TILES = (dict(), dict(qkv_tc=12), dict(od_tc=4), dict(qkv_tc=12, od_tc=4), dict(od_tc=4, d_ks2=1, d_nw2=8), dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8))
-ATTN = (dict(),) + at.ATTN_VARIANTS
-EPI = (dict(), dict(pre_epi=1))
-singles = [dict(t) for t in at.TILE_VARIANTS[1:]] + [dict(a) for a in at.ATTN_VARIANTS] + [dict(e) for e in at.EPI_VARIANTS]
-combos = [dict(t, **a, **e) for t in TILES for a in ATTN for e in EPI]
-seen, cands = set(), []
-for v in singles + combos:
-    k = at.canon(v)
-    if k and k not in seen:
-        seen.add(k)
-        cands.append(dict(k))
+from chatterbox_amd.t3 import T3Engine
+# every geometry the autotuner can compose from the engines' default and from the frozen round-3 base, plus what is already listed
+cands, seen = [], set()
+for t, k in at.composed_candidates(T3Engine._TUNE, at.LIB_KNOBS) + at.composed_candidates(at.BASE_TUNE, at.BASE_KNOBS) + [(dict(c), {}) for c in sorted(at.green_variants()) if os.environ.get("CBX_GREEN_RECHECK") == "1"]:
+    c = at.canon(t, k)
+    if c not in seen:
+        seen.add(c)
+        cands.append(dict(c))
 budget = float(os.environ.get("CBX_GREEN_BUDGET_S", "240"))
 t0 = time.perf_counter()
 green, red, skipped = [], [], []

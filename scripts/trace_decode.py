@@ -40,7 +40,7 @@ def name(tag):
     k = tag >> 28
     if k == 1:
         n = tag & 0xfffff
-        return {3072: "gemv qkv", 1024: "gemv o/down", 4096: "gemv gate|up"}.get(n, f"gemv N={n}") + (" +np%d" % ((tag >> 20) & 15) if (tag >> 20) & 15 else "")
+        return {3072: "gemv qkv", 1024: "gemv o/down", 4096: "gemv gate|up"}.get(n, f"gemv N={n}") + (" ct" if tag & 0x2000000 else "") + (" +np%d" % ((tag >> 20) & 15) if (tag >> 20) & 15 else "")
     return KIND.get(k, f"kind{k}") + (f" flags={tag & 15}" if k == 2 and tag & 15 else "")
 
 
@@ -98,6 +98,10 @@ texts = [synth.text_tokens(64, seed=b) for b in range(B)]
 u = synth.rand((B, N), seed=1).to(dev)
 kw = dict(max_new_tokens=N, uniforms=u, ban_eos=True, ban_from=6561)
 variants = [("default", {}, {})]
+if os.environ.get("CBX_TRACE_TUNE"):  # e.g. CBX_TRACE_TUNE="qkv_ks=4,qkv_ct=3,head_ct=2,da_pipe=7"
+    from chatterbox_amd.autotune import split_variant
+    tv, kv = split_variant({k: int(x) for k, x in (kv.split("=") for kv in os.environ["CBX_TRACE_TUNE"].split(","))})
+    variants = [(os.environ["CBX_TRACE_TUNE"], tv, kv)]
 if os.environ.get("CBX_TRACE_VARIANTS", "1") == "1":
     variants += [("da_pipe=7,pre_epi=1", {}, dict(da_pipe=7, pre_epi=1)), ("qkv_tc=12,od_tc=4,d_ks2=1,d_nw2=8", dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), {})]
 result = {}

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -35,7 +35,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
-               "cbx_sampler_t": _lib.SamplerParams}
+               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -469,17 +469,24 @@ def test_c_step_descriptor_accepts_a_state_without_split_workspace():
     assert g2.ws.numel() == 128 * 8 * 66 and g2.cnt.dtype == torch.int32 and not bool(g2.cnt.any())
 
 
-def test_green_allow_list_is_canonical_and_contains_the_builtin_geometry():
-    """chatterbox_amd/decode_green.json (the geometries bench.py may adopt): canonical keys only, every entry made of knobs the engine / library
-    know, the built-in geometry always on it; canon() drops default-valued keys so that the autotuner's composed candidates are found."""
+def test_green_allow_list_is_canonical_and_contains_the_default_geometry():
+    """chatterbox_amd/decode_green.json (the geometries bench.py may run or adopt): every entry made of knobs the engine / library know, in canon
+    form against the FROZEN round-3 base (so entries keep their meaning when defaults move); the frozen base and the engines' current default
+    geometry are on it; every geometry the autotuner can compose from the default is on it too (else bench.py would skip it -- allowed, but then
+    the candidate list is stale)."""
     import json
     from chatterbox_amd import autotune as at
     from chatterbox_amd.t3 import T3Engine
     green = at.green_variants()
-    assert at.canon({}) in green and at.canon(dict(qkv_tc=0, da_pipe=0, da_u=4)) == ()
+    assert () in green and at.canon({}) == () and at.canon(dict(qkv_tc=0, da_pipe=0, da_u=4)) == ()
     assert at.canon(dict(da_pipe=7, pre_epi=1, qkv_tc=0)) == (("da_pipe", 7), ("pre_epi", 1))
+    assert at.canon(dict(qkv_ks=0, qkv_ct=2)) == () and at.canon(dict(qkv_ks=4, qkv_ct=2)) == (("qkv_ct", 2), ("qkv_ks", 4))
+    assert set(at.BASE_TUNE) == set(T3Engine._TUNE), "the frozen base knows every tune key"
     known = set(T3Engine._TUNE) | set(at.LIB_KNOBS)
     doc = json.load(open(at.GREEN_FILE))
     assert isinstance(doc["green"], list) and doc.get("source"), "decode_green.json names the hardware run it was written from"
     for v in doc["green"]:
         assert set(v) <= known and at.canon(v) in green, v
+    assert at.canon(T3Engine._TUNE, at.LIB_KNOBS) in green, "the default geometry must be hardware-verified"
+    missing = [at.canon(t, k) for t, k in at.composed_candidates(T3Engine._TUNE, at.LIB_KNOBS) if at.canon(t, k) not in green]
+    assert not missing, f"{len(missing)} composable candidates are not on the allow-list, e.g. {missing[:3]}"

@@ -72,6 +72,9 @@ _OPS = [
     ("test_gemv_narrow_tiles", (16, 3072, 1024, 1, 8, 12, "rms_np2")), ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 16, 4, "res")),
     ("test_gemv_narrow_tiles", (9, 1024, 4096, 1, 8, 4, "plain")), ("test_gemv_narrow_tiles", (5, 40, 256, 2, 4, 12, "plain")),
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
+    ("test_gemv_col_tiles_and_split_k", (16, 3072, 1024, 3, 4, 2)), ("test_gemv_col_tiles_and_split_k", (16, 8194, 1024, 2, 1, 2)),
+    ("test_gemv_col_tiles_and_split_k", (9, 200, 2048, 3, 2, 0)), ("test_gemv_col_tiles_and_split_k", (16, 3072, 1024, 3, 1, 4)),
+    ("test_decode_attn_folds_qkv_partial_sums", (5, 16, 2, 1)), ("test_decode_attn_folds_qkv_partial_sums", (2, 12, 4, 0)),
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
 ]
@@ -474,7 +477,8 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
 _SLOW2 = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="80 s (2 layers at the real width): CBX_EMU_SLOW=1")
 
 
-@pytest.mark.parametrize("tune", [dict(), pytest.param(dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2)], ids=["default", "qkv12_od4_nopartials"])
+@pytest.mark.parametrize("tune", [dict(), dict(qkv_ks=4, qkv_ct=3, head_ct=2), pytest.param(dict(qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), marks=_SLOW2)],
+                         ids=["default", "qkv_splitk_head_ct2", "qkv12_od4_nopartials"])
 def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE Multilingual T3 path of chatterbox_amd/t3.py on the emulator at the real width (1024 / 4096 / 16 heads, ONE layer): conditioning
     encoder + Perceiver, the ragged batched prefill (exact fp32 GEMMs, flash attention, RoPE + cache fill), CFG row pairs, the decode steps
@@ -485,7 +489,7 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     from chatterbox_amd.t3 import T3Engine
     from oracle import ref_torch as O
     samp = dict(temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
-    L, steps = (2 if tune else 1), 3
+    L, steps = (2 if tune else 1), 3  # (2 layers: the second q/k/v GEMV folds the first layer's down-projection partial images)
     sd = synth.t3_state_dict(L, 0)
     eng = T3Engine(sd, CPU)
     assert eng.c_step and eng.decode_mode == "v2"

@@ -168,7 +168,84 @@ def test_decode_attn_split_workspaces_are_caller_owned(dev):
         _close(serial[i][0].view(H, 64), F.scaled_dot_product_attention(q[0].reshape(H, 1, 64), kk, vv)[:, 0], 2e-5, f"split attention, ctx {m + 1}")
 
 
-@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "od_tc=4"])
+@pytest.mark.parametrize("M,N,K,ct,ks,np_", [(16, 3072, 1024, 3, 4, 2), (16, 3072, 1024, 3, 4, 4), (16, 3072, 1024, 2, 2, 0), (16, 8194, 1024, 2, 1, 2), (16, 8194, 1024, 4, 1, 0),
+                                               (5, 3072, 1024, 3, 4, 2), (16, 3072, 1024, 1, 1, 2), (9, 200, 2048, 3, 2, 0), (16, 3072, 1024, 3, 1, 4)])
+def test_gemv_col_tiles_and_split_k(dev, M, N, K, ct, ks, np_):
+    """cbx_gemv_t.col_tiles (ABI v11): the RMSNorm-folded packed GEMV with `ct` column tiles per workgroup sharing every x register and 1 / ks of K
+    per workgroup.  ks == 1: bit-identical to the one-tile kernel (same MFMA order per tile, same 8-way LDS reduction) and equal to torch;
+    ks > 1: UN-normalised partial sums + per-slice sums of squares whose fixed-order fold (what cbx_decode_attn_t.qkv_nparts does) equals torch;
+    with partial images (np_) the reduced residual stream x_out is exact.  Ragged N (8194 = 513 tiles, 200 = 13 tiles), M < 16."""
+    from chatterbox_amd import ops
+    x, w, nwt = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), 1 + 0.1 * _r((K,), 3)
+    parts = _r((max(np_, 1), M, K), 5, 0.3)
+    xs = x + sum(parts[j] for j in range(np_)) if np_ else x
+    ref = F.linear(xs * torch.rsqrt((xs * xs).mean(-1, keepdim=True) + 1e-5) * nwt, w)
+    xp, wp = ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(w.to(dev))
+    extra = dict(norm_w=nwt.to(dev))
+    mk_extra = lambda: dict(extra, xpart=torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(np_)]), x_out=torch.zeros_like(xp)) if np_ else dict(extra)
+    kw = dict(N=N, M=M, K=K, nw=8, w_packed=True, x_packed=True)
+    tol = 3e-5 * max(1.0, math.sqrt(K / 256))
+    if ks == 1:
+        a, b = torch.zeros(M, N, device=dev), torch.full((M, N), float("nan"), device=dev)
+        ea, eb = mk_extra(), mk_extra()
+        ops.gemv(xp, wp, a, **kw, **ea)
+        ops.gemv(xp, wp, b, col_tiles=ct, **kw, **eb)
+        assert torch.equal(a, b), f"col_tiles = {ct} differs from the one-tile kernel: {_first_diff(a.cpu(), b.cpu())}"
+        _close(b, ref, 2 * tol, f"gemv col_tiles = {ct}")
+        if np_:
+            assert torch.equal(ea["x_out"], eb["x_out"])
+            _close(_unpack_operand(eb["x_out"], M, K), xs, 1e-6, "x_out = x + partial images")
+        return
+    out, ssq = torch.full((ks, M, N), float("nan"), device=dev), torch.full((ks, 16), float("nan"), device=dev)
+    e = mk_extra()
+    ops.gemv(xp, wp, out, col_tiles=ct, ksplit=ks, ssq_out=ssq, **kw, **e)
+    o, q = out.cpu(), ssq.cpu()
+    assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(q[:, :M]).all())
+    acc, sq = o[0].clone(), q[0, :M].clone()
+    for j in range(1, ks):  # the consumer's fixed-order fold
+        acc += o[j]
+        sq += q[j, :M]
+    _close(sq, (xs * xs).sum(-1), 1e-4 * K / 256, "sum of squares over the K slices")
+    _close(acc * torch.rsqrt(sq / K + 1e-5)[:, None], ref, 2 * tol, f"split-K col_tiles = {ct}, ksplit = {ks}")
+    if np_:
+        _close(_unpack_operand(e["x_out"], M, K), xs, 1e-6, "x_out = x + partial images (written slice by slice)")
+
+
+@pytest.mark.parametrize("rows,H,nparts,pipe", [(16, 16, 4, 0), (16, 16, 4, 7), (5, 16, 2, 1), (2, 12, 4, 0)])
+def test_decode_attn_folds_qkv_partial_sums(dev, rows, H, nparts, pipe):
+    """cbx_decode_attn_t.qkv_nparts (ABI v11): the attention launch adds the split-K partial sums of the q/k/v row in fixed order and applies
+    rstd = rsqrt(sum ssq / dim + eps) -- against the same launch on the finished row (outputs to 1e-6: the device rsqrt may differ from the
+    host's by an ulp, which a sharp softmax amplifies), appended cache rows included; one-workgroup and split-context grids, plain and pipelined
+    forms."""
+    from chatterbox_amd import ops
+    from oracle import ref_torch as O
+    maxp, D = 640, H * 64
+    kc0, vc0 = _r((rows, H, maxp, 64), 1), _r((rows, H, maxp, 64), 2)
+    cos, sin = O.rope_cos_sin(torch.arange(maxp), O.llama3_inv_freq())
+    parts, ssq = _r((nparts, rows, 3 * D), 3), torch.zeros(nparts, 16)
+    ssq[:, :rows] = _r((nparts, rows), 4).abs() * D / nparts
+    tot, sq = parts[0].clone(), ssq[0].clone()
+    for j in range(1, nparts):
+        tot += parts[j]
+        sq += ssq[j]
+    full = tot * torch.rsqrt(sq[:rows] / D + 1e-5)[:, None]
+    for ctx in (1, 40, 65, 300, 639):
+        pos = torch.tensor([(ctx - 1 + 37 * r) % maxp for r in range(rows)], dtype=torch.int32)
+        res = []
+        for src in ("parts", "row"):
+            geom = ops.DecodeAttnGeom(dev, pipeline=pipe, split_min=256)
+            kc, vc, out = kc0.clone().to(dev), vc0.clone().to(dev), torch.zeros(rows, D, device=dev)
+            if src == "parts":
+                ops.decode_attn_rope(parts.to(dev), pos.to(dev), cos.to(dev), sin.to(dev), kc, vc, out, 0.125, geom=geom, qkv_ssq=ssq.to(dev), rms_dim=D)
+            else:
+                ops.decode_attn_rope(full.to(dev), pos.to(dev), cos.to(dev), sin.to(dev), kc, vc, out, 0.125, geom=geom)
+            res.append((out.cpu(), kc.cpu(), vc.cpu()))
+        for a, b, what in zip(res[0], res[1], ("output", "k cache", "v cache")):
+            _close(a, b, 1e-5, f"attention on q/k/v partial sums vs the finished row: {what}, ctx {ctx}")
+
+
+@pytest.mark.parametrize("tune", ["qkv_tc=12,od_tc=4,d_ks2=1", "qkv_tc=12", "od_tc=4,d_ks2=1,d_nw2=8", "od_tc=4", "qkv_ks=4,qkv_ct=3", "qkv_ks=4,qkv_ct=3,head_ct=2",
+                                  "qkv_ks=4,qkv_ct=3,head_ct=2,half_tiles=0,d_ks2=4", "qkv_ks=2,qkv_ct=2,head_ct=4,od_tc=4,d_ks2=1,d_nw2=8"])
 def test_t3_decode_tile_variants_sample_the_reference_tokens(dev, tune, monkeypatch):
     """The round-3 decode geometries (CBX_T3_TUNE: 12-column q/k/v tiles, 4-column o / down tiles, down projection without partial images)
     against the golden tokens of the reference (t3_l2: 2 layers, 64 steps) on the hipGraph + C-step path, and against the default geometry
@@ -271,7 +348,7 @@ def test_decode_autotuner_adopts_only_bit_identical_geometries(dev):
     assert "error" not in rep, rep
     rows = [r for r in rep["candidates"] if "variant" in r]
     assert len(rows) >= len(at.TILE_VARIANTS) + len(at.ATTN_VARIANTS) and all(("ms_per_token" in r) != ("error" in r) for r in rows), rows
-    same_arith = [r for r in rows if "ms_per_token" in r and not any(k in r["variant"] for k in ("d_ks2", "d_nw2", "da_u"))]
+    same_arith = [r for r in rows if "ms_per_token" in r and not any(k in r["variant"] for k in ("d_ks2", "d_nw2", "da_u", "qkv_ks"))]
     assert all(r.get("identical") for r in same_arith), [r for r in same_arith if not r.get("identical")]
     best = rep["best"]
     if best:
@@ -284,14 +361,15 @@ def test_decode_autotuner_adopts_only_bit_identical_geometries(dev):
 
 def _green():
     from chatterbox_amd import autotune as at
-    return [dict(v) for v in sorted(at.green_variants()) if v]
+    return [dict(v) for v in sorted(at.green_variants())]
 
 
-@pytest.mark.parametrize("variant", _green(), ids=lambda v: ",".join(f"{k}={x}" for k, x in sorted(v.items())) or "builtin")
+@pytest.mark.parametrize("variant", _green(), ids=lambda v: ",".join(f"{k}={x}" for k, x in sorted(v.items())) or "r03-base")
 def test_green_variant_is_bit_identical_and_samples_the_reference_tokens(dev, variant):
-    """Every geometry on the allow-list bench.py may adopt (chatterbox_amd/decode_green.json), on THIS hardware: (a) its logits over the ragged
-    probe contexts {1, 38, 63, 64, 65, 225, 640} at B = 8 and B = 1 (split grid) equal the built-in geometry's bit for bit -- or, for a
-    geometry that sums the down projection in another order, to 2e-4 of the logit scale --, (b) it samples the reference's golden tokens
+    """Every geometry on the allow-list bench.py may run or adopt (chatterbox_amd/decode_green.json; an entry = the keys in which a full geometry
+    differs from the frozen round-3 base, autotune.BASE_TUNE / BASE_KNOBS), on THIS hardware: (a) its logits over the ragged probe contexts
+    {1, 38, 63, 64, 65, 225, 640} at B = 8 and B = 1 (split grid) equal the base geometry's bit for bit -- or, for a geometry that sums a
+    projection in another order (split-K factors, wave counts), to 2e-4 of the logit scale --, (b) it samples the reference's golden tokens
     (t3_l2, 64 steps, hipGraph + C-step path)."""
     from chatterbox_amd import autotune as at, synth
     from chatterbox_amd.t3 import T3Engine
@@ -299,18 +377,27 @@ def test_green_variant_is_bit_identical_and_samples_the_reference_tokens(dev, va
     steps, n_text = int(g["steps"]), int(g["n_text"])
     sd = synth.t3_state_dict(2, 0)
     base, eng = T3Engine(sd, dev), T3Engine(sd, dev)
+    base.apply_variant(dict(at.BASE_TUNE), dict(at.BASE_KNOBS))
     t, k = at.split_variant(variant)
-    eng.apply_variant(dict(eng.tune, **t), dict(eng.knobs, **k))
-    reorders = any(x in variant for x in ("d_ks2", "d_nw2", "o_nw2", "gu_nw", "da_u"))
+    eng.apply_variant(dict(at.BASE_TUNE, **t), dict(at.BASE_KNOBS, **k))
+    assert at.canon(eng.tune, eng.knobs) == at.canon(variant)
+    reorders = any(x in variant for x in ("d_ks2", "d_nw2", "o_nw2", "gu_nw", "da_u", "qkv_ks"))
     for B in (8, 1):
         a, b = base.probe_decode(B=B).cpu(), eng.probe_decode(B=B).cpu()
         if reorders:
             assert (a - b).abs().max() <= 2e-4 * max(1.0, float(a.abs().max())), f"B = {B}: {_first_diff(a, b)}"
         else:
-            assert torch.equal(a, b), f"{variant}, B = {B}: probe logits differ from the built-in geometry: {_first_diff(a, b)}"
+            assert torch.equal(a, b), f"{variant}, B = {B}: probe logits differ from the base geometry: {_first_diff(a, b)}"
     u = torch.from_numpy(g["uniforms"])[None]
     toks = eng.generate(synth.t3_cond(), [synth.text_tokens(n_text)], max_new_tokens=steps, uniforms=u, ban_eos=True, **SAMP)
     assert toks[0].tolist() == g["tokens"].tolist(), f"{variant}: golden tokens"
+
+
+def test_the_default_geometry_is_on_the_allow_list():
+    """What T3Engine runs out of the box (T3Engine._TUNE + autotune.LIB_KNOBS) must itself be a hardware-verified geometry."""
+    from chatterbox_amd import autotune as at
+    from chatterbox_amd.t3 import T3Engine
+    assert at.canon(T3Engine._TUNE, at.LIB_KNOBS) in at.green_variants(), at.canon(T3Engine._TUNE, at.LIB_KNOBS)
 
 
 def test_two_engines_with_different_geometries_in_one_process(dev):
@@ -325,7 +412,7 @@ def test_two_engines_with_different_geometries_in_one_process(dev):
     sd = synth.t3_state_dict(2, 0)
     ea, eb = T3Engine(sd, dev), T3Engine(sd, dev)
     ea.apply_variant(dict(ea.tune, qkv_tc=12), dict(ea.knobs, da_pipe=7, pre_epi=1))
-    eb.apply_variant(dict(eb.tune, od_tc=4), dict(eb.knobs, da_pipe=0, da_u=8))
+    eb.apply_variant(dict(eb.tune, od_tc=4, qkv_ks=0, head_ct=0), dict(eb.knobs, da_pipe=0, da_u=8, pre_epi=0))
     u = torch.from_numpy(g["uniforms"])[None]
     kw = dict(max_new_tokens=steps, uniforms=u, ban_eos=True, async_mode=True, run_steps=1, **SAMP)
     ha = ea.generate(synth.t3_cond(), [synth.text_tokens(n_text)], slot=0, **kw)

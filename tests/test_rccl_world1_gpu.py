@@ -62,4 +62,4 @@ def test_bench_under_torchrun_with_one_rank_goes_through_rccl(dev):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "no N > 1 scaling curve" in line["multi_gpu_note"]
-    assert line["t3_geometry"]["adopted"] == {} and line["t3_geometry"]["knobs"]["da_pipe"] == 0
+    assert line["t3_geometry"]["adopted"] == {} and line["t3_geometry"]["knobs"]["da_pipe"] == 7 and line["t3_geometry"]["on_green_list"]

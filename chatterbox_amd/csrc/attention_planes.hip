@@ -317,17 +317,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
     }
     const int tstep = grp == 0 ? (int)(PKT * a.k_st * 2) : PKT * 2;  // bytes per tile along the key axis
     const int lds_w = ((grp ? 2 : 0) + plane) * PL_TILE + rbase * 128;  // this wave's first destination inside a stage
-    // Stage of tile t is t % 3, kept as three rotating wave-uniform counters (round 4): written as `t % 3` hipcc strength-reduces the LDS addresses
-    // into VECTOR arithmetic on the loop counter (a v_subrev + a v_add per ds_read address: 24 of the matrix block's 47 VALU per key tile and wave);
-    // with the stage in an SGPR an address is ONE v_add of a loop-invariant lane term.  Same addresses, same arithmetic.
-    auto issue = [&](int t, int stage) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3.  The whole address is in the VECTOR offset: the
-        unsigned char* dst = smem2 + stage * PL_STAGE + lds_w;  // descriptor's bounds check ignores a scalar offset
+    auto issue = [&](int t) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3.  The whole address is in the VECTOR offset: the
+        unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w;  // descriptor's bounds check ignores a scalar offset
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i] + t * tstep, 0, 0, 0);
     };
-    if (nt > 0) issue(0, 0);
-    if ((FREE || grp == 0) && nt > 1) issue(1, 1);
-    int sg_cur = 0, sg_next = 1, sg_prev = 2;  // t % 3, (t + 1) % 3, (t + 2) % 3 == (t - 1) % 3
+    if (nt > 0) issue(0);
+    if ((FREE || grp == 0) && nt > 1) issue(1);
 
     f16x8 qh[4], ql[4];
     {
@@ -366,21 +362,21 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t + 1 (issued an iteration ago)
                 __builtin_amdgcn_s_barrier();                      // tile t + 1 is in LDS for everybody; everybody is done with tile t - 1
             }
-            if (t + 2 < nt) issue(t + 2, sg_prev);  // into the stage of tile t - 1
+            if (t + 2 < nt) issue(t + 2);  // into the stage of tile t - 1
             __builtin_amdgcn_sched_barrier(0);
         }
         // ================= matrix block: PV(t-1), S(t)   [FREE: S(t) here, PV(t) after the softmax]
         if constexpr (!FREE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the previous block (an iteration old): published by the barriers below
             if (grp == 0) {
-                if (t + 2 < nt) issue(t + 2, sg_prev);
+                if (t + 2 < nt) issue(t + 2);
             } else {
-                if (t + 1 < nt) issue(t + 1, sg_next);
+                if (t + 1 < nt) issue(t + 1);
             }
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
-        auto pv = [&](int stage) {
-            const unsigned char* st_v = smem2 + stage * PL_STAGE + 2 * PL_TILE;
+        auto pv = [&](int tv) {
+            const unsigned char* st_v = smem2 + (tv % 3) * PL_STAGE + 2 * PL_TILE;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const f16x8 pfh = __builtin_bit_cast(f16x8, ph[c]), pfl = __builtin_bit_cast(f16x8, pl[c]);
@@ -395,9 +391,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
                 }
             }
         };
-        if (!FREE && t > 0) pv(sg_prev);
+        if (!FREE && t > 0) pv(t - 1);
         if (t < nt) {
-            const unsigned char* st_k = smem2 + sg_cur * PL_STAGE;
+            const unsigned char* st_k = smem2 + (t % 3) * PL_STAGE;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f32x16 stc;
@@ -485,15 +481,11 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FREE) {
-            pv(sg_cur);
+            pv(t);
         } else {
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
-        {  // rotate the stage counters (wave-uniform)
-            const int n = sg_prev;
-            sg_prev = sg_cur, sg_cur = sg_next, sg_next = n;
-        }
     }
     if (!FREE && grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's stagger barrier
 
@@ -518,7 +510,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
 
 }  // namespace
 
-static int g_attn_pl_version = getenv("CBX_ATTN_PL_VERSION") ? atoi(getenv("CBX_ATTN_PL_VERSION")) : 2;
+// default 4 since round 4: same-box A/B at the bench shape (profiles/r04_attn_planes_ab.log) 111.1-111.2 us against 114.4-115.5 for version 2, twice in a row
+static int g_attn_pl_version = getenv("CBX_ATTN_PL_VERSION") ? atoi(getenv("CBX_ATTN_PL_VERSION")) : 4;
 extern "C" int cbx_set_attn_planes_version(int v) {
     g_attn_pl_version = v;
     return 0;
@@ -540,7 +533,7 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
 #ifdef CBX_DIAG
     a.diag = getenv("CBX_ATTN_DIAG") ? atoi(getenv("CBX_ATTN_DIAG")) : 0;
 #endif
-    // version 2 (ping-pong, 256 queries per workgroup) serves the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
+    // versions 2 / 4 (256 queries per workgroup; 4 = the free-running loop, the default) serve the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
     // (or CBX_ATTN_PL_VERSION) keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
     const int ver = g_attn_pl_version;
     const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;

@@ -268,8 +268,8 @@ int cbx_mlp_planes(const void* h, const void* w1, const void* w2, const float* b
 int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
                           int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
                           long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
-/* tuning knob: kernel version of cbx_flash_attn_planes (2 = default: two wave groups alternating matrix / vector blocks; 1 = one group;
- * 3 = version 2 with wave priorities) */
+/* tuning knob (A/B hook, no engine calls it): kernel version of cbx_flash_attn_planes (4 = default since round 4: free-running loop, every wave
+ * meets the others once per key tile; 2 = two wave groups alternating matrix / vector blocks; 1 = one group; 3 = version 2 with wave priorities) */
 int cbx_set_attn_planes_version(int v);
 
 /* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).

@@ -22,6 +22,8 @@ VARIANTS = [dict(), dict(P7), dict(QK), dict(QK, head_ct=2), dict(QK, head_ct=3)
             dict(QK, head_ct=2, od_tc=4), dict(QK, head_ct=2, od_tc=4, **P7), dict(QK, head_ct=2, od_tc=4, d_ks2=1, d_nw2=8), dict(QK, head_ct=2, d_ks2=4, d_nw2=8),
             dict(qkv_ks=4, qkv_ct=2, head_ct=2), dict(qkv_ks=4, qkv_ct=4, head_ct=2), dict(qkv_ks=2, qkv_ct=2, head_ct=2), dict(head_ct=2),
             dict(QK, head_ct=2, da_pipe=5, pre_epi=1), dict(QK, head_ct=2, da_pipe=3, pre_epi=1), dict()]
+if os.environ.get('CBX_AB_SHORT'):
+    VARIANTS = [dict(), dict(o_nw2=16), dict(d_nw2=8), dict(o_nw2=16, d_nw2=8), dict(gu_nw=4), dict(da_pipe=3), dict(da_pipe=1, da_u=8), dict(pre_epi=0), dict()]
 rows, ref = [], None
 for v in VARIANTS:
     t, k = split_variant(v)
@@ -37,5 +39,7 @@ for v in VARIANTS:
     d = float((lg - ref).abs().max())
     rows.append(dict(variant=v, ms_per_token=round(ms, 4), identical=bool(torch.equal(lg, ref)), max_abs_diff=d))
     print(f"{ms:.4f} ms/token  identical={rows[-1]['identical']} (max |d logits| {d:.2e})  {v}", flush=True)
+if os.environ.get('CBX_AB_SHORT'):
+    pass
 if len(sys.argv) > 1:
     json.dump(dict(B=B, layers=L, ctx=225, rows=rows, device=torch.cuda.get_device_name(0)), open(sys.argv[1], "w"), indent=1)

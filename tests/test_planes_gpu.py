@@ -189,7 +189,7 @@ def attn_version(request):
     from chatterbox_amd import ops
     ops.lib.cbx_set_attn_planes_version(request.param)
     yield request.param
-    ops.lib.cbx_set_attn_planes_version(2)
+    ops.lib.cbx_set_attn_planes_version(4)  # the library default
 
 
 @pytest.mark.parametrize("Z,T,lens", [(2, 1000, None), (3, 517, [517, 130, 64]), (1, 64, None), (2, 200, [1, 199]), (1, 300, [0])])

@@ -193,7 +193,7 @@ def test_flash_attn_planes_small(emu, version):
         test_planes_gpu.test_flash_attn_planes(CPU, version, 3, 200, [200, 130, 1])
         test_planes_gpu.test_flash_attn_planes(CPU, version, 1, 64, None)
     finally:
-        emu.cbx_set_attn_planes_version(2)
+        emu.cbx_set_attn_planes_version(4)  # the library default
 
 
 def test_mlp_planes_small(emu):

@@ -163,10 +163,11 @@ class FlowEngine:
     # larger batch is walked in row groups (rows are independent).  60 s of audio = 1.15 GB per utterance: of 288 GB, not a capacity
     # problem, but a bound keeps one long VC batch from taking the allocator's whole pool.
     ENC_SCORE_BYTES = int(float(os.environ.get("CBX_ENC_SCORE_GB", "32")) * 2 ** 30)
-    # CBX_ENC_FLASH: "1" = the encoder's rel-pos attention always runs in the flash form (cbx_flash_relpos_f32: no score tensors, memory O(T));
-    # "0" = always materialised (the measured path; a batch above ENC_SCORE_BYTES is walked in row groups); "auto" (default) = flash for
-    # the calls the materialised form would have to split.  Both are exact fp32 MFMA; they differ by fp32 summation order.
-    ENC_FLASH = os.environ.get("CBX_ENC_FLASH", "auto")
+    # CBX_ENC_FLASH: "1" (default since round 4) = the encoder's rel-pos attention always runs in the flash form (cbx_flash_relpos_f32: no score
+    # tensors, memory O(T), exact fp32 MFMA) -- measured on one box (profiles/r04_prefill_encoder_ab.log): 6.2 ms against 9.0-9.4 for the
+    # materialised form at the bench shape (B = 8, 500 tokens), 6.8 against 10.6 at 60 s; "0" = always materialised (ac / bd on the engine's GEMM
+    # precision; a batch above ENC_SCORE_BYTES is walked in row groups); "auto" = flash only for the calls the materialised form would have to split.
+    ENC_FLASH = os.environ.get("CBX_ENC_FLASH", "1")
 
     def encode(self, tok, lens):
         """tok (B,N) int64 padded with any valid id, lens (B,) int32 -> mu (B, 2N, 80) channel-last."""

@@ -100,8 +100,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     for (int t = 0; t < MT; ++t) {
         int m = t * 16 + c;
         xok[t] = m < p.M;
-        if constexpr (XPK)  // packed x: [row tile][K/32][2][64][4], rows padded to whole tiles (pad rows hold finite values)
-            xp[t] = p.x + ((long)t * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 4;
+        if constexpr (XPK)  // packed x: [row tile][K/32][2][64][4], rows padded to whole tiles (pad rows hold finite values).
+            // A lane whose row is past M reads ROW 0's 16 bytes of its k group instead of its own pad row (its value is zeroed below either way):
+            // a wave-level load then touches 64 M bytes instead of 1 KiB -- at M = 1 (Turbo / Nano at batch 1: profiles/r04_decode_launch_timeline_turbo.txt)
+            // the x operand and the partial images cost 1/16 of the lines, and the packed images of small batches stop being "16 rows wide".
+            xp[t] = p.x + ((long)t * (p.K >> 5) + (kbeg >> 5)) * 512 + (xok[t] ? lane : (lane & 48)) * 4;
         else
             xp[t] = p.x + (long)(xok[t] ? m : 0) * p.ldx + kbeg + 8 * q;
     }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
                     if constexpr (NP > 0) {
 #pragma unroll
                         for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
-                        if (p.x_out && blockIdx.x == 0 && on[d])  // the reduced residual stream, same packed address as x
+                        if (p.x_out && blockIdx.x == 0 && on[d] && xok[0])  // the reduced residual stream, same packed address as x (pad rows stay as allocated: zero)
                             *reinterpret_cast<f32x4*>(p.x_out + (xp[0] - p.x) + (it0 + d) * 512 + h * 256) = xq;
                     }
                     xq = (on[d] && xok[t]) ? xq : zero4;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
     CBX_TRC_STAMP(5);  // epilogue stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CBX_TRC_STAMP(6);  // ... and acknowledged
-    CBX_TRC_FLUSH(0x10000000u | (unsigned)(SWIGLU ? 0x1000000 : 0) | (unsigned)(NP << 20) | (unsigned)(p.N & 0xfffff));
+    CBX_TRC_FLUSH(0x10000000u | (unsigned)(SWIGLU ? 0x1000000 : 0) | (unsigned)(p.K > p.N ? 0x8000000 : 0) | (unsigned)(NP << 20) | (unsigned)(p.N & 0xfffff));
 #endif
 }
 
@@ -356,13 +359,13 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
         wok[c] = tile0 + c < ntiles;
         wp[c] = p.W + ((long)(wok[c] ? tile0 + c : tile0) * KB + kb0) * 512 + lane * 4;  // [tile][K/32][2][64][4]; a tile past N re-reads tile0
     }
-    const long xo = kb0 * 512 + lane * 4;            // packed x: [K/32][2][64][4] (one 16-row tile)
+    const bool xok = (lane & 15) < p.M;
+    const long xo = kb0 * 512 + (xok ? lane : (lane & 48)) * 4;  // packed x: [K/32][2][64][4] (one 16-row tile); rows past M read row 0's bytes (gemv_kernel)
     const float* nwp = p.norm_w + kb0 * 32 + 8 * (lane >> 4);
     f32x4 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
-    const bool xok = (lane & 15) < p.M;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // DEPTH = K blocks requested per batch (picked by the host so that it divides the wave's block count: an idle slot would re-read a block,
     // i.e. spend the very per-CU bytes this form saves; registers: DEPTH * 2 * (CT + NP + 2) float4)
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
                 if constexpr (NP > 0) {
 #pragma unroll
                     for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
-                    if (p.x_out && blockIdx.x == 0 && on[d])  // the reduced residual stream (this wave's K slice), same packed address as x
+                    if (p.x_out && blockIdx.x == 0 && on[d] && xok)  // the reduced residual stream (this wave's K slice), same packed address as x; pad rows stay zero
                         *reinterpret_cast<f32x4*>(p.x_out + xo + (it0 + d) * 512 + h * 256) = xq;
                 }
                 xq = (on[d] && xok) ? xq : zero4;

@@ -498,8 +498,10 @@ class DecodeAttnGeom:
     stream of launches that may be in flight together): nothing of it is process-wide, so two engines in one process -- or a hipGraph captured
     before another engine changed its geometry -- keep their own.  Allocate outside stream captures (the engines do it at construction)."""
 
-    def __init__(self, device, unroll=0, pipeline=0, split_min=0, max_pairs=128, split=True):
+    def __init__(self, device, unroll=0, pipeline=0, split_min=None, max_pairs=128, split=True):
         dev = torch.device(device)
+        if split_min is None:  # 0 = the library's 512; CBX_DA_SPLIT_MIN: A/B scripts
+            split_min = int(os.environ.get("CBX_DA_SPLIT_MIN", "0") or 0)
         self.unroll, self.pipeline, self.split_min, self.max_pairs = int(unroll), int(pipeline), int(split_min), int(max_pairs)
         self.ws = torch.empty(max_pairs * 8 * 66, dtype=torch.float32, device=dev) if split else None
         self.cnt = torch.zeros(max_pairs, dtype=torch.int32, device=dev) if split else None

@@ -24,6 +24,8 @@ VARIANTS = [dict(), dict(P7), dict(QK), dict(QK, head_ct=2), dict(QK, head_ct=3)
             dict(QK, head_ct=2, da_pipe=5, pre_epi=1), dict(QK, head_ct=2, da_pipe=3, pre_epi=1), dict()]
 if os.environ.get('CBX_AB_SHORT'):
     VARIANTS = [dict(), dict(o_nw2=16), dict(d_nw2=8), dict(o_nw2=16, d_nw2=8), dict(gu_nw=4), dict(da_pipe=3), dict(da_pipe=1, da_u=8), dict(pre_epi=0), dict()]
+if os.environ.get('CBX_AB_B1'):  # Llama at batch 1 (2 rows): geometries without partial images / with narrow tiles
+    VARIANTS = [dict(), dict(od_tc=4, d_ks2=1, d_nw2=8), dict(od_tc=4, d_ks2=1, d_nw2=16), dict(d_ks2=1, d_nw2=16), dict(qkv_ks=0), dict(qkv_ks=0, od_tc=4, d_ks2=1, d_nw2=8), dict(qkv_ks=0, qkv_tc=12, od_tc=4, d_ks2=1, d_nw2=8), dict(half_tiles=0, d_ks2=4, d_nw2=8), dict(da_pipe=3), dict()]
 rows, ref = [], None
 for v in VARIANTS:
     t, k = split_variant(v)

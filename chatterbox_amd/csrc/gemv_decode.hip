@@ -343,6 +343,7 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
     constexpr int NW = 8;
     __shared__ __attribute__((aligned(16))) float red[NW * CT * 256];
     __shared__ float ssq[NW * 16];
+    __shared__ float ssx[NW * 16];  // row sums (LayerNorm form: ln_cw / ln_cb, ksplit == 1)
     CBX_TRC_DECL;
     CBX_TRC_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
     f32x4 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ss = 0.f;
+    float ss = 0.f, sx = 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // DEPTH = K blocks requested per batch (picked by the host so that it divides the wave's block count: an idle slot would re-read a block,
     // i.e. spend the very per-CU bytes this form saves; registers: DEPTH * 2 * (CT + NP + 2) float4)
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
                 }
                 xq = (on[d] && xok) ? xq : zero4;
                 ss += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
+                sx += (xq[0] + xq[1]) + (xq[2] + xq[3]);
                 xq *= nv[d][h];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
@@ -439,10 +441,12 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(w * CT + c) * 256 + (q * 4 + r) * 16 + c16] = acc[c][r];
     {
-        float v = ss;
+        float v = ss, u = sx;
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (q == 0) ssq[w * 16 + c16] = v;
+        u += __shfl_xor(u, 16);
+        u += __shfl_xor(u, 32);
+        if (q == 0) ssq[w * 16 + c16] = v, ssx[w * 16 + c16] = u;
     }
     __syncthreads();
     CBX_TRC_STAMP(4);
@@ -455,7 +459,14 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
         for (int ww = 0; ww < NW; ++ww) v += red[(ww * CT + c) * 256 + rc];
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) sq += ssq[ww * 16 + row];
-        if (p.ksplit == 1) {
+        if (p.ln_cw) {  // LayerNorm form (GPT-2 ln_f + head; ksplit == 1): the expression of gemv_kernel
+            float su = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) su += ssx[ww * 16 + row];
+            const float mean = su / (float)p.K;
+            const float rstd = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.f) + p.eps);
+            v = rstd * (v - mean * p.ln_cw[n]) + p.ln_cb[n];
+        } else if (p.ksplit == 1) {
             v *= rsqrtf(sq / (float)p.K + p.eps);
         } else if (blockIdx.x == 0 && c == 0 && col == 0) {
             p.ssq_out[ks * 16 + row] = sq;  // this K slice's sum of squares of row `row` (identical in every column group: group 0 writes it)
@@ -769,9 +780,9 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     CBX_REQUIRE(!p.out_packed || p.N % 32 == 0, "gemv: out_packed needs N %% 32 == 0");
     CBX_REQUIRE(!(p.w_packed || p.x_packed) || p.K % 32 == 0, "gemv: packed operands need K %% 32 == 0");
     if (p.col_tiles > 0) {  // column-tile / split-K form of the RMSNorm-folded packed GEMV (gemv_ct_kernel)
-        CBX_REQUIRE(p.col_tiles <= 4 && p.norm_w && p.w_packed && p.x_packed && !p.w_bf16 && !p.swiglu && !p.ln_cw && !p.bias && !p.res && !p.act && !p.out_packed &&
-                        p.half_tile == 0 && p.M <= 16,
-                    "gemv: col_tiles serves the plain RMSNorm-folded packed fp32 form (M <= 16, 16-column image, no bias / residual / activation)");
+        CBX_REQUIRE(p.col_tiles <= 4 && p.norm_w && p.w_packed && p.x_packed && !p.w_bf16 && !p.swiglu && !p.bias && !p.res && !p.act && !p.out_packed &&
+                        p.half_tile == 0 && p.M <= 16 && (!p.ln_cw || (p.ln_cb && p.ksplit == 1)),
+                    "gemv: col_tiles serves the plain RMSNorm- / LayerNorm-folded packed fp32 form (M <= 16, 16-column image, no bias / residual / activation; LayerNorm form: ksplit == 1)");
         CBX_REQUIRE(p.K % (256 * p.ksplit) == 0 && (p.ksplit == 1 || p.ssq_out), "gemv: col_tiles needs K %% (256 * ksplit) == 0, and ssq_out with ksplit > 1");
         CBX_REQUIRE(p.n_xpart == 0 || ((p.n_xpart == 2 || p.n_xpart == 4) && p.xpart && p.x_out != p.x), "gemv: col_tiles with xpart: 2 or 4 images, x_out != x");
         hipStream_t st = (hipStream_t)stream;

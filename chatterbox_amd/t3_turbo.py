@@ -42,7 +42,8 @@ class T3TurboEngine:
         # 8-column tiles for the two N = D projections (twice the workgroups), split-K factor / waves of the MLP projection;
         # qkv_tc = 12 / od_tc = 4 (ABI v9): c_attn resp. the two N = D projections on N / 12 resp. N / 4 workgroups, d_ks = 1: the MLP
         # projection adds bias + residual itself (no partial images, no fold in the next c_attn GEMV)
-        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0)
+        # head_ct: column tiles per workgroup of the head GEMV (cbx_gemv_t.col_tiles: 6563 columns = 411 tiles -> 206 workgroups, one round of the chip)
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, head_ct=2)
         for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
             k, v = kv.split("=")
             assert k.strip() in self.tune, f"CBX_TURBO_TUNE: unknown knob {k!r} (known: {sorted(self.tune)})"
@@ -127,7 +128,8 @@ class T3TurboEngine:
                 ops.gemv(g, self._image(lw, "wpr", odtc), cur, N=D, K=4 * D, nw=tn["d_nw"], bias=lw["bpr"], res=cur, out_packed=True, half_tile=ot, **pk)
         if red:
             red["x_out"] = None
-        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1], **red, **pk)
+        ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1],
+                 col_tiles=int(tn.get("head_ct") or 0) if D % 256 == 0 else 0, **red, **pk)
 
     def _tiles(self):
         """(c_attn tile width, attention / MLP projection tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""

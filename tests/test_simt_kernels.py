@@ -74,6 +74,7 @@ _OPS = [
     ("test_gemv_narrow_tiles", (16, 1024, 4096, 1, 8, 4, "bf16")),
     ("test_gemv_col_tiles_and_split_k", (16, 3072, 1024, 3, 4, 2)), ("test_gemv_col_tiles_and_split_k", (16, 8194, 1024, 2, 1, 2)),
     ("test_gemv_col_tiles_and_split_k", (9, 200, 2048, 3, 2, 0)), ("test_gemv_col_tiles_and_split_k", (16, 3072, 1024, 3, 1, 4)),
+    ("test_gemv_col_tiles_layernorm_form", (1, 6563, 1024, 2, 2)), ("test_gemv_col_tiles_layernorm_form", (5, 6563, 768, 2, 0)),
     ("test_decode_attn_folds_qkv_partial_sums", (5, 16, 2, 1)), ("test_decode_attn_folds_qkv_partial_sums", (2, 12, 4, 0)),
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),

@@ -211,6 +211,27 @@ def test_gemv_col_tiles_and_split_k(dev, M, N, K, ct, ks, np_):
         _close(_unpack_operand(e["x_out"], M, K), xs, 1e-6, "x_out = x + partial images (written slice by slice)")
 
 
+@pytest.mark.parametrize("M,N,K,ct,np_", [(1, 6563, 1024, 2, 2), (5, 6563, 768, 2, 0), (16, 3072, 1024, 3, 4)])
+def test_gemv_col_tiles_layernorm_form(dev, M, N, K, ct, np_):
+    """cbx_gemv_t.col_tiles with ln_cw / ln_cb (GPT-2: ln_f folded into the head GEMV of Turbo / Nano, K = 1024 / 768): bit-identical to the one-tile
+    kernel's LayerNorm form and equal to torch."""
+    from chatterbox_amd import ops
+    x, w, lw, lb, bias = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), 1 + 0.1 * _r((K,), 3), 0.1 * _r((K,), 4), _r((N,), 6)
+    parts = _r((max(np_, 1), M, K), 5, 0.3)
+    xs = x + sum(parts[j] for j in range(np_)) if np_ else x
+    ref = F.linear(F.layer_norm(xs, (K,), lw, lb, 1e-5), w, bias)
+    xp, wp = ops.pack_gemv_weight(x.to(dev)), ops.pack_gemv_weight(w.to(dev))
+    cw, cb = F.linear(lw[None], w)[0], F.linear(lb[None], w)[0] + bias
+    mk = lambda: dict(norm_w=lw.to(dev), ln_cw=cw.to(dev), ln_cb=cb.to(dev),
+                      **(dict(xpart=torch.stack([ops.pack_gemv_weight(parts[j].to(dev)) for j in range(np_)]), x_out=torch.zeros_like(xp)) if np_ else {}))
+    kw = dict(N=N, M=M, K=K, nw=8, w_packed=True, x_packed=True)
+    a, b = torch.zeros(M, N, device=dev), torch.full((M, N), float("nan"), device=dev)
+    ops.gemv(xp, wp, a, **kw, **mk())
+    ops.gemv(xp, wp, b, col_tiles=ct, **kw, **mk())
+    assert torch.equal(a, b), f"col_tiles = {ct} (LayerNorm form) differs from the one-tile kernel: {_first_diff(a.cpu(), b.cpu())}"
+    _close(b, ref, 1e-4 * max(1.0, math.sqrt(K / 256)), "LayerNorm-folded gemv on column tiles")
+
+
 @pytest.mark.parametrize("rows,H,nparts,pipe", [(16, 16, 4, 0), (16, 16, 4, 7), (5, 16, 2, 1), (2, 12, 4, 0)])
 def test_decode_attn_folds_qkv_partial_sums(dev, rows, H, nparts, pipe):
     """cbx_decode_attn_t.qkv_nparts (ABI v11): the attention launch adds the split-K partial sums of the q/k/v row in fixed order and applies

@@ -411,6 +411,12 @@ def decode_step_entry(t3, n_layers, gpt2=False):
                 weight_bytes_per_step=round(w_bytes, 0), kv_bytes_per_step_mean=round(kv / steps, 0))
 
 
+def _on_green(t3):
+    """Is the decode geometry the timed region ran on the committed allow-list of hardware-verified geometries (chatterbox_amd/decode_green.json)?"""
+    from chatterbox_amd import autotune as at
+    return at.canon(t3.tune, t3.knobs) in at.green_variants()
+
+
 def log(msg):
     if os.environ.get("CBX_BENCH_VERBOSE"):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -694,7 +700,7 @@ def main():
                        "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial")},
             # the T3 decode geometry the timed region ran (built-in + what the autotuner adopted from the hardware-green allow-list)
             "t3_geometry": ({"adopted": (tune_rep or {}).get("adopted") or {}, "tune": {k: v for k, v in eng.t3.tune.items() if v != type(eng.t3)._TUNE.get(k)},
-                             "knobs": dict(eng.t3.knobs), "on_green_list": True} if not turbo else {"tune": dict(eng.t3.tune), "knobs": dict(eng.t3.knobs)}),
+                             "knobs": dict(eng.t3.knobs), "on_green_list": _on_green(eng.t3)} if not turbo else {"tune": dict(eng.t3.tune), "knobs": dict(eng.t3.knobs)}),
             "multi_gpu_note": ("single-GPU run: no N > 1 scaling curve exists in this repo (the driver owns multi-GPU leases)" if world == 1 else None),
             "roofline": roof,
             "decode_step": dstep,

@@ -97,6 +97,13 @@ class T3Step(ctypes.Structure):
                 ("qkv_ksplit", c_int), ("qkv_ct", c_int), ("head_ct", c_int), ("qkv_ssq", c_f)]  # ABI v11
 
 
+class T3Prefill(ctypes.Structure):  # cbx_t3_prefill_t
+    _fields_ = [("n_layers", c_int), ("rows", c_int), ("S", c_int), ("dim", c_int), ("ffn", c_int), ("n_heads", c_int), ("precision", c_int),
+                ("eps", c_float), ("attn_scale", c_float), ("layers", ctypes.POINTER(T3Layer)), ("x", c_f), ("h", c_f), ("qkv", c_f), ("att", c_f), ("g", c_f),
+                ("positions", c_f), ("cache_rows", c_f), ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f),
+                ("kv_layer_stride", c_long), ("kv_row_stride", c_long), ("kv_head_stride", c_long)]
+
+
 _SIGS = {
     "cbx_abi_version": ([], c_int),
     "cbx_last_error": ([], ctypes.c_char_p),
@@ -149,6 +156,7 @@ _SIGS = {
     "cbx_stats_pool_f32": ([c_f, c_f, c_int, c_int, c_long, c_f], c_int),
     "cbx_fsq_index": ([c_f, c_f, c_long, c_long, c_f], c_int),
     "cbx_t3_decode_step": ([ctypes.POINTER(T3Step), c_f], c_int),
+    "cbx_t3_prefill": ([ctypes.POINTER(T3Prefill), c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
     "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),

@@ -87,3 +87,44 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     if ((rc = cbx_gemv_f32(&g, stream))) return rc;
     return d->sampler ? cbx_t3_sample(d->sampler, stream) : 0;
 }
+
+// Stage-level C entry point of the T3 PREFILL (reference models/t3/t3.py:303-335 through t3_hf_backend.py:71-111: the HF LlamaModel forward over
+// the S0 prompt positions of every row, KV cache filled): n_layers x [RMSNorm, fused q/k/v GEMM, RoPE + cache fill, causal flash attention, o GEMM + residual,
+// RMSNorm, gate | up GEMM with SwiGLU, down GEMM + residual] on the caller's stream -- the launches chatterbox_amd/t3.py::_layer_prefill issues one by one,
+// with the same arguments (bit-identical results).  Together with cbx_t3_decode_step a C host drives the whole device side of T3.inference; the speech head on
+// the last position of every row is one more cbx_layernorm_f32 + cbx_gemm_f32 of the caller's.  No allocation, no synchronisation.
+extern "C" int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream) {
+    CBX_REQUIRE(d && d->layers && d->n_layers > 0 && d->x && d->h && d->qkv && d->att && d->g && d->positions && d->cache_rows && d->kc && d->vc,
+                "t3_prefill: null descriptor field");
+    CBX_REQUIRE(d->rows >= 1 && d->S >= 1 && d->dim == d->n_heads * 64 && d->ffn > 0, "t3_prefill: bad shape (head_dim 64)");
+    const int D = d->dim, F = d->ffn, H = d->n_heads;
+    const long M = (long)d->rows * d->S;
+    auto linear = [&](const float* A, const float* W, float* C, const float* R, int N, int K, int swiglu) {
+        cbx_gemm_t g{};
+        g.A = A, g.W = W, g.C = C, g.R = R;
+        g.M = (int)M, g.N = N, g.K = K, g.Cin = K, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1, g.swiglu = swiglu;
+        g.alpha = 1.0f, g.lda = K, g.ldw = K, g.ldc = swiglu ? N / 2 : N, g.ldr = R ? D : 0, g.precision = swiglu ? 0 : d->precision;
+        return cbx_gemm_f32(&g, stream);
+    };
+    int rc = 0;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const cbx_t3_layer_t& L = d->layers[i];
+        float* kc = d->kc + (long)i * d->kv_layer_stride;
+        float* vc = d->vc + (long)i * d->kv_layer_stride;
+        if ((rc = cbx_layernorm_f32(d->x, d->h, L.ln1, nullptr, nullptr, M, D, D, D, d->eps, 1, CBX_ACT_NONE, 1.0f, stream))) return rc;
+        if ((rc = linear(d->h, L.wqkv, d->qkv, nullptr, 3 * D, D, 0))) return rc;
+        if ((rc = cbx_rope_kv_f32(d->qkv, d->positions, d->cos_t, d->sin_t, kc, vc, d->cache_rows, M, H, 3 * D, d->kv_row_stride, d->kv_head_stride, stream))) return rc;
+        const long sb = (long)d->S * 3 * D, st = 3 * D;
+        if (d->precision == 3 || d->precision == 6 || d->precision == 16)
+            rc = cbx_flash_attn_split_f32(d->qkv, d->qkv + D, d->qkv + 2 * D, d->att, nullptr, d->rows, H, d->S, d->S, sb, st, sb, st, sb, st, (long)d->S * D, D, d->attn_scale, 1,
+                                          d->precision, stream);
+        else
+            rc = cbx_flash_attn_f32(d->qkv, d->qkv + D, d->qkv + 2 * D, d->att, nullptr, d->rows, H, d->S, d->S, sb, st, sb, st, sb, st, (long)d->S * D, D, d->attn_scale, 1, stream);
+        if (rc) return rc;
+        if ((rc = linear(d->att, L.wo, d->x, d->x, D, D, 0))) return rc;
+        if ((rc = cbx_layernorm_f32(d->x, d->h, L.ln2, nullptr, nullptr, M, D, D, D, d->eps, 1, CBX_ACT_NONE, 1.0f, stream))) return rc;
+        if ((rc = linear(d->h, L.wgu, d->g, nullptr, 2 * F, D, 1))) return rc;
+        if ((rc = linear(d->g, L.wd, d->x, d->x, D, F, 0))) return rc;
+    }
+    return 0;
+}

@@ -410,6 +410,24 @@ class T3Engine:
         ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
         ops.linear(ws["g"], lw["wd"], x, residual=x)
 
+    def _prefill_c(self, xf, ws, S, rows, st, pos, crow):
+        """The prefill through cbx_t3_prefill (include/cbx.h): the launches of _layer_prefill x n_layers, sequenced in C."""
+        import ctypes
+        from ._lib import T3Layer, T3Prefill, check, lib
+        p = lambda t: t.data_ptr()
+        if not hasattr(self, "_prefill_layers"):
+            arr = (T3Layer * self.L)()
+            for i, lw in enumerate(self.layers):
+                arr[i].ln1, arr[i].ln2, arr[i].wqkv, arr[i].wo, arr[i].wgu, arr[i].wd = p(lw["ln1"]), p(lw["ln2"]), p(lw["wqkv"]), p(lw["wo"]), p(lw["wgu"]), p(lw["wd"])
+            self._prefill_layers = arr
+        d = T3Prefill()
+        d.n_layers, d.rows, d.S, d.dim, d.ffn, d.n_heads, d.precision = self.L, rows, S, self.D, self.F, self.H, int(self.tune.get("prefill_prec") or 0)
+        d.eps, d.attn_scale, d.layers = 1e-5, 0.125, self._prefill_layers
+        d.x, d.h, d.qkv, d.att, d.g = p(xf), p(ws["h"]), p(ws["qkv"]), p(ws["att"]), p(ws["g"])
+        d.positions, d.cache_rows, d.cos_t, d.sin_t, d.kc, d.vc = p(pos), p(crow), p(self.cos), p(self.sin), p(st["kc"]), p(st["vc"])
+        d.kv_layer_stride, d.kv_row_stride, d.kv_head_stride = st["kc"].stride(0), st["kc"].stride(1), st["kc"].stride(2)
+        check(lib.cbx_t3_prefill(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "cbx_t3_prefill")
+
     def _forward_decode(self, st):
         """One token for every row.  The residual stream x is only touched by add_rmsnorm, which folds the split-K
         partials of the previous projection, the residual add and the RMSNorm into one pass."""
@@ -665,9 +683,12 @@ class T3Engine:
         # prefill_prec (tune / CBX_T3_TUNE="prefill_prec=6", opt-in, untimed): the prefill's plain projections (q/k/v, o, down) and its attention
         # on the bf16x6 split kernels (24 significand bits, fp32 range, accumulation error below the exact MFMA's own: DESIGN.md section 1)
         # instead of the exact fp32 MFMA; gate|up (SwiGLU epilogue) and every decode step stay exact
-        with ops.gemm_precision(self.tune.get("prefill_prec") or 0):
-            for i, lw in enumerate(self.layers):
-                self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
+        if self.c_step and not ops.TIMER:  # the same launches through the stage-level C entry point cbx_t3_prefill (one ctypes call instead of 9 per layer)
+            self._prefill_c(xf, pws, S, rows, st, pos, crow)
+        else:
+            with ops.gemm_precision(self.tune.get("prefill_prec") or 0):
+                for i, lw in enumerate(self.layers):
+                    self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
         last = torch.tensor([r * S + s0[r % B] - 1 for r in range(rows)], device=dev)
         hl = xf.index_select(0, last).contiguous()
         ops.layernorm(hl, self.norm, None, st["dws"]["h"], 1e-5, rms=True)

@@ -432,6 +432,27 @@ typedef struct cbx_t3_step_t {
 } cbx_t3_step_t;
 int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
 
+/* ---- stage-level entry point: the PREFILL of T3.inference for every row (t3.py:303-335 -> t3_hf_backend.py:71-111: HF LlamaModel over the S prompt
+ * positions, KV cache filled) ----
+ * x (rows * S, dim) holds the input embeddings (prepare_input_embeds + the second BOS, t3.py:102-130, 305-313; rows right-padded to S) and returns the last
+ * layer's residual stream; the caller applies tfmr.norm + speech_head to the positions it needs (cbx_layernorm_f32 + cbx_gemm_f32).  `layers`: the
+ * cbx_t3_layer_t of the decode step with ROW-MAJOR weights (torch Linear layout; wgu = the [32 gate | 32 up]-interleaved image, cbx_gemm_t.swiglu).
+ * positions / cache_rows [rows * S]: RoPE position and KV-cache row of every prompt position.  precision: cbx_gemm_t.precision of the plain projections and
+ * of the attention (0 / 1 = exact fp32 MFMA, the parity path; 6 = bf16x6).  Sequences kernel-level entry points only: no allocation, no synchronisation,
+ * hipGraph-capturable; results bit-identical to issuing the same launches one by one. */
+typedef struct cbx_t3_prefill_t {
+    int n_layers, rows, S, dim, ffn, n_heads, precision;
+    float eps, attn_scale;
+    const cbx_t3_layer_t* layers;         /* HOST array [n_layers], row-major weights */
+    float* x;                             /* [rows * S][dim] in / out */
+    float *h, *qkv, *att, *g;             /* workspaces: [rows * S][dim], [..][3 * dim], [..][dim], [..][ffn] */
+    const int *positions, *cache_rows;    /* [rows * S] */
+    const float *cos_t, *sin_t;           /* RoPE tables [max_pos][64] */
+    float *kc, *vc;                       /* KV cache [n_layers][rows][n_heads][max_ctx][64] */
+    long kv_layer_stride, kv_row_stride, kv_head_stride;  /* floats */
+} cbx_t3_prefill_t;
+int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream);
+
 /* ---- HiFT source + (i)STFT (hifigan.py:201-231,267-283,396-410) ---- */
 int cbx_hift_source_f32(const float* f0, const float* phase, const float* noise, const float* lin_w, float lin_b,
                         float* s, double* frame_cum, int B, int T, int up, float sr, void* stream);

@@ -35,7 +35,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
-               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams}
+               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

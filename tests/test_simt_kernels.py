@@ -506,6 +506,13 @@ def test_t3_llama_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
         assert toks[b].tolist() == ref.tolist(), f"utterance {b}: {toks[b].tolist()} vs oracle {ref.tolist()}"
 
 
+def test_t3_prefill_c_entry_point_on_the_emulator(emu):
+    """tests/test_zz_abi_v9_gpu.py::test_t3_prefill_through_the_c_entry_point_equals_the_python_sequence on the emulator: one layer at the real width, two
+    ragged utterances, two token steps (the ragged 3-utterance, 2-layer body of the GPU test would take minutes here)."""
+    import test_zz_abi_v9_gpu
+    test_zz_abi_v9_gpu.test_t3_prefill_through_the_c_entry_point_equals_the_python_sequence(CPU, layers=1, lens=(3, 5), steps=2)
+
+
 @pytest.mark.parametrize("name", ["test_s3_log_mel_vs_reference", "test_mel24k_vs_reference"])
 def test_frontend_bodies_against_the_references_golden_vectors_on_the_emulator(emu, name):
     """tests/test_frontend_gpu.py bodies on the emulator: the S3 tokenizer's log-mel and the 24 kHz prompt mel (framed DFT as an exact fp32

@@ -421,6 +421,27 @@ def test_the_default_geometry_is_on_the_allow_list():
     assert at.canon(T3Engine._TUNE, at.LIB_KNOBS) in at.green_variants(), at.canon(T3Engine._TUNE, at.LIB_KNOBS)
 
 
+def test_t3_prefill_through_the_c_entry_point_equals_the_python_sequence(dev, layers=2, lens=(12, 20, 7), steps=6):
+    """cbx_t3_prefill (stage-level C seam of T3.inference's prefill, t3.py:303-335): the KV cache and the prefill logits of a ragged batch are
+    bit-identical to issuing the same launches one by one from Python (T3Engine._layer_prefill), and the sampled tokens follow."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3 import T3Engine
+    sd = synth.t3_state_dict(layers, 0)
+    tt = [synth.text_tokens(n, seed=i + 1) for i, n in enumerate(lens)]
+    u = synth.rand((len(lens), steps), seed=3)
+    kw = dict(max_new_tokens=steps, uniforms=u, ban_eos=True, return_prefill_logits=True, **SAMP)
+    res = []
+    for c_step in (True, False):
+        eng = T3Engine(sd, dev)
+        eng.c_step = c_step
+        toks, logits = eng.generate(synth.t3_cond(), tt, **kw)
+        st = next(iter(eng._state.values()))
+        res.append(([t.tolist() for t in toks], logits.cpu(), st["kc"].cpu().clone(), st["vc"].cpu().clone()))
+    assert res[0][0] == res[1][0]
+    for a, b, what in zip(res[0][1:], res[1][1:], ("prefill logits", "k cache", "v cache")):
+        assert torch.equal(a, b), f"cbx_t3_prefill vs the Python launch sequence: {what}: {_first_diff(a, b)}"
+
+
 def test_two_engines_with_different_geometries_in_one_process(dev):
     """ABI v10: the decode geometry travels per call (cbx_decode_attn_t, cbx_gemv_t.flags, cbx_t3_step_t.da_* / gemv_flags) -- nothing is
     process-wide.  Two T3Engines with different geometries, their decode graphs captured one after the other and replayed INTERLEAVED, each

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 11  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 12  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -104,6 +104,40 @@ class T3Prefill(ctypes.Structure):  # cbx_t3_prefill_t
                 ("kv_layer_stride", c_long), ("kv_row_stride", c_long), ("kv_head_stride", c_long)]
 
 
+class PlanesRef(ctypes.Structure):  # cbx_planes_t (ABI v12)
+    _fields_ = [("p", c_f), ("ld", c_long), ("lo", c_long)]
+
+
+class CfmTBlock(ctypes.Structure):  # cbx_cfm_tblock_t
+    _fields_ = [(k, c_f) for k in ("n1_w", "n1_b", "n3_w", "n3_b", "bo", "b1", "b2")] + [(k, PlanesRef) for k in ("wqkv", "wo", "w1", "w2")]
+
+
+class CfmStage(ctypes.Structure):  # cbx_cfm_stage_t
+    _fields_ = ([(k, PlanesRef) for k in ("c1", "c2", "res", "tail")]
+                + [(k, c_f) for k in ("c1_b", "n1_w", "n1_b", "c2_b", "n2_w", "n2_b", "res_b", "tail_b")]
+                + [("cin", c_int), ("n_tb", c_int), ("tb", ctypes.POINTER(CfmTBlock))])
+
+
+class CfmSolve(ctypes.Structure):  # cbx_cfm_t
+    _fields_ = ([(k, c_int) for k in ("n_stages", "rows", "B", "n_steps", "cfg", "fused_qkv", "fused_mlp")]
+                + [("T", c_long), ("cfg_rate", c_float), ("dt", ctypes.POINTER(c_float)), ("stages", ctypes.POINTER(CfmStage)),
+                   ("fin_c", PlanesRef), ("fin_proj", PlanesRef)]
+                + [(k, c_f) for k in ("fin_c_b", "fin_n_w", "fin_n_b", "fin_proj_b", "tbias", "lens", "xin")]
+                + [("xinP", PlanesRef)] + [(k, c_f) for k in ("ra", "rb", "x", "v")]
+                + [(k, PlanesRef) for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP")])
+
+
+class HiftResblock(ctypes.Structure):  # cbx_hift_resblock_t
+    _fields_ = [(k, c_f * 3) for k in ("c1_w", "c1_b", "c2_w", "c2_b", "a1", "a2")]
+
+
+class HiftDecode(ctypes.Structure):  # cbx_hift_t
+    _fields_ = ([("B", c_int), ("precision", c_int), ("fade", c_int), ("T", c_long), ("mel", c_f), ("s", c_f), ("wav", c_f), ("lens", c_f),
+                 ("conv_pre_w", c_f), ("conv_pre_b", c_f), ("ups_w", c_f * 3), ("ups_b", c_f * 3), ("src_down_w", c_f * 3), ("src_down_b", c_f * 3),
+                 ("conv_post_w", c_f), ("conv_post_b", c_f), ("src_rb", HiftResblock * 3), ("rb", HiftResblock * 9)]
+                + [(k, c_f) for k in ("spec", "post", "x0", "xs", "t1", "xa", "xb", "an", "si", "sa", "acc", "a0")] + [("nxt", c_f * 2)])
+
+
 _SIGS = {
     "cbx_abi_version": ([], c_int),
     "cbx_last_error": ([], ctypes.c_char_p),
@@ -158,6 +192,8 @@ _SIGS = {
     "cbx_t3_decode_step": ([ctypes.POINTER(T3Step), c_f], c_int),
     "cbx_t3_prefill": ([ctypes.POINTER(T3Prefill), c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
+    "cbx_cfm_solve": ([ctypes.POINTER(CfmSolve), c_f], c_int),
+    "cbx_hift_decode": ([ctypes.POINTER(HiftDecode), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
     "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),
     "cbx_hift_istft_f32": ([c_f, c_f, c_int, c_long, c_long, c_float, c_int, c_f], c_int),

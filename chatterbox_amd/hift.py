@@ -61,6 +61,10 @@ class HiFTEngine:
         self.rb = [resblock(h + f"resblocks.{i}.") for i in range(9)]
         wpost = fw(h + "conv_post")  # (18, 64, 7) -> output columns padded to 32 for the iSTFT kernel's row stride
         self.conv_post = (d(weights.pack_conv(wpost)), d(sd[h + "conv_post.bias"]))
+        # decode() through the stage-level C entry point cbx_hift_decode (ABI v12; the same launches with the same arguments as the Python
+        # sequencing below -- bit-identical results).  Opt-in until a whole-suite hardware run has used it.
+        self.c_seam = os.environ.get("CBX_HIFT_CSEAM", "0") == "1"
+        self._c_static = None
 
     # ------------------------------------------------------------------ pieces
     def _resblock(self, rb, k, x, a_first, C, lens, out, alpha, beta, out2=None, act2=ops.NONE, act2_slope=0.0, ws=None):
@@ -106,11 +110,47 @@ class HiFTEngine:
         ops.hift_source(f0, phase.reshape(B, 9).contiguous(), noise.contiguous(), self.src_w, self.src_b, s, cum)
         return s
 
+    def _decode_c(self, mel, s, lens, fade):
+        """decode() as ONE call of cbx_hift_decode: the constant half of cbx_hift_t (weights) is built once per engine."""
+        import ctypes
+
+        from ._lib import HiftDecode, check, lib
+        p = ops._p
+        if self._c_static is None:
+            d = HiftDecode()
+            d.conv_pre_w, d.conv_pre_b, d.conv_post_w, d.conv_post_b = p(self.conv_pre[0]), p(self.conv_pre[1]), p(self.conv_post[0]), p(self.conv_post[1])
+            for i in range(3):
+                d.ups_w[i], d.ups_b[i], d.src_down_w[i], d.src_down_b[i] = p(self.ups[i][0]), p(self.ups[i][1]), p(self.src_down[i][0]), p(self.src_down[i][1])
+            for dst, src in [(d.src_rb[i], self.src_rb[i]) for i in range(3)] + [(d.rb[i], self.rb[i]) for i in range(9)]:
+                for j in range(3):
+                    dst.c1_w[j], dst.c1_b[j], dst.c2_w[j], dst.c2_b[j] = p(src[j]["c1"][0]), p(src[j]["c1"][1]), p(src[j]["c2"][0]), p(src[j]["c2"][1])
+                    dst.a1[j], dst.a2[j] = p(src[j]["a1"]), p(src[j]["a2"])
+            self._c_static = d
+        d = HiftDecode()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(self._c_static), ctypes.sizeof(HiftDecode))
+        dev, (B, T, _) = self.dev, mel.shape
+        f = lambda *sh: torch.empty(*sh, device=dev)
+        L3 = 120 * T + 1
+        wav = f(B, 480 * T)
+        lens5 = None if lens is None else torch.stack([lens, lens * 8, lens * 40, lens * 120 + 1, lens * 480]).int().contiguous()
+        ws = dict(spec=f(B, L3, 32), post=f(B, L3, 32), x0=f(B, T, 512))
+        wide = [f(B, L3, 64) for _ in range(11)]
+        d.B, d.precision, d.fade, d.T = B, ops.GEMM_PRECISION, int(bool(fade)), T
+        d.mel, d.s, d.wav, d.lens = p(mel), p(s), p(wav), p(lens5)
+        d.spec, d.post, d.x0 = p(ws["spec"]), p(ws["post"]), p(ws["x0"])
+        for k, t in zip(("xs", "t1", "xa", "xb", "an", "si", "sa", "acc", "a0"), wide):
+            setattr(d, k, p(t))
+        d.nxt[0], d.nxt[1] = p(wide[9]), p(wide[10])
+        check(lib.cbx_hift_decode(ctypes.byref(d), ops._stream()), "cbx_hift_decode")
+        return wav
+
     @ops.on_device
     @torch.inference_mode()
     def decode(self, mel, s, lens=None, fade=True):
         """HiFTGenerator.decode: mel (B,T,80), s (B,480T) -> wav (B,480T).  lens (B,) int32 valid mel frames or None."""
         dev, (B, T, _) = self.dev, mel.shape
+        if self.c_seam and not ops.TIMER and mel.is_contiguous() and s.is_contiguous() and mel.dtype == torch.float32:
+            return self._decode_c(mel, s, lens, fade)
         f = lambda *sh: torch.empty(*sh, device=dev)
         L3 = 120 * T + 1
         spec = f(B, L3, 32)

@@ -118,6 +118,10 @@ class FlowEngine:
         self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None
+        # the Euler loop through the stage-level C entry point cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python
+        # sequencing below -- bit-identical results; plane-format path only).  Opt-in until a whole-suite hardware run has used it.
+        self.c_seam = os.environ.get("CBX_FLOW_CSEAM", "0") == "1"
+        self._cfm_static = None
 
     # ------------------------------------------------------------------ conformer encoder
     def _rel_pos_table(self, T, dev=None, dm=512):
@@ -373,6 +377,54 @@ class FlowEngine:
         cv(ws["aP"], pw["fin_proj"], taps=1, out=ws["v"], bias=self.fin["proj"][1])
         return ws["v"]
 
+    def _cfm_descriptor(self):
+        """The constant part of cbx_cfm_t (weights of every stage as cbx_cfm_stage_t / cbx_cfm_tblock_t host arrays), built once per engine."""
+        if self._cfm_static is None:
+            from ._lib import CfmSolve, CfmStage, CfmTBlock, PlanesRef
+            ref = lambda P: PlanesRef(P.ptr, P.ld, P.lo)
+            p = ops._p
+            pw = self._plane_weights()
+            keep, stages = [], (CfmStage * len(self.stages))()
+            for k, (sw, sp) in enumerate(zip(self.stages, pw["stages"])):
+                tbs = (CfmTBlock * len(sw["tb"]))()
+                for j, (tw, tp) in enumerate(zip(sw["tb"], sp["tb"])):
+                    t = tbs[j]
+                    t.n1_w, t.n1_b, t.n3_w, t.n3_b, t.bo, t.b1, t.b2 = (p(tw["n1"][0]), p(tw["n1"][1]), p(tw["n3"][0]), p(tw["n3"][1]), p(tw["bo"]),
+                                                                        p(tw["b1"]), p(tw["b2"]))
+                    t.wqkv, t.wo, t.w1, t.w2 = ref(tp["wqkv"]), ref(tp["wo"]), ref(tp["w1"]), ref(tp["w2"])
+                st = stages[k]
+                st.c1, st.c2, st.res = ref(sp["c1"]), ref(sp["c2"]), ref(sp["res"])
+                st.c1_b, st.n1_w, st.n1_b, st.c2_b = p(sw["c1"][1]), p(sw["n1"][0]), p(sw["n1"][1]), p(sw["c2"][1])
+                st.n2_w, st.n2_b, st.res_b = p(sw["n2"][0]), p(sw["n2"][1]), p(sw["res"][1])
+                if "tail" in sw:
+                    st.tail, st.tail_b = ref(sp["tail"]), p(sw["tail"][1])
+                st.cin, st.n_tb, st.tb = int(sw["cin"]), len(sw["tb"]), tbs
+                keep.append(tbs)
+            d = CfmSolve()
+            d.n_stages, d.stages = len(self.stages), stages
+            d.fin_c, d.fin_proj = ref(pw["fin_c"]), ref(pw["fin_proj"])
+            d.fin_c_b, d.fin_n_w, d.fin_n_b, d.fin_proj_b = p(self.fin["c"][1]), p(self.fin["n"][0]), p(self.fin["n"][1]), p(self.fin["proj"][1])
+            self._cfm_static = (d, stages, keep)
+        return self._cfm_static[0]
+
+    def _cfm_solve_c(self, xin, xinP, lens_r, tb, t_span, ws, B, rows, T, n_steps, cfg, cfg_rate):
+        """solve_euler through cbx_cfm_solve: one ctypes call instead of ~4400 per utterance batch."""
+        import ctypes
+
+        from ._lib import CfmSolve, PlanesRef, check, lib
+        d = CfmSolve()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(self._cfm_descriptor()), ctypes.sizeof(CfmSolve))
+        ref = lambda P: PlanesRef(P.ptr, P.ld, P.lo)
+        dt = (ctypes.c_float * n_steps)(*[float(t_span[k + 1] - t_span[k]) for k in range(n_steps)])
+        assert tb.is_contiguous() and tb.shape == (n_steps, len(self.stages), 256) and lens_r.dtype == torch.int32 and lens_r.numel() == rows
+        d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.fused_mlp, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), int(self.fused_mlp), T
+        d.cfg_rate, d.dt = cfg_rate, dt
+        d.tbias, d.lens, d.xin, d.xinP = ops._p(tb), ops._p(lens_r), ops._p(xin), ref(xinP)
+        d.ra, d.rb, d.x, d.v = ops._p(ws["ra"]), ops._p(ws["rb"]), ops._p(ws["x"]), ops._p(ws["v"])
+        for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP"):
+            setattr(d, k, ref(ws[k]))
+        check(lib.cbx_cfm_solve(ctypes.byref(d), ops._stream()), "cbx_cfm_solve")
+
     def _planes_ok(self, rows, T):
         """The plane-format path serves the f16x3 numerics (precision 16) with 31-bit operand offsets; anything else runs the fp32-operand kernels."""
         # (cbx_gemm_planes addresses one batch of an operand / output with 32-bit byte offsets: the widest plane tensor, the feed-forward
@@ -444,6 +496,9 @@ class FlowEngine:
         if planes:  # the packed estimator input in plane format: [mu | spk | cond] are split once, x after every Euler step
             xin2 = xin.view(rows * T, 320)
             xinP = ops.split_planes(xin2)
+        if planes and self.c_seam and not ops.TIMER:
+            self._cfm_solve_c(xin, xinP, lens_r, tb, t_span, ws, B, rows, T, n_steps, cfg, cfg_rate)
+            return xin[:B, :, :80]
         for k in range(n_steps):
             if planes:
                 if k:

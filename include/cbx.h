@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 11 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 12 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
@@ -25,7 +25,8 @@ extern "C" {
                                   the positional entry points only;
                               11: cbx_gemv_t.col_tiles / ssq_out (column-tile / split-K form of the RMSNorm-folded decode GEMV), cbx_decode_attn_t.qkv_nparts /
                                   qkv_part_stride / qkv_ssq / rms_dim / rms_eps (the attention adds the q/k/v partial sums and applies rstd),
-                                  cbx_t3_step_t.qkv_ksplit / qkv_ct / head_ct / qkv_ssq */
+                                  cbx_t3_step_t.qkv_ksplit / qkv_ct / head_ct / qkv_ssq, cbx_t3_prefill;
+                              12: stage-level seams of the flow decoder and the vocoder: cbx_planes_t, cbx_cfm_solve, cbx_hift_decode */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -452,6 +453,72 @@ typedef struct cbx_t3_prefill_t {
     long kv_layer_stride, kv_row_stride, kv_head_stride;  /* floats */
 } cbx_t3_prefill_t;
 int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream);
+
+/* ---- stage-level entry points of the S3Gen flow decoder and of the HiFT vocoder (ABI v12) ----
+ * A plane-format operand (see PLANE-FORMAT operands above) as the stage descriptors carry it: base of the h plane with any column offset applied, row
+ * stride and plane offset in halves. */
+typedef struct cbx_planes_t { void* p; long ld, lo; } cbx_planes_t;
+
+/* BasicTransformerBlock of the CFM estimator (matcha/transformer.py:243-316): norm1 -> to_q | to_k | to_v -> attention -> to_out + residual -> norm3 ->
+ * FeedForward (GELU) + residual.  wqkv: planes of the (1536, 256) row block [Wq; Wk; Wv]; wo (256, 512); w1 (1024, 256); w2 (256, 1024). */
+typedef struct cbx_cfm_tblock_t {
+    const float *n1_w, *n1_b, *n3_w, *n3_b, *bo, *b1, *b2;
+    cbx_planes_t wqkv, wo, w1, w2;
+} cbx_cfm_tblock_t;
+/* One down / mid / up stage of ConditionalDecoder (decoder.py:243-333): CausalResnetBlock1D (c1, n1 + Mish + time bias, c2, n2 + Mish, 1x1 res_conv), n_tb
+ * transformer blocks and -- down and up stage only -- the trailing CausalConv1d (tail.p == NULL otherwise).  Conv weights: planes of the tap-major
+ * (256, taps * cin) image. */
+typedef struct cbx_cfm_stage_t {
+    cbx_planes_t c1, c2, res, tail;
+    const float *c1_b, *n1_w, *n1_b, *c2_b, *n2_w, *n2_b, *res_b, *tail_b;
+    int cin, n_tb;
+    const cbx_cfm_tblock_t* tb;           /* HOST array [n_tb] */
+} cbx_cfm_stage_t;
+/* CausalConditionalCFM.solve_euler (models/s3gen/flow_matching.py:78-145, 196-233; meanflow: 196-233 with cfg = 0) around ConditionalDecoder.forward on
+ * plane-format operands (the f16x3 numerics, cbx_gemm_t.precision 16): n_steps x [x columns of xinP re-split (steps > 0), estimator -> v, Euler (+ CFG) update
+ * of xin].  xin (rows, T, 320) fp32 = [x | mu | spk | cond] per position (rows = 2 B with CFG: the second B rows hold [x | 0 | 0 | 0]); xinP its plane image,
+ * split by the caller before the call; on return xin[:B, :, :80] is the mel.  tbias [n_steps][n_stages][256]: every ResNet's time-MLP output per step (a
+ * function of the schedule only; the caller computes it once).  dt: HOST array [n_steps] of t_span[k + 1] - t_span[k].  lens [rows]: valid positions per row.
+ * Needs T even, rows * T > 32, (rows * T + 512) * 4096 < 2^31.  Sequences kernel-level entry points only (results bit-identical to issuing them one by one):
+ * no allocation, no synchronisation, hipGraph-capturable. */
+typedef struct cbx_cfm_t {
+    int n_stages, rows, B, n_steps, cfg, fused_qkv, fused_mlp;
+    long T;
+    float cfg_rate;
+    const float* dt;                      /* HOST [n_steps] */
+    const cbx_cfm_stage_t* stages;        /* HOST [n_stages]: down, mid ..., up */
+    cbx_planes_t fin_c, fin_proj;         /* final_block conv (256, 3 * 256), final_proj (80, 256) */
+    const float *fin_c_b, *fin_n_w, *fin_n_b, *fin_proj_b;
+    const float* tbias;
+    const int* lens;
+    float* xin;
+    cbx_planes_t xinP;                    /* (rows * T, 320) */
+    float *ra, *rb, *x, *v;               /* workspaces (rows, T, 256) x 3, estimator output (rows, T, 80) */
+    cbx_planes_t aP, hP, qkP, attP, ffP, xP, yP, catP;   /* plane workspaces over rows * T rows: 256, 256, 1024, 512, 1024, 256, 256, 512 columns */
+    cbx_planes_t vtP;                     /* V^T: (rows * 512) rows x (T rounded up to 8) columns, the padding zero */
+} cbx_cfm_t;
+int cbx_cfm_solve(const cbx_cfm_t* d, void* stream);
+
+/* ResBlock of HiFT (hifigan.py:118-161): three (Snake, dilated conv, Snake, conv, + x) rounds; conv weights tap-major (C, k * C), weight_norm folded */
+typedef struct cbx_hift_resblock_t {
+    const float *c1_w[3], *c1_b[3], *c2_w[3], *c2_b[3], *a1[3], *a2[3];
+} cbx_hift_resblock_t;
+/* HiFTGenerator.decode (hifigan.py:412-444) for B rows: STFT of the source s, conv_pre, 3 x [leaky ReLU, ConvTranspose1d (phase-packed 3-tap form, cbx_gemm_t),
+ * + source_resblock(source_down(STFT)), mean of 3 ResBlocks], conv_post, iSTFT (+ S3Gen's trim_fade when fade).  mel (B, T, 80) channel-last, s (B, 480 T),
+ * wav (B, 480 T).  lens: NULL or [5][B] = valid rows of {mel, stage 1, stage 2, stage 3 = STFT frames, source samples} = {n, 8 n, 40 n, 120 n + 1, 480 n}.
+ * precision: cbx_gemm_t.precision of every conv.  Workspaces: spec, post (B, 120 T + 1, 32); x0 (B, T, 512); xs .. nxt[1]: (B, 120 T + 1, 64) floats each
+ * (the widest stage; stages 1 and 2 use a prefix).  Same contract as cbx_cfm_solve. */
+typedef struct cbx_hift_t {
+    int B, precision, fade;
+    long T;
+    const float *mel, *s;
+    float* wav;
+    const int* lens;
+    const float *conv_pre_w, *conv_pre_b, *ups_w[3], *ups_b[3], *src_down_w[3], *src_down_b[3], *conv_post_w, *conv_post_b;
+    cbx_hift_resblock_t src_rb[3], rb[9];
+    float *spec, *post, *x0, *xs, *t1, *xa, *xb, *an, *si, *sa, *acc, *a0, *nxt[2];
+} cbx_hift_t;
+int cbx_hift_decode(const cbx_hift_t* d, void* stream);
 
 /* ---- HiFT source + (i)STFT (hifigan.py:201-231,267-283,396-410) ---- */
 int cbx_hift_source_f32(const float* f0, const float* phase, const float* noise, const float* lin_w, float lin_b,

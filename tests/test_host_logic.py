@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 11
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -35,7 +35,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
-               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill}
+               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill,
+               "cbx_planes_t": _lib.PlanesRef, "cbx_cfm_tblock_t": _lib.CfmTBlock, "cbx_cfm_stage_t": _lib.CfmStage, "cbx_cfm_t": _lib.CfmSolve,
+               "cbx_hift_resblock_t": _lib.HiftResblock, "cbx_hift_t": _lib.HiftDecode}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -490,3 +492,11 @@ def test_green_allow_list_is_canonical_and_contains_the_default_geometry():
     assert at.canon(T3Engine._TUNE, at.LIB_KNOBS) in green, "the default geometry must be hardware-verified"
     missing = [at.canon(t, k) for t, k in at.composed_candidates(T3Engine._TUNE, at.LIB_KNOBS) if at.canon(t, k) not in green]
     assert not missing, f"{len(missing)} composable candidates are not on the allow-list, e.g. {missing[:3]}"
+
+
+def test_stage_seams_reject_an_empty_descriptor():
+    """cbx_cfm_solve / cbx_hift_decode (ABI v12) validate their descriptor before the first launch (no GPU needed to see that)."""
+    import ctypes
+    from chatterbox_amd import _lib
+    for fn, cls in ((_lib.lib.cbx_cfm_solve, _lib.CfmSolve), (_lib.lib.cbx_hift_decode, _lib.HiftDecode)):
+        assert fn(ctypes.byref(cls()), None) == -22 and b"null descriptor" in _lib.lib.cbx_last_error()

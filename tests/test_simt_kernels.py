@@ -606,3 +606,23 @@ def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
     for knob in ("qkv_tc", "da_pipe", "pre_epi"):  # (what a knob is tried on top of depends on the emulator's "clock")
         hit = [r for r in rows.values() if r["variant"].get(knob) and not r["variant"].get("d_ks2")]
         assert hit and all(r["identical"] for r in hit), (knob, hit)
+
+
+_SLOW = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="half a minute each: CBX_EMU_SLOW=1")
+
+
+@pytest.mark.parametrize("meanflow,T,fused_qkv,fused_mlp", [(False, 20, True, False), (True, 34, True, False), pytest.param(False, 18, True, False, marks=_SLOW),
+                                                            pytest.param(False, 20, True, True, marks=_SLOW), pytest.param(True, 36, True, False, marks=_SLOW)])
+def test_cfm_solve_c_entry_point_on_the_emulator(emu, meanflow, T, fused_qkv, fused_mlp):
+    """tests/test_zzz_stage_seams_gpu.py on the emulator: cbx_cfm_solve (ABI v12) against FlowEngine.cfm's own launch sequence, bit for bit -- one utterance,
+    one mid stage, two Euler steps; CFG with the fused q | k | V^T projection, meanflow with (T % 4 != 0) the separate one; opt-in: the fused feed-forward
+    and the other pairings (all pass)."""
+    import test_zzz_stage_seams_gpu as S
+    S.test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(CPU, meanflow, T, fused_qkv, fused_mlp, n_mid=1, B=1, n_steps=2)
+
+
+@pytest.mark.parametrize("ragged,fade,precision", [(True, True, 16), pytest.param(False, False, 1, marks=_SLOW)])
+def test_hift_decode_c_entry_point_on_the_emulator(emu, ragged, fade, precision):
+    """cbx_hift_decode (ABI v12) against HiFTEngine.decode's own launch sequence on the emulator, bit for bit (2 rows of 3 mel frames)."""
+    import test_zzz_stage_seams_gpu as S
+    S.test_hift_decode_through_the_c_entry_point_equals_the_python_sequence(CPU, ragged, fade, precision, T=3, B=2)

@@ -1,0 +1,57 @@
+"""Stage-level C entry points of the flow decoder and the vocoder (-m gpu; ABI v12): `cbx_cfm_solve` and `cbx_hift_decode` sequence the same
+kernel-level launches, with the same arguments, as `FlowEngine.cfm` / `HiFTEngine.decode` issue one by one -- so their results must be BIT-identical
+to the Python sequencing (which the golden / oracle tests of tests/test_models_gpu.py pin against the reference).  The bodies take the device as an
+argument: tests/test_simt_kernels.py runs them on the SIMT emulator at smaller shapes.  The file sorts after every other `-m gpu` file on purpose.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("meanflow,T,fused_qkv,fused_mlp", [(False, 152, True, False), (False, 150, True, False), (True, 152, True, False),
+                                                            (False, 152, False, False), (False, 152, True, True)])
+def test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(dev, meanflow, T, fused_qkv, fused_mlp, n_mid=2, B=3, n_steps=3):
+    """solve_euler (CFG or meanflow) on the plane-format estimator: cbx_cfm_solve against FlowEngine.cfm's own launch sequence, for a ragged batch, the fused
+    and the separate q | k | V^T projection (T % 4 != 0 forces the separate one), the fused feed-forward."""
+    from chatterbox_amd import ops, synth
+    from chatterbox_amd.s3gen import FlowEngine
+    sd = synth.s3gen_state_dict(0, meanflow=meanflow, n_mid=n_mid, n_enc=1, n_up_enc=1)
+    eng = FlowEngine(sd, dev, meanflow=meanflow)
+    eng.fused_qkv, eng.fused_mlp = fused_qkv, fused_mlp
+    mu, cond, z = (synth.randn((B, T, 80), seed=s).to(dev) for s in (1, 2, 3))
+    cond[:, T // 3:] = 0
+    spk = synth.randn((B, 80), seed=4).to(dev)
+    lens = torch.tensor([T, T - 7, max(2, T // 2)][:B], dtype=torch.int32, device=dev)
+    out, calls, inner = {}, [], eng._cfm_solve_c
+    eng._cfm_solve_c = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    for seam in (False, True):
+        eng.c_seam = seam
+        with ops.gemm_precision(16), torch.inference_mode():
+            assert eng._planes_ok((1 if meanflow else 2) * B, T)
+            out[seam] = eng.cfm(mu, lens, spk, cond, z, n_steps=n_steps).clone()
+    assert len(calls) == 1, "the second pass went through cbx_cfm_solve"
+    assert torch.isfinite(out[True]).all() and out[True].abs().max() > 0
+    assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("ragged,fade,precision", [(True, False, 16), (False, True, 16), (True, True, 1)])
+def test_hift_decode_through_the_c_entry_point_equals_the_python_sequence(dev, ragged, fade, precision, T=20, B=3):
+    """HiFTGenerator.decode: cbx_hift_decode against HiFTEngine.decode's own launch sequence (ragged batch / full rows, with and without trim_fade,
+    f16x3 and exact fp32 convs)."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.hift import HiFTEngine
+    eng = HiFTEngine(synth.s3gen_state_dict(0), dev, precision=precision)
+    mel = (synth.randn((B, T, 80), seed=9) * 1.5 - 4.0).to(dev)
+    s = torch.tanh(synth.randn((B, 480 * T), seed=10)).to(dev)
+    lens = torch.tensor([T, max(1, T - 7), max(1, T // 3)][:B], dtype=torch.int32, device=dev) if ragged else None
+    from chatterbox_amd import ops
+    out, calls, inner = {}, [], eng._decode_c
+    eng._decode_c = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    for seam in (False, True):
+        eng.c_seam = seam
+        with ops.gemm_precision(precision):
+            out[seam] = eng.decode(mel, s, lens=lens, fade=fade).clone()
+    assert len(calls) == 1, "the second pass went through cbx_hift_decode"
+    assert torch.isfinite(out[True]).all() and out[True].abs().max() > 0
+    assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"

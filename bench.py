@@ -697,7 +697,9 @@ def main():
                                     f"batch {B}/GPU, {N} speech tokens (NOT the headline metric's config)"),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "stage_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage.items()}, "model_build_s": round(build_s, 1),
-                       "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial")},
+                       "schedule": ("pipelined: T3(k+1) on a high-priority stream overlaps flow+HiFT(k)" if pipelined else "serial"),
+                       # which stages ran through their stage-level C entry point (cbx_t3_prefill + cbx_t3_decode_step / cbx_cfm_solve / cbx_hift_decode)
+                       "stage_seams": {"t3": bool(getattr(eng.t3, "c_step", False)), "flow": bool(eng.flow.c_seam), "hift": bool(eng.hift.c_seam)}},
             # the T3 decode geometry the timed region ran (built-in + what the autotuner adopted from the hardware-green allow-list)
             "t3_geometry": ({"adopted": (tune_rep or {}).get("adopted") or {}, "tune": {k: v for k, v in eng.t3.tune.items() if v != type(eng.t3)._TUNE.get(k)},
                              "knobs": dict(eng.t3.knobs), "on_green_list": _on_green(eng.t3)} if not turbo else {"tune": dict(eng.t3.tune), "knobs": dict(eng.t3.knobs)}),

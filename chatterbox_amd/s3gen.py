@@ -114,7 +114,8 @@ class FlowEngine:
         # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
         self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
         # ff1 + GELU + ff2 + residual in one launch (cbx_mlp_planes): measured EQUAL to the two GEMMs it replaces at the bench shape (81.6 vs 80 us:
-        # with 64 tokens per workgroup it re-streams W1 / W2 through L2 -> LDS once per token tile, 640 MB per call) -- opt-in, not the default
+        # with 64 tokens per workgroup it re-streams W1 / W2 through L2 -> LDS once per token tile, 640 MB per call) and 18-27 % SLOWER on the flow stage at
+        # batch 1 (profiles/r04_batch1_seams_and_fused_mlp.log) -- opt-in, not the default
         self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None

@@ -500,3 +500,18 @@ def test_stage_seams_reject_an_empty_descriptor():
     from chatterbox_amd import _lib
     for fn, cls in ((_lib.lib.cbx_cfm_solve, _lib.CfmSolve), (_lib.lib.cbx_hift_decode, _lib.HiftDecode)):
         assert fn(ctypes.byref(cls()), None) == -22 and b"null descriptor" in _lib.lib.cbx_last_error()
+
+
+def test_c_blocks_of_integration_md_compile(tmp_path):
+    """Every ```c block of INTEGRATION.md is a translation unit against include/cbx.h (the header is plain C; the sketch of a C host stays in step with it)."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    blocks = re.findall(r"```c\n(.*?)```", open(os.path.join(ROOT, "INTEGRATION.md")).read(), flags=re.S)
+    assert blocks, "INTEGRATION.md holds at least the C host sketch"
+    for i, b in enumerate(blocks):
+        src = tmp_path / f"block{i}.c"
+        src.write_text(b)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])

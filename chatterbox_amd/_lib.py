@@ -127,6 +127,23 @@ class CfmSolve(ctypes.Structure):  # cbx_cfm_t
                 + [(k, PlanesRef) for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP")])
 
 
+class Conformer(ctypes.Structure):  # cbx_conformer_t
+    _fields_ = [(k, c_f) for k in ("ln_mha_w", "ln_mha_b", "w4", "b4", "wpos", "wo", "bo", "ln_ff_w", "ln_ff_b", "w1", "b1", "w2", "b2")]
+
+
+class S3Encode(ctypes.Structure):  # cbx_s3enc_t
+    _fields_ = ([(k, c_int) for k in ("B", "N", "n_enc", "n_up", "precision")] + [(k, c_f) for k in ("ids", "lens", "lens2")]
+                + [(k, c_f) for k in ("emb", "e_w", "e_b", "e_lnw", "e_lnb", "u_w", "u_b", "u_lnw", "u_lnb", "pl1_w", "pl1_b", "pl2_w", "pl2_b", "up_w", "up_b",
+                                      "after_w", "after_b", "proj_w", "proj_b")]
+                + [("enc", ctypes.POINTER(Conformer)), ("up_enc", ctypes.POINTER(Conformer)), ("pe", c_f), ("pe2", c_f)]
+                + [(k, c_f) for k in ("x0", "xa", "y1", "x2", "xu", "xb", "h", "q4", "pp", "att", "ff", "mu")])
+
+
+class HiftF0(ctypes.Structure):  # cbx_hift_f0_t
+    _fields_ = [("B", c_int), ("T", c_long), ("mel", c_f), ("lens", c_f), ("f0_w", c_f * 5), ("f0_b", c_f * 5), ("cls_w", c_f), ("cls_b", c_f), ("src_w", c_f),
+                ("src_b", c_float), ("phase", c_f), ("noise", c_f), ("buf0", c_f), ("buf1", c_f), ("f0", c_f), ("s", c_f), ("cum", c_f)]
+
+
 class HiftResblock(ctypes.Structure):  # cbx_hift_resblock_t
     _fields_ = [(k, c_f * 3) for k in ("c1_w", "c1_b", "c2_w", "c2_b", "a1", "a2")]
 
@@ -193,6 +210,8 @@ _SIGS = {
     "cbx_t3_prefill": ([ctypes.POINTER(T3Prefill), c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_cfm_solve": ([ctypes.POINTER(CfmSolve), c_f], c_int),
+    "cbx_s3gen_encode": ([ctypes.POINTER(S3Encode), c_f], c_int),
+    "cbx_hift_f0_source": ([ctypes.POINTER(HiftF0), c_f], c_int),
     "cbx_hift_decode": ([ctypes.POINTER(HiftDecode), c_f], c_int),
     "cbx_hift_source_f32": ([c_f, c_f, c_f, c_f, c_float, c_f, c_f, c_int, c_int, c_int, c_float, c_f], c_int),
     "cbx_hift_stft_f32": ([c_f, c_f, c_f, c_int, c_long, c_long, c_f], c_int),

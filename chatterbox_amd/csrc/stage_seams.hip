@@ -266,3 +266,110 @@ extern "C" int cbx_hift_decode(const cbx_hift_t* d, void* stream) {
     if ((rc = h.run(p))) return rc;
     return cbx_hift_istft_f32(d->post, d->wav, B, L3, 32, 0.99f, d->fade ? 480 : 0, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------ S3Gen token encoder
+namespace {
+
+struct EncCtx {
+    const cbx_s3enc_t* d;
+    void* stream;
+
+    // F.linear as ops.linear describes it to cbx_gemm_f32
+    int linear(const float* x, const float* w, float* out, const float* bias, const float* R, long M, int N, int K, int act) const {
+        cbx_gemm_t g{};
+        g.A = x, g.W = w, g.C = out, g.bias = bias, g.R = R;
+        g.M = (int)M, g.N = N, g.K = K, g.Cin = K, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1;
+        g.act1 = act, g.alpha = 1.0f, g.lda = K, g.ldw = K, g.ldc = N, g.ldr = R ? N : 0, g.precision = d->precision;
+        return cbx_gemm_f32(&g, stream);
+    }
+    // Conv1d over (B, Tin, 512) -> (B, Tout, 512), channel-last (ops.conv1d)
+    int conv(const float* x, const float* w, float* out, const float* bias, const float* R, const int* lens, long Tin, long Tout, int taps, int pad_left, int up,
+             int act, float slope) const {
+        cbx_gemm_t g{};
+        g.A = x, g.W = w, g.C = out, g.bias = bias, g.R = R, g.lens = lens;
+        g.M = (int)Tout, g.N = 512, g.K = taps * 512, g.Cin = 512, g.taps = taps, g.dil = 1, g.stride = 1, g.pad_left = pad_left, g.up = up, g.Tin = (int)Tin;
+        g.nz1 = d->B, g.nz2 = 1, g.act1 = act, g.act1_slope = slope, g.alpha = 1.0f;
+        g.lda = 512, g.a_s1 = Tin * 512, g.ldw = (long)taps * 512, g.ldc = 512, g.c_s1 = Tout * 512;
+        if (R) g.ldr = 512, g.r_s1 = Tout * 512;
+        g.precision = d->precision;
+        return cbx_gemm_f32(&g, stream);
+    }
+    int ln(const float* x, float* y, const float* w, const float* b, long rows, float eps, float scale) const {
+        return cbx_layernorm_f32(x, y, w, b, nullptr, rows, 512, 512, 512, eps, 0, CBX_ACT_NONE, scale, stream);
+    }
+    // LinearNoSubsampling / the up_embed twin: Linear -> LayerNorm -> * sqrt(d_model) (the positional encoding's xscale)
+    int embed(const float* xin, float* y, const float* w, const float* b, const float* lnw, const float* lnb, long M) const {
+        int rc = linear(xin, w, y, b, nullptr, M, 512, 512, CBX_ACT_NONE);
+        return rc ? rc : ln(y, y, lnw, lnb, M, 1e-5f, (float)sqrt(512.0));
+    }
+    int conformer(const cbx_conformer_t& L, float* x, long T, const float* pe, const int* lens) const {
+        const long M = (long)d->B * T;
+        int rc;
+        if ((rc = ln(x, d->h, L.ln_mha_w, L.ln_mha_b, M, 1e-12f, 1.0f))) return rc;
+        if ((rc = linear(d->h, L.w4, d->q4, L.b4, nullptr, M, 2048, 512, CBX_ACT_NONE))) return rc;
+        if ((rc = linear(pe, L.wpos, d->pp, nullptr, nullptr, 2 * T - 1, 512, 512, CBX_ACT_NONE))) return rc;
+        if ((rc = cbx_flash_relpos_f32(d->q4, d->q4 + 512, d->q4 + 1024, d->q4 + 1536, d->pp, d->att, lens, d->B, 8, (int)T, T * 2048, 2048, 512, T * 512, 512,
+                                       0.125f, stream)))
+            return rc;
+        if ((rc = linear(d->att, L.wo, x, L.bo, x, M, 512, 512, CBX_ACT_NONE))) return rc;
+        if ((rc = ln(x, d->h, L.ln_ff_w, L.ln_ff_b, M, 1e-12f, 1.0f))) return rc;
+        if ((rc = linear(d->h, L.w1, d->ff, L.b1, nullptr, M, 2048, 512, CBX_ACT_SILU))) return rc;
+        return linear(d->ff, L.w2, x, L.b2, x, M, 512, 2048, CBX_ACT_NONE);
+    }
+};
+
+}  // namespace
+
+extern "C" int cbx_s3gen_encode(const cbx_s3enc_t* d, void* stream) {
+    CBX_REQUIRE(d && d->ids && d->lens && d->lens2 && d->emb && d->pe && d->pe2 && d->mu && d->x0 && d->xa && d->y1 && d->x2 && d->xu && d->xb && d->h && d->q4 &&
+                    d->pp && d->att && d->ff && (d->enc || !d->n_enc) && (d->up_enc || !d->n_up),
+                "s3gen_encode: null descriptor field");
+    CBX_REQUIRE(d->B >= 1 && d->N >= 1 && d->n_enc >= 0 && d->n_up >= 0, "s3gen_encode: bad shape");
+    EncCtx c{d, stream};
+    const long N = d->N, T2 = 2 * N, MN = (long)d->B * N, M2 = (long)d->B * T2;
+    int rc;
+    if ((rc = cbx_embed_f32(d->ids, d->emb, nullptr, nullptr, d->x0, MN, 512, 512, 1.0f, 1, stream))) return rc;
+    if ((rc = c.embed(d->x0, d->xa, d->e_w, d->e_b, d->e_lnw, d->e_lnb, MN))) return rc;
+    // PreLookaheadLayer (upsample_encoder.py:81-96): right-pad 3 conv k4 -> leaky_relu -> left-pad 2 conv k3 -> + x
+    if ((rc = c.conv(d->xa, d->pl1_w, d->y1, d->pl1_b, nullptr, d->lens, N, N, 4, 0, 1, CBX_ACT_LRELU, 0.01f))) return rc;
+    if ((rc = c.conv(d->y1, d->pl2_w, d->x2, d->pl2_b, d->xa, nullptr, N, N, 3, 2, 1, CBX_ACT_NONE, 0.0f))) return rc;
+    for (int i = 0; i < d->n_enc; ++i)
+        if ((rc = c.conformer(d->enc[i], d->x2, N, d->pe, d->lens))) return rc;
+    // Upsample1D (upsample_encoder.py:59-63): nearest x2, left-pad 4, conv k5 -- fused in the A-operand address map
+    if ((rc = c.conv(d->x2, d->up_w, d->xu, d->up_b, nullptr, nullptr, N, T2, 5, 4, 2, CBX_ACT_NONE, 0.0f))) return rc;
+    if ((rc = c.embed(d->xu, d->xb, d->u_w, d->u_b, d->u_lnw, d->u_lnb, M2))) return rc;
+    for (int i = 0; i < d->n_up; ++i)
+        if ((rc = c.conformer(d->up_enc[i], d->xb, T2, d->pe2, d->lens2))) return rc;
+    if ((rc = c.ln(d->xb, d->xb, d->after_w, d->after_b, M2, 1e-5f, 1.0f))) return rc;
+    cbx_gemm_t g{};  // encoder_proj (flow.py:168-169)
+    g.A = d->xb, g.W = d->proj_w, g.C = d->mu, g.bias = d->proj_b;
+    g.M = (int)M2, g.N = 80, g.K = 512, g.Cin = 512, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1, g.alpha = 1.0f;
+    g.lda = 512, g.ldw = 512, g.ldc = 80, g.precision = d->precision;
+    return cbx_gemm_f32(&g, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ HiFT F0 predictor + source
+extern "C" int cbx_hift_f0_source(const cbx_hift_f0_t* d, void* stream) {
+    CBX_REQUIRE(d && d->mel && d->cls_w && d->cls_b && d->src_w && d->phase && d->noise && d->buf0 && d->buf1 && d->f0 && d->s && d->cum,
+                "hift_f0_source: null descriptor field");
+    CBX_REQUIRE(d->B >= 1 && d->T >= 1, "hift_f0_source: bad shape");
+    const long T = d->T;
+    const float* x = d->mel;
+    int cin = 80, rc;
+    float* bufs[2] = {d->buf0, d->buf1};
+    for (int n = 0; n < 5; ++n) {
+        CBX_REQUIRE(d->f0_w[n] && d->f0_b[n], "hift_f0_source: null condnet weight %d", n);
+        cbx_gemm_t g{};
+        g.A = x, g.W = d->f0_w[n], g.C = bufs[n & 1], g.bias = d->f0_b[n], g.lens = d->lens;
+        g.M = (int)T, g.N = 512, g.K = 3 * cin, g.Cin = cin, g.taps = 3, g.dil = 1, g.stride = 1, g.pad_left = 1, g.up = 1, g.Tin = (int)T, g.nz1 = d->B, g.nz2 = 1;
+        g.act1 = CBX_ACT_ELU, g.alpha = 1.0f, g.lda = cin, g.a_s1 = T * cin, g.ldw = 3L * cin, g.ldc = 512, g.c_s1 = T * 512, g.precision = 1;
+        if ((rc = cbx_gemm_f32(&g, stream))) return rc;
+        x = bufs[n & 1], cin = 512;
+    }
+    cbx_gemm_t g{};  // classifier + abs
+    g.A = x, g.W = d->cls_w, g.C = d->f0, g.bias = d->cls_b;
+    g.M = (int)(d->B * T), g.N = 1, g.K = 512, g.Cin = 512, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1;
+    g.act1 = CBX_ACT_ABS, g.alpha = 1.0f, g.lda = 512, g.ldw = 512, g.ldc = 1, g.precision = 1;
+    if ((rc = cbx_gemm_f32(&g, stream))) return rc;
+    return cbx_hift_source_f32(d->f0, d->phase, d->noise, d->src_w, d->src_b, d->s, d->cum, d->B, (int)T, 480, 24000.0f, stream);
+}

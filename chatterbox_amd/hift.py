@@ -144,6 +144,24 @@ class HiFTEngine:
         check(lib.cbx_hift_decode(ctypes.byref(d), ops._stream()), "cbx_hift_decode")
         return wav
 
+    def _f0_source_c(self, mel, phase, noise, lens):
+        """f0_predict + source as ONE call of cbx_hift_f0_source (ABI v12): the same launches with the same arguments."""
+        import ctypes
+
+        from ._lib import HiftF0, check, lib
+        p, dev, (B, T, _) = ops._p, self.dev, mel.shape
+        f = lambda *sh: torch.empty(*sh, device=dev)
+        d = HiftF0()
+        for n, (w, bias, _cin) in enumerate(self.f0):
+            d.f0_w[n], d.f0_b[n] = p(w), p(bias)
+        keep = (f(B, T, 512), f(B, T, 512), f(B * T, 1), torch.empty(B, 9, T, dtype=torch.float64, device=dev), phase.reshape(B, 9).contiguous(),
+                noise.contiguous())
+        s = f(B, 480 * T)
+        d.B, d.T, d.mel, d.lens, d.cls_w, d.cls_b, d.src_w, d.src_b = B, T, p(mel), p(lens), p(self.f0_cls[0]), p(self.f0_cls[1]), p(self.src_w), self.src_b
+        d.buf0, d.buf1, d.f0, d.cum, d.phase, d.noise, d.s = p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]), p(keep[4]), p(keep[5]), p(s)
+        check(lib.cbx_hift_f0_source(ctypes.byref(d), ops._stream()), "cbx_hift_f0_source")
+        return s
+
     @ops.on_device
     @torch.inference_mode()
     def decode(self, mel, s, lens=None, fade=True):
@@ -207,9 +225,12 @@ class HiFTEngine:
             phase[:, 0] = 0
         if noise is None:
             noise = torch.randn(B, 9, 480 * T, device=self.dev)
-        with ops.gemm_precision(1):
-            f0 = self.f0_predict(mel, lens)
-        s = self.source(f0, phase.to(self.dev).float(), noise.to(self.dev).float())
+        if self.c_seam and not ops.TIMER and mel.is_contiguous() and mel.dtype == torch.float32:
+            s = self._f0_source_c(mel, phase.to(self.dev).float(), noise.to(self.dev).float(), lens)
+        else:
+            with ops.gemm_precision(1):
+                f0 = self.f0_predict(mel, lens)
+            s = self.source(f0, phase.to(self.dev).float(), noise.to(self.dev).float())
         if cache_source is not None and cache_source.shape[1]:
             s[:, : cache_source.shape[1]] = cache_source.to(self.dev)
         with ops.gemm_precision(self.precision):

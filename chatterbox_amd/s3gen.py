@@ -119,10 +119,11 @@ class FlowEngine:
         self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None
-        # the Euler loop through the stage-level C entry point cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python
-        # sequencing below -- bit-identical results; plane-format path only).  Opt-in until a whole-suite hardware run has used it.
+        # the token encoder (flash rel-pos form) and the Euler loop (plane-format path) through the stage-level C entry points cbx_s3gen_encode /
+        # cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python sequencing below -- bit-identical results).  Opt-in until a
+        # whole-suite hardware run has used them.
         self.c_seam = os.environ.get("CBX_FLOW_CSEAM", "0") == "1"
-        self._cfm_static = None
+        self._cfm_static = self._enc_static = None
 
     # ------------------------------------------------------------------ conformer encoder
     def _rel_pos_table(self, T, dev=None, dm=512):
@@ -185,11 +186,50 @@ class FlowEngine:
             return self._encode_rows(tok, lens)
         return torch.cat([self._encode_rows(tok[i:i + group], lens[i:i + group]) for i in range(0, B, group)], 0)
 
+    def _encode_c(self, ids, lens, B, N):
+        """_encode_rows (flash form) as ONE call of cbx_s3gen_encode (ABI v12): the same launches with the same arguments."""
+        import ctypes
+
+        from ._lib import Conformer, S3Encode, check, lib
+        p, dev, T2 = ops._p, self.dev, 2 * N
+        if self._enc_static is None:
+            def layers(ls):
+                arr = (Conformer * max(1, len(ls)))()
+                for a, lw in zip(arr, ls):
+                    a.ln_mha_w, a.ln_mha_b, a.ln_ff_w, a.ln_ff_b = p(lw["ln_mha"][0]), p(lw["ln_mha"][1]), p(lw["ln_ff"][0]), p(lw["ln_ff"][1])
+                    for k in ("w4", "b4", "wpos", "wo", "bo", "w1", "b1", "w2", "b2"):
+                        setattr(a, k, p(lw[k]))
+                return arr
+            d = S3Encode()
+            d.n_enc, d.n_up, d.enc, d.up_enc = len(self.enc), len(self.up_enc), layers(self.enc), layers(self.up_enc)
+            d.emb, d.after_w, d.after_b, d.proj_w, d.proj_b = p(self.emb), p(self.after_norm[0]), p(self.after_norm[1]), p(self.proj_w), p(self.proj_b)
+            d.e_w, d.e_b, d.e_lnw, d.e_lnb = (p(self.embed[k]) for k in ("w", "b", "lnw", "lnb"))
+            d.u_w, d.u_b, d.u_lnw, d.u_lnb = (p(self.up_embed[k]) for k in ("w", "b", "lnw", "lnb"))
+            d.pl1_w, d.pl1_b, d.pl2_w, d.pl2_b, d.up_w, d.up_b = p(self.pl1[0]), p(self.pl1[1]), p(self.pl2[0]), p(self.pl2[1]), p(self.up_conv[0]), p(self.up_conv[1])
+            self._enc_static = (d, d.enc, d.up_enc)
+        d = S3Encode()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(self._enc_static[0]), ctypes.sizeof(S3Encode))
+        f = lambda *s: torch.empty(*s, device=dev)
+        pe, pe2, lens2 = self._rel_pos_table(N, dev), self._rel_pos_table(T2, dev), (lens * 2).to(torch.int32)
+        ws = dict(x0=f(B * N, 512), xa=f(B * N, 512), y1=f(B * N, 512), x2=f(B * N, 512), xu=f(B * T2, 512), xb=f(B * T2, 512), h=f(B * T2, 512),
+                  q4=f(B * T2, 2048), pp=f(2 * T2, 512), att=f(B * T2, 512), ff=f(B * T2, 2048))
+        mu = f(B, T2, 80)
+        d.B, d.N, d.precision = B, N, ops.GEMM_PRECISION
+        d.ids, d.lens, d.lens2, d.pe, d.pe2, d.mu = p(ids), p(lens), p(lens2), p(pe), p(pe2), p(mu)
+        for k, t in ws.items():
+            setattr(d, k, p(t))
+        check(lib.cbx_s3gen_encode(ctypes.byref(d), ops._stream()), "cbx_s3gen_encode")
+        return mu
+
     @ops.on_device
     def _encode_rows(self, tok, lens, flash=False):
         dev, (B, N) = self.dev, tok.shape
         T2 = 2 * N
         f = lambda *s: torch.empty(*s, device=dev)
+        if flash and self.c_seam and not ops.TIMER and lens.dtype == torch.int32 and lens.is_contiguous():
+            ids = tok.reshape(-1).clone()
+            ids[(torch.arange(N, device=dev)[None, :] >= lens[:, None]).reshape(-1)] = -1
+            return self._encode_c(ids, lens, B, N)
         Tp, Pp = (T2 + 3) // 4 * 4, (2 * T2 - 1 + 3) // 4 * 4
         ws = dict(h=f(B * T2, 512), q4=f(B * T2, 2048), pp=f(2 * T2, 512), att=f(B * T2, 512), ff=f(B * T2, 2048), Tp=Tp, Pp=Pp)
         if flash:

@@ -26,7 +26,7 @@ extern "C" {
                               11: cbx_gemv_t.col_tiles / ssq_out (column-tile / split-K form of the RMSNorm-folded decode GEMV), cbx_decode_attn_t.qkv_nparts /
                                   qkv_part_stride / qkv_ssq / rms_dim / rms_eps (the attention adds the q/k/v partial sums and applies rstd),
                                   cbx_t3_step_t.qkv_ksplit / qkv_ct / head_ct / qkv_ssq, cbx_t3_prefill;
-                              12: stage-level seams of the flow decoder and the vocoder: cbx_planes_t, cbx_cfm_solve, cbx_hift_decode */
+                              12: stage-level seams of the flow and the vocoder: cbx_planes_t, cbx_s3gen_encode, cbx_cfm_solve, cbx_hift_f0_source, cbx_hift_decode */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -498,6 +498,45 @@ typedef struct cbx_cfm_t {
     cbx_planes_t vtP;                     /* V^T: (rows * 512) rows x (T rounded up to 8) columns, the padding zero */
 } cbx_cfm_t;
 int cbx_cfm_solve(const cbx_cfm_t* d, void* stream);
+
+/* ConformerEncoderLayer of the S3Gen token encoder (transformer/encoder_layer.py:160-236 with RelPositionMultiHeadedAttention, attention.py:249-330):
+ * w4 / b4 = the fused projection [q + pos_bias_u | q + pos_bias_v | k | v] (2048, 512); wpos = linear_pos (512, 512, no bias). */
+typedef struct cbx_conformer_t {
+    const float *ln_mha_w, *ln_mha_b, *w4, *b4, *wpos, *wo, *bo, *ln_ff_w, *ln_ff_b, *w1, *b1, *w2, *b2;
+} cbx_conformer_t;
+/* UpsampleConformerEncoder.forward + encoder_proj (transformer/upsample_encoder.py:237-304, flow.py:161-169) for B rows of N tokens: input_embedding
+ * gather (ids < 0 = padded position: zero vector), embed (Linear + LayerNorm * sqrt(512)), PreLookaheadLayer, n_enc conformer layers, Upsample1D (nearest x2
+ * + conv k5, fused in the conv's address map), up_embed, n_up conformer layers over 2 N positions, after_norm, encoder_proj -> mu (B, 2 N, 80).  The rel-pos
+ * attention runs in its flash form (cbx_flash_relpos_f32).  pe / pe2: EspnetRelPositionalEncoding tables of N resp. 2 N positions ((2 T - 1) x 512, row r <->
+ * relative position T - 1 - r), constants of the length.  precision: cbx_gemm_t.precision of every Linear / conv.  Workspaces: x0, xa, y1, x2 (B N x 512);
+ * xu, xb, h, att (B 2N x 512); q4, ff (B 2N x 2048); pp (4 N x 512).  Same contract as cbx_cfm_solve. */
+typedef struct cbx_s3enc_t {
+    int B, N, n_enc, n_up, precision;
+    const long long* ids;                 /* [B * N] */
+    const int *lens, *lens2;              /* [B]: valid tokens per row, twice that */
+    const float *emb, *e_w, *e_b, *e_lnw, *e_lnb, *u_w, *u_b, *u_lnw, *u_lnb, *pl1_w, *pl1_b, *pl2_w, *pl2_b, *up_w, *up_b, *after_w, *after_b, *proj_w, *proj_b;
+    const cbx_conformer_t *enc, *up_enc;  /* HOST arrays [n_enc], [n_up] */
+    const float *pe, *pe2;
+    float *x0, *xa, *y1, *x2, *xu, *xb, *h, *q4, *pp, *att, *ff;
+    float* mu;
+} cbx_s3enc_t;
+int cbx_s3gen_encode(const cbx_s3enc_t* d, void* stream);
+
+/* The front half of HiFTGenerator.inference (hifigan.py:462-469): ConvRNNF0Predictor (f0_predictor.py:52-55: 5 x Conv1d k3 + ELU, Linear, abs; always exact
+ * fp32 -- its output is integrated into a phase over ~10^5 samples) -> f0 (B, T), then f0_upsamp + SourceModuleHnNSF (hifigan.py:201-231, 267-283) with the
+ * caller's initial phases (B, 9) and noise (B, 9, 480 T) -> s (B, 480 T).  buf0 / buf1: (B, T, 512) workspaces; cum: (B, 9, T) doubles.  lens: NULL or [B]. */
+typedef struct cbx_hift_f0_t {
+    int B;
+    long T;
+    const float* mel;                     /* (B, T, 80) */
+    const int* lens;
+    const float *f0_w[5], *f0_b[5], *cls_w, *cls_b, *src_w;
+    float src_b;
+    const float *phase, *noise;
+    float *buf0, *buf1, *f0, *s;
+    double* cum;
+} cbx_hift_f0_t;
+int cbx_hift_f0_source(const cbx_hift_f0_t* d, void* stream);
 
 /* ResBlock of HiFT (hifigan.py:118-161): three (Snake, dilated conv, Snake, conv, + x) rounds; conv weights tap-major (C, k * C), weight_norm folded */
 typedef struct cbx_hift_resblock_t {

@@ -37,7 +37,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
                "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill,
                "cbx_planes_t": _lib.PlanesRef, "cbx_cfm_tblock_t": _lib.CfmTBlock, "cbx_cfm_stage_t": _lib.CfmStage, "cbx_cfm_t": _lib.CfmSolve,
-               "cbx_hift_resblock_t": _lib.HiftResblock, "cbx_hift_t": _lib.HiftDecode}
+               "cbx_hift_resblock_t": _lib.HiftResblock, "cbx_hift_t": _lib.HiftDecode,
+               "cbx_conformer_t": _lib.Conformer, "cbx_s3enc_t": _lib.S3Encode, "cbx_hift_f0_t": _lib.HiftF0}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -495,10 +496,11 @@ def test_green_allow_list_is_canonical_and_contains_the_default_geometry():
 
 
 def test_stage_seams_reject_an_empty_descriptor():
-    """cbx_cfm_solve / cbx_hift_decode (ABI v12) validate their descriptor before the first launch (no GPU needed to see that)."""
+    """The stage-level entry points of ABI v12 validate their descriptor before the first launch (no GPU needed to see that)."""
     import ctypes
     from chatterbox_amd import _lib
-    for fn, cls in ((_lib.lib.cbx_cfm_solve, _lib.CfmSolve), (_lib.lib.cbx_hift_decode, _lib.HiftDecode)):
+    for fn, cls in ((_lib.lib.cbx_cfm_solve, _lib.CfmSolve), (_lib.lib.cbx_hift_decode, _lib.HiftDecode), (_lib.lib.cbx_s3gen_encode, _lib.S3Encode),
+                    (_lib.lib.cbx_hift_f0_source, _lib.HiftF0)):
         assert fn(ctypes.byref(cls()), None) == -22 and b"null descriptor" in _lib.lib.cbx_last_error()
 
 

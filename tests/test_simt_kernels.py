@@ -631,39 +631,14 @@ def test_hift_decode_c_entry_point_on_the_emulator(emu, ragged, fade, precision)
 def test_s3gen_encode_c_entry_point_on_the_emulator(emu):
     """cbx_s3gen_encode (ABI v12) against FlowEngine._encode_rows' own launch sequence (flash rel-pos form), bit for bit: a ragged batch of 2 x 10 tokens, one
     conformer layer before and one after the upsampling (20 rows take the skinny GEMM, the 40 upsampled rows the split-operand kernel)."""
-    from chatterbox_amd import ops, synth
-    from chatterbox_amd.s3gen import FlowEngine
-    eng = FlowEngine(synth.s3gen_state_dict(0, n_mid=1, n_enc=1, n_up_enc=1), CPU)
-    tok = synth.speech_tokens(20, seed=3).view(2, 10)
-    lens = torch.tensor([10, 7], dtype=torch.int32)
-    out, calls, inner = {}, [], eng._encode_c
-    eng._encode_c = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
-    for seam in (False, True):
-        eng.c_seam = seam
-        with ops.gemm_precision(16), torch.inference_mode():
-            out[seam] = eng.encode(tok, lens).clone()
-    assert len(calls) == 1 and torch.isfinite(out[True]).all() and out[True].abs().max() > 0
-    assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
+    import test_zzz_stage_seams_gpu as S
+    S.test_s3gen_encode_through_the_c_entry_point_equals_the_python_sequence(CPU, B=2, N=10, n_enc=1, n_up=1)
 
 
 def test_hift_f0_source_c_entry_point_on_the_emulator(emu):
     """cbx_hift_f0_source (ABI v12) against HiFTEngine.f0_predict + source, bit for bit (the source signal of a ragged batch of 2 x 4 mel frames)."""
-    from chatterbox_amd import synth
-    from chatterbox_amd.hift import HiFTEngine
-    eng = HiFTEngine(synth.s3gen_state_dict(0), CPU)
-    B, T = 2, 4
-    mel = (synth.randn((B, T, 80), seed=9) * 1.5 - 4.0)
-    phase, noise = synth.rand((B, 9), seed=5) * 6.28 - 3.14, synth.randn((B, 9, 480 * T), seed=6)
-    phase[:, 0] = 0
-    lens = torch.tensor([4, 2], dtype=torch.int32)
-    eng.decode = lambda mel, s, lens=None, fade=True: s.clone()  # the front half only: inference() hands the source to decode()
-    out, calls, inner = {}, [], eng._f0_source_c
-    eng._f0_source_c = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
-    for seam in (False, True):
-        eng.c_seam = seam
-        out[seam] = eng.inference(mel, phase=phase, noise=noise, lens=lens)[1].clone()
-    assert len(calls) == 1 and torch.isfinite(out[True]).all() and out[True].abs().max() > 0
-    assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
+    import test_zzz_stage_seams_gpu as S
+    S.test_hift_f0_source_through_the_c_entry_point_equals_the_python_sequence(CPU, B=2, T=4)
 
 
 @_SLOW

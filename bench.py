@@ -17,6 +17,7 @@ INSIDE the timed region; `cpu_baseline` is the reference itself (kind "reference
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -36,12 +37,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 8; vc60: 1)")
     ap.add_argument("--tokens", type=int, default=250, help="speech tokens per utterance (25/s)")
     ap.add_argument("--text-tokens", type=int, default=64)
     ap.add_argument("--t3-layers", type=int, default=30)
-    ap.add_argument("--workload", default="mtl", choices=["mtl", "turbo", "nano"],
-                    help="mtl = configs[2] (the headline metric); turbo / nano = configs[1] / configs[0] architectures (GPT-2 T3, 2-step meanflow)")
+    ap.add_argument("--workload", default="mtl", choices=["mtl", "turbo", "nano", "vc60"],
+                    help="mtl = configs[2] (the headline metric); turbo / nano = configs[1] / configs[0] architectures (GPT-2 T3, 2-step meanflow); "
+                         "vc60 = configs[4]: voice conversion of 60 s utterances (S3 tokenizer -> S3Gen at T = 3500 mel frames -> HiFT; no T3), "
+                         "--batch utterances per step (default there: 1)")
+    ap.add_argument("--vc-seconds", type=float, default=60.0, help="vc60: length of the source utterance")
     ap.add_argument("--pipelined", action="store_true",
                     help="throughput mode: T3 of batch k+1 overlaps the CFM/vocoder of batch k on a second HIP stream (same work, "
                          "same results, ~+10%% audio-s/s but ~2x per-batch latency).  Default: the K steps run strictly one after the other")
@@ -76,7 +80,10 @@ def parse():
                     help="launcher / collective self-test WITHOUT kernels (gloo, host tensors): the N ranks rendezvous, C1 (broadcast of the "
                          "Conditionals) and C2 (gather of waveforms) fire on synthetic payloads of the benched shapes, rank 0 prints the JSON "
                          "line with value = null.  Used by tests/test_bench_launcher.py on the CPU; it measures nothing")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1 if args.workload == "vc60" else 8
+    return args
 
 
 def _free_port():
@@ -417,6 +424,97 @@ def _on_green(t3):
     return at.canon(t3.tune, t3.knobs) in at.green_variants()
 
 
+
+def vc60_main(args, dev, rank, world):
+    """configs[4] (BASELINE.json): the voice-conversion path of example_vc.py / vc.py:83-104 on long-form audio -- S3 tokenizer on the 16 kHz source,
+    S3Gen (encoder + 10-step CFG CFM) with the target voice's 10 s prompt, HiFT -- `--batch` utterances of `--vc-seconds` per step in ONE device
+    batch.  60 s = 1500 speech tokens + the 250-token prompt = T 3500 mel frames per CFM row (2 rows per utterance with CFG): attention is
+    3.5x heavier per frame than in the headline config.  No T3 on this path.  Prints its own JSON line (NOT the headline metric's config)."""
+    import torch.distributed as dist
+    from chatterbox_amd import dist as cdist, ops, synth
+    from chatterbox_amd.api import ChatterboxVC
+    B = args.batch
+    t_build = time.perf_counter()
+    vc = ChatterboxVC.from_synthetic(dev, seed=0)
+    eng, tok, ref = vc.engine, vc.analyzer.tokenizer, vc.ref_dict
+    if args.s3gen_precision is not None:
+        eng.flow.precision = eng.hift.precision = args.s3gen_precision
+    build_s = time.perf_counter() - t_build
+    L16 = int(args.vc_seconds * 16000)
+    g = torch.Generator().manual_seed(31 + rank)
+    # synthetic "speech": band-limited noise with a syllable-rate envelope (the tokenizer's arithmetic does not depend on the content)
+    t = torch.arange(L16) / 16000.0
+    src = [(0.1 * torch.randn(L16, generator=g) * (0.6 + 0.4 * torch.sin(2 * math.pi * (3.0 + b) * t))).float() for b in range(B)]
+    gd = torch.Generator(device=dev).manual_seed(77 + rank)
+
+    def one_step():
+        t0 = time.perf_counter()
+        toks = [tok(w)[0].view(-1).long().cpu() for w in src]  # S3 tokenizer per utterance (25 tokens / s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        T = 2 * (int(ref["prompt_token"].shape[1]) + max(int(x.numel()) for x in toks))
+        z = torch.randn(len(toks), T, 80, generator=gd, device=dev)
+        wavs, _ = eng.vocode(toks, ref, z=z)
+        host = [w.cpu() for w in wavs]
+        t2 = time.perf_counter()
+        tm = dict(tokenizer_s=t1 - t0, **eng.last_timing)
+        cdist.gather_waveforms(wavs, dst=0)
+        return sum(w.numel() for w in host) / 24000.0, t2 - t0, tm, T
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    audio, lats, stage, T = 0.0, [], {}, 0
+    for _ in range(args.steps):
+        a, lat, tm, T = one_step()
+        audio += a
+        lats.append(lat)
+        for k, v in tm.items():
+            stage[k] = stage.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([elapsed, audio], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx, sm = stats.clone(), stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, audio = float(mx[0]), float(sm[1])
+    timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32", "gemm_planes", "flash_attn_planes"])
+    ops.TIMER = timer  # the instrumented extra step, outside the timed region (per-kernel HIP events; the Python launch sequencing)
+    one_step()
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    if rank != 0:
+        return
+    roofs = roofline_entries(timer.summary(), elapsed, args.steps, 1, eng.flow.precision, 0, None)
+    dom = max(roofs, key=lambda k: roofs[k]["share_of_step"]) if roofs else None
+    roof = roofs.pop(dom, None)
+    for e in [roof] + list(roofs.values()):
+        if e:  # the committed PMC passes are of the headline shape (T = 1000): not this workload's traffic
+            e["traffic"], e["traffic_source"] = None, "not collected at this shape (the committed PMC passes are of the headline workload)"
+    lats.sort()
+    print(json.dumps({
+        "metric": "audio-sec/wall-sec (xRT), voice conversion of long-form audio (configs[4]; NOT the headline metric's config)",
+        "value": round(audio / elapsed, 3), "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "stage_ms": {k[:-2]: round(1e3 * v / args.steps, 1) for k, v in stage.items()},
+        "dtype": "f32 (S3 tokenizer: exact fp32 MFMA; S3Gen: f16x3 planes = 22 significand bits per operand, fp32 accumulate)" if eng.flow.precision == 16
+                 else f"f32 (S3Gen precision mode {eng.flow.precision})",
+        "data": "synthetic (seeded random-init weights in the reference checkpoint layout; synthetic 16 kHz source audio, synthetic 10 s target-voice prompt)",
+        "p50_latency_ms": round(1e3 * lats[len(lats) // 2], 1),
+        "config": {"workload": (f"configs[4]: voice conversion (example_vc.py): S3 tokenizer -> S3Gen 10-step CFG CFM -> HiFT, {args.vc_seconds:.0f} s utterances "
+                                f"({T // 2 - int(ref['prompt_token'].shape[1])} tokens + {int(ref['prompt_token'].shape[1])}-token prompt: T = {T} mel frames per CFM row), "
+                                f"batch {B}/GPU in one device batch"),
+                   "global_batch": B * world, "parallelism": f"dp{world}", "model_build_s": round(build_s, 1),
+                   "stage_seams": {"flow": bool(eng.flow.c_seam), "hift": bool(eng.hift.c_seam)}},
+        "roofline": roof, "roofline_secondary": list(roofs.values())}), flush=True)
+
+
 def log(msg):
     if os.environ.get("CBX_BENCH_VERBOSE"):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -455,6 +553,12 @@ def main():
     from chatterbox_amd import dist as cdist, ops, synth
     from chatterbox_amd.engine import ChatterboxEngine, TurboEngine
 
+    if args.workload == "vc60":
+        vc60_main(args, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     t_build = time.perf_counter()
     turbo = args.workload != "mtl"
     if turbo:
@@ -517,12 +621,13 @@ def main():
     for i in range(args.warmup):
         one_step(-1 - i)
     pipelined = args.pipelined and not args.serial and not turbo
-    # HIP-event timing of every GEMM / attention launch costs ~25 ms per step (4000 event records): it is switched on for the
-    # LAST timed step only (all steps in --pipelined mode), so the headline number carries 1/K of that overhead
+    # HIP-event timing of every GEMM / attention launch costs ~25 ms per step (4000 event records) and sends the flow / vocoder through their
+    # per-kernel Python sequencing: it runs in ONE EXTRA step AFTER the timed region (round 5; rounds 1-4 instrumented the last timed step), so the
+    # headline number carries none of it.  The decode-step roofline stays in-run: two HIP events per generate() call around the graph replays.
     timer = ops.KernelTimer(["gemm_f32", "gemm_split", "flash_attn_f32", "gemm_planes", "flash_attn_planes"])
     eng.t3.time_decode, eng.t3.decode_events = True, []
-    timed_steps = args.steps if pipelined else 1
-    ops.TIMER = timer if pipelined else None
+    timed_steps = 1
+    ops.TIMER = None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -536,8 +641,6 @@ def main():
             cdist.gather_waveforms(host, dst=0)  # C2
     else:
         for i in range(args.steps):
-            if i == args.steps - 1:
-                ops.TIMER = timer
             a, lat, tm = one_step(i)
             audio += a
             lats.append(lat)
@@ -547,6 +650,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    eng.t3.time_decode = False
+    ops.TIMER = timer  # the instrumented step (every rank: one_step contains the C2 collective)
+    one_step(args.steps)
+    torch.cuda.synchronize()
     ops.TIMER = None
 
     stats = torch.tensor([elapsed, audio], dtype=torch.float64, device=dev)
@@ -560,7 +667,6 @@ def main():
     # ---- outside the timed region: (a) eager replay of the decode step for the gemv roofline, (b) one step at each of the other
     # S3Gen precisions so that the exact-fp32 figure is reported by the same run
     alt, gemv, dstep, cfg3, stream = {}, None, None, None, None
-    eng.t3.time_decode = False
     run_cfg3 = (args.config3 or world == 8) and not turbo
     if run_cfg3:  # configs[3]: 256 utterances, contiguous shards (dist.shard_range), 32 per GPU at 8 GPUs; every rank takes part
         lo, hi = cdist.shard_range(256, rank, world)
@@ -680,6 +786,8 @@ def main():
             "metric": "audio-sec/wall-sec (xRT) + p50 first-audio latency, Multilingual-V3 500M",
             "value": round(audio / elapsed, 3), "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # T3 / flow / HiFT wall ms per step (host clocks around each stage of the serial schedule; the same numbers as config.stage_ms_per_step)
+            "stage_ms": {k[:-2]: round(1e3 * v / args.steps, 1) for k, v in stage.items()},
             "dtype": "f32" if s3_prec == 1 else
                      ("f32 (T3: exact fp32 MFMA; S3Gen: every fp32 operand = 2 fp16 planes h + l/2048 = 22 significand bits, 3 fp16 MFMA products "
                       "per fp32 product in two fp32 accumulators: error at or below the exact-fp32 MFMA path; operand range checked on the "

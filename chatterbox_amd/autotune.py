@@ -176,6 +176,7 @@ def tune_decode(eng, B=8, ctx=224, steps=24, reps=2, min_gain=0.01, allow_reorde
     if allow_reorder:
         best, best_ms = best_any, any_ms
     eng.apply_variant(base_tune, base_knobs)
+    eng.release_state(slot=7)  # the probe / measurement states (KV caches of 2B rows x 704 positions x L layers) must not stay pinned on a serving engine
     return dict(best=best, ms_per_token=round(best_ms, 5), best_any=best_any, ms_per_token_any=round(any_ms, 5), baseline_ms_per_token=round(ms0, 5),
                 B=B, ctx=ctx, steps=steps, layers=eng.L, graph=bool(use_graph), allow_reorder=bool(allow_reorder), green_only=bool(green_only),
                 probe_ctxs=list(probe_ctxs), candidates=rows)

@@ -27,8 +27,8 @@ extern "C" int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream) {
     CBX_REQUIRE(d->rows >= 1 && d->rows <= 16, "t3_decode_step: rows=%d (this entry point serves the packed <= 16-row path)", d->rows);
     CBX_REQUIRE(d->d_ksplit == 1 || d->d_ksplit == 2 || d->d_ksplit == 4, "t3_decode_step: d_ksplit must be 1, 2 or 4");
     const int qks = d->qkv_ksplit > 1 ? d->qkv_ksplit : 1;  // ABI v11: the q/k/v projection as split-K partial sums folded by the attention launch
-    CBX_REQUIRE(qks == 1 || (qks <= 4 && d->qkv_ct >= 1 && d->qkv_ct <= 4 && d->qkv_ssq && d->qkv_tile == 0 && !d->w_bf16),
-                "t3_decode_step: qkv_ksplit 2 .. 4 needs qkv_ct 1 .. 4, qkv_ssq, the 16-column fp32 q/k/v image");
+    CBX_REQUIRE(qks == 1 || ((qks == 2 || qks == 4) && d->dim % (256 * qks) == 0 && d->qkv_ct >= 1 && d->qkv_ct <= 4 && d->qkv_ssq && d->qkv_tile == 0 && !d->w_bf16),
+                "t3_decode_step: qkv_ksplit 2 or 4 (dim %% (256 qkv_ksplit) == 0) needs qkv_ct 1 .. 4, qkv_ssq, the 16-column fp32 q/k/v image");
     CBX_REQUIRE(d->head_ct >= 0 && d->head_ct <= 4 && !(d->head_ct && d->w_bf16), "t3_decode_step: head_ct in 0 .. 4 (fp32 images)");
     const int D = d->dim, F = d->ffn, H = d->n_heads;
     float* cur = d->x_a;
@@ -103,7 +103,7 @@ extern "C" int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream) {
         cbx_gemm_t g{};
         g.A = A, g.W = W, g.C = C, g.R = R;
         g.M = (int)M, g.N = N, g.K = K, g.Cin = K, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1, g.swiglu = swiglu;
-        g.alpha = 1.0f, g.lda = K, g.ldw = K, g.ldc = swiglu ? N / 2 : N, g.ldr = R ? D : 0, g.precision = swiglu ? 0 : d->precision;
+        g.alpha = 1.0f, g.lda = K, g.ldw = K, g.ldc = swiglu ? N / 2 : N, g.ldr = R ? D : 0, g.precision = d->precision;  // as the Python sequence passes it (the SwiGLU form is served by the exact kernel in every mode)
         return cbx_gemm_f32(&g, stream);
     };
     int rc = 0;

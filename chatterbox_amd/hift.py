@@ -61,9 +61,10 @@ class HiFTEngine:
         self.rb = [resblock(h + f"resblocks.{i}.") for i in range(9)]
         wpost = fw(h + "conv_post")  # (18, 64, 7) -> output columns padded to 32 for the iSTFT kernel's row stride
         self.conv_post = (d(weights.pack_conv(wpost)), d(sd[h + "conv_post.bias"]))
-        # decode() through the stage-level C entry point cbx_hift_decode (ABI v12; the same launches with the same arguments as the Python
-        # sequencing below -- bit-identical results).  Opt-in until a whole-suite hardware run has used it.
-        self.c_seam = os.environ.get("CBX_HIFT_CSEAM", "0") == "1"
+        # decode() and the F0 predictor + source through the stage-level C entry points cbx_hift_decode / cbx_hift_f0_source (ABI v12; the same
+        # launches with the same arguments as the Python sequencing below -- bit-identical results on the MI355X: tests/test_zzz_stage_seams_gpu.py).
+        # The default since round 5, so every vocoder golden passes through them; the identity tests flip this attribute.
+        self.c_seam = True
         self._c_static = None
 
     # ------------------------------------------------------------------ pieces

@@ -120,9 +120,10 @@ class FlowEngine:
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None
         # the token encoder (flash rel-pos form) and the Euler loop (plane-format path) through the stage-level C entry points cbx_s3gen_encode /
-        # cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python sequencing below -- bit-identical results).  Opt-in until a
-        # whole-suite hardware run has used them.
-        self.c_seam = os.environ.get("CBX_FLOW_CSEAM", "0") == "1"
+        # cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python sequencing below -- bit-identical results on the MI355X:
+        # tests/test_zzz_stage_seams_gpu.py).  The default since round 5, so every S3Gen golden passes through them; the Python sequencing stays as
+        # the per-kernel-timed path (ops.TIMER) and as the other side of the identity tests (which flip this attribute).
+        self.c_seam = True
         self._cfm_static = self._enc_static = None
 
     # ------------------------------------------------------------------ conformer encoder

@@ -415,14 +415,13 @@ class T3Engine:
         import ctypes
         from ._lib import T3Layer, T3Prefill, check, lib
         p = lambda t: t.data_ptr()
-        if not hasattr(self, "_prefill_layers"):
-            arr = (T3Layer * self.L)()
-            for i, lw in enumerate(self.layers):
-                arr[i].ln1, arr[i].ln2, arr[i].wqkv, arr[i].wo, arr[i].wgu, arr[i].wd = p(lw["ln1"]), p(lw["ln2"]), p(lw["wqkv"]), p(lw["wo"]), p(lw["wgu"]), p(lw["wd"])
-            self._prefill_layers = arr
+        # built per call (30 x 6 pointers): a cached array would outlive a re-packed / re-loaded weight tensor
+        arr = (T3Layer * self.L)()
+        for i, lw in enumerate(self.layers):
+            arr[i].ln1, arr[i].ln2, arr[i].wqkv, arr[i].wo, arr[i].wgu, arr[i].wd = p(lw["ln1"]), p(lw["ln2"]), p(lw["wqkv"]), p(lw["wo"]), p(lw["wgu"]), p(lw["wd"])
         d = T3Prefill()
         d.n_layers, d.rows, d.S, d.dim, d.ffn, d.n_heads, d.precision = self.L, rows, S, self.D, self.F, self.H, int(self.tune.get("prefill_prec") or 0)
-        d.eps, d.attn_scale, d.layers = 1e-5, 0.125, self._prefill_layers
+        d.eps, d.attn_scale, d.layers = 1e-5, 0.125, arr
         d.x, d.h, d.qkv, d.att, d.g = p(xf), p(ws["h"]), p(ws["qkv"]), p(ws["att"]), p(ws["g"])
         d.positions, d.cache_rows, d.cos_t, d.sin_t, d.kc, d.vc = p(pos), p(crow), p(self.cos), p(self.sin), p(st["kc"]), p(st["vc"])
         d.kv_layer_stride, d.kv_row_stride, d.kv_head_stride = st["kc"].stride(0), st["kc"].stride(1), st["kc"].stride(2)
@@ -549,6 +548,12 @@ class T3Engine:
                       positions=st["positions"], ctx_lens=st["ctx_lens"])
 
     # ------------------------------------------------------------------ state / workspaces
+    def release_state(self, slot):
+        """Drop every decode state (KV cache, workspaces, captured graph) of `slot`: measure_decode / probe_decode park theirs in slot 7
+        (≈ 2.6 GB at B = 8, L = 30), which a serving engine must get back after an in-process autotune."""
+        for k in [k for k in self._state if k[3] == slot]:
+            del self._state[k]
+
     def _get_state(self, B, max_ctx, max_steps, slot=0):
         key = (B, max_ctx, max_steps, slot)
         if key in self._state:

@@ -176,7 +176,9 @@ typedef struct cbx_gemv_t {
                             layout, reduced in fixed order on the way to the MFMA); needs norm_w, M <= 16, nw == 8 */
     const float* xpart;  /* [n_xpart] images, xpart_stride floats apart */
     long xpart_stride;
-    float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it) */
+    float* x_out;        /* or NULL: receives x + sum_j xpart[j] (packed; must not alias x: other workgroups still read it).  Since ABI v11 rows >= M of
+                          * a packed image (x_packed operands, xpart, x_out) are NEITHER READ NOR WRITTEN: lanes past M fetch row 0 and are zeroed before
+                          * the MFMA, x_out stores are guarded -- a host that reuses a buffer keeps whatever its pad rows held (the engines zero theirs) */
     int w_bf16;          /* W is a cbx_pack_gemv_weight_bf16 image (opt-in: weights rounded to bf16, half the streamed bytes; M <= 16) */
     int flags;           /* (was reserved1) ABI v10, CBX_GEMV_* bits below; 0 = the plain launch */
     const float* ln_cw;  /* or NULL: LayerNorm instead of RMSNorm (GPT-2 ln_1 / ln_2 / ln_f): with norm_w = LN weight w, ln_cw[n] = */
@@ -425,7 +427,7 @@ typedef struct cbx_t3_step_t {
      * launch, cbx_gemv_t.flags of every GEMV launch */
     int da_unroll, da_pipeline, da_split_min, gemv_flags;
     float* da_ws; int* da_cnt; long da_pairs;
-    /* ABI v11: qkv_ksplit > 1 (with qkv_ct = column tiles per workgroup, qkv_tile = 0): the q/k/v projection in the split-K column-tile form --
+    /* ABI v11: qkv_ksplit = 2 or 4 (dim % (256 qkv_ksplit) == 0; with qkv_ct = column tiles per workgroup, qkv_tile = 0): the q/k/v projection in the split-K column-tile form --
      * qkv then holds [qkv_ksplit][rows][3*dim] partial sums and qkv_ssq [qkv_ksplit][16] sums of squares, which the attention launch folds;
      * head_ct > 0: the speech head in the column-tile form (ksplit 1).  0 = the one-tile forms. */
     int qkv_ksplit, qkv_ct, head_ct;

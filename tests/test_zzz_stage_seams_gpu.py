@@ -3,15 +3,13 @@ kernel-level launches, with the same arguments, as `FlowEngine.cfm` / `HiFTEngin
 to the Python sequencing (which the golden / oracle tests of tests/test_models_gpu.py pin against the reference).  The bodies take the device as an
 argument: tests/test_simt_kernels.py runs them on the SIMT emulator at smaller shapes.  The file sorts after every other `-m gpu` file on purpose.
 """
-import os
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-# cbx_s3gen_encode / cbx_hift_f0_source were written after round 4's GPU minutes were spent: their bodies below have run on the SIMT emulator only
-# (tests/test_simt_kernels.py calls them with a CPU device).  CBX_TEST_PENDING_SEAMS=1 switches their hardware run on -- round 5's first GPU call.
-PENDING = pytest.mark.skipif(os.environ.get("CBX_TEST_PENDING_SEAMS") != "1", reason="first hardware run pending (CBX_TEST_PENDING_SEAMS=1)")
+# All four entry points are the engines' DEFAULT path since round 5 (first hardware run of cbx_s3gen_encode / cbx_hift_f0_source: round 5, call A,
+# profiles/r05_a_seams_first_hardware_run.log -- green), so every S3Gen / HiFT golden of tests/test_models_gpu.py passes through them as well.
 
 
 @pytest.mark.parametrize("meanflow,T,fused_qkv,fused_mlp", [(False, 152, True, False), (False, 150, True, False), (True, 152, True, False),
@@ -62,7 +60,6 @@ def test_hift_decode_through_the_c_entry_point_equals_the_python_sequence(dev, r
     assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
 
 
-@PENDING
 def test_s3gen_encode_through_the_c_entry_point_equals_the_python_sequence(dev, B=3, N=60, n_enc=2, n_up=2):
     """UpsampleConformerEncoder.forward + encoder_proj (flash rel-pos form): cbx_s3gen_encode against FlowEngine._encode_rows' own launch sequence, ragged batch."""
     from chatterbox_amd import ops, synth
@@ -81,7 +78,6 @@ def test_s3gen_encode_through_the_c_entry_point_equals_the_python_sequence(dev, 
     assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
 
 
-@PENDING
 def test_hift_f0_source_through_the_c_entry_point_equals_the_python_sequence(dev, B=3, T=20):
     """The front half of HiFTGenerator.inference (F0 predictor + source module): cbx_hift_f0_source against HiFTEngine.f0_predict + source, ragged batch."""
     from chatterbox_amd import synth

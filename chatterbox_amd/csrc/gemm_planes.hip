@@ -30,10 +30,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // waves per SIMD the register allocation must leave room for: as many workgroups per CU as the LDS admits (two co-resident workgroups
 // overlap one's epilogue with the other's K loop), at most 4 waves per SIMD (128 VGPRs)
-template <int BM, int BN, int BK, int NS, int NWV, bool LD>
+template <int BM, int BN, int BK, int NS, int NWV, int LD>
 struct PlOcc {
     static constexpr int occ = 160 * 1024 / (NS * 2 * (BM + BN) * (BK / 8) * 16);
-    static constexpr int w = LD ? (NWV + 1 + 3) / 4 : occ * NWV / 4;  // loader-wave form: one workgroup (NWV + 1 waves) per CU
+    static constexpr int w = LD ? (NWV + LD + 3) / 4 : occ * NWV / 4;  // loader-wave form: one workgroup (NWV + LD waves) per CU
     static constexpr int waves_per_simd = w > 4 ? 4 : w < 1 ? 1 : w;
 };
 
@@ -43,13 +43,17 @@ __device__ __forceinline__ void pl_dma16(const __amdgpu_buffer_rsrc_t rs, unsign
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
 }
 
-// LD = loader-wave form: the workgroup has one EXTRA wave that does nothing but issue the DMAs of every K tile and wait for them; the
+// LD > 0 = loader-wave form: the workgroup has LD EXTRA waves that do nothing but issue the DMAs of every K tile and wait for them; the
 // NWV consumer waves only read LDS, multiply and run the epilogue.  A vector-memory instruction costs its issuing wave 100-200 cycles while
 // the CU's address path is busy, and a wave issues in order: in the symmetric form every wave's MFMAs queue behind its own DMA issue
-// (measured: DMA time and MFMA time ADD, profiles/r03_planes_diag_switches.log); with a dedicated loader they overlap.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, bool LD>
+// (measured: DMA time and MFMA time ADD, profiles/r03_planes_diag_switches.log); with dedicated loaders they overlap.  ONE loader wave issues
+// a 1 KiB DMA per ~100 cycles -- MI355X_MICROARCH.md `ldsdma-fill`: ~25 GB/s per CU, 6.4 TB/s over the chip, which is the "operand stream at
+// ~8 TB/s in every tile form" of DESIGN section 6.0 -- while the MFMAs of a 128 x 128 x 64 K tile want 64 KiB per ~1500 cycles (~100 GB/s per
+// CU): round 5 adds LD = 2 and LD = 4 (one loader per SIMD), each loader wave issuing 1 / LD of a K tile's DMAs (for LD = 4 exactly one of
+// {A.h, W.h, A.l, W.l}).
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
 // (the parentheses keep the template commas away from the variadic __launch_bounds__ macro)
-__global__ __launch_bounds__((WARPS_M * WARPS_N + (LD ? 1 : 0)) * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N, LD>::waves_per_simd))
+__global__ __launch_bounds__((WARPS_M * WARPS_N + LD) * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N, LD>::waves_per_simd))
 void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int NWV = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -61,17 +65,17 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int STAGE_BYTES = STAGE_SLOTS * 16;
     constexpr int NLOAD = STAGE_SLOTS / 64;         // wave-level DMA instructions (1 KiB each) per stage
     static_assert((BM * CH) % 64 == 0 && (BN * CH) % 64 == 0, "a DMA instruction must not straddle the A / B boundary");
-    static_assert(LD || NLOAD % NWV == 0, "DMA instructions must divide evenly over the waves");
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && (CH == 4 || CH == 8), "tile shape");
-    constexpr int LPW = LD ? NLOAD : NLOAD / NWV;  // DMA instructions per K tile issued by one (loader) wave
+    static_assert(LD ? NLOAD % LD == 0 : NLOAD % NWV == 0, "DMA instructions must divide evenly over the (loader) waves");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (CH == 4 || CH == 8) && LD >= 0 && LD <= 4, "tile shape");
+    constexpr int LPW = LD ? NLOAD / LD : NLOAD / NWV;  // DMA instructions per K tile issued by one (loader) wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
-    const bool is_loader = LD && wid == NWV;
-    const int lbase = LD ? 0 : wid * LPW;  // first DMA instruction (of a stage) this wave issues
+    const bool is_loader = LD && wid >= NWV;
+    const int lbase = LD ? (is_loader ? wid - NWV : 0) * LPW : wid * LPW;  // first DMA instruction (of a stage) this wave issues
     // ---- persistent tile loop: workgroup b owns the virtual tiles b, b + gridDim.x, ...; the LOADER side (DMA issue) runs NS - 1 K tiles ahead
     //      of the CONSUMER side (MFMA + epilogue) straight across tile boundaries, so the first K tiles of the next output tile are in flight
     //      while this one's epilogue computes and stores, and no tile but a workgroup's first pays the load latency.  With gridDim.x = number
@@ -375,12 +379,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 int g_pl_persist = getenv("CBX_PL_PERSIST") ? atoi(getenv("CBX_PL_PERSIST")) : 1;
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, bool LD>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
 int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD>;
-    constexpr int THREADS = (WARPS_M * WARPS_N + (LD ? 1 : 0)) * 64;
+    constexpr int THREADS = (WARPS_M * WARPS_N + LD) * 64;
     static int resident_dev[64] = {0};  // per device ordinal (hipFuncSetAttribute and the CU count are per device): workgroups the chip holds at
     int& resident = resident_dev[cbx_device()];  // once (advisory: nothing in the kernel depends on co-residency)
     if (!resident) {
@@ -400,7 +404,7 @@ int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     return cbx_check_launch("gemm_planes");
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2, bool LD = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2, int LD = 0>
 int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
     if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF, LD>(p, st);
     if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU, LD>(p, st);
@@ -483,15 +487,23 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 18: return launch_pl<256, 128, 4, 2, 32, 3>(p, st);  // 8 waves 64x64, 3 stages, 144 KB
         case 19: return launch_pl<128, 256, 2, 4, 32, 3>(p, st);  // 8 waves 64x64, 3 stages, 144 KB
         // loader-wave forms (8 consumer waves + 1 loader wave, one workgroup per CU)
-        case 21: if (k64) return launch_pl<128, 128, 4, 2, 64, 2, true>(p, st); break;  // 128 KB
-        case 22: return launch_pl<128, 128, 2, 4, 32, 3, true>(p, st);   // 96 KB
-        case 23: return launch_pl<256, 128, 4, 2, 32, 3, true>(p, st);   // 144 KB, 64x64 per wave
-        case 24: return launch_pl<128, 128, 4, 2, 32, 2, true>(p, st);   // 64 KB
-        case 25: return launch_pl<128, 128, 2, 4, 32, 4, true>(p, st);   // 4 stages, 128 KB
+        case 21: if (k64) return launch_pl<128, 128, 4, 2, 64, 2, 1>(p, st); break;  // 128 KB
+        case 22: return launch_pl<128, 128, 2, 4, 32, 3, 1>(p, st);   // 96 KB
+        case 23: return launch_pl<256, 128, 4, 2, 32, 3, 1>(p, st);   // 144 KB, 64x64 per wave
+        case 24: return launch_pl<128, 128, 4, 2, 32, 2, 1>(p, st);   // 64 KB
+        case 25: return launch_pl<128, 128, 2, 4, 32, 4, 1>(p, st);   // 4 stages, 128 KB
         // 16-wave workgroups (1024 threads, one per CU, 4 waves per SIMD): 25 % less operand traffic per FLOP than 128 x 128 at the same 32 x 64 wave tile
         case 26: return launch_pl<256, 128, 8, 2, 32>(p, st);      // 96 KB
         case 27: return launch_pl<256, 128, 8, 2, 32, 3>(p, st);   // 144 KB
         case 28: return launch_pl<128, 256, 4, 4, 32>(p, st);      // 96 KB
+        // round 5: several loader waves (8 consumers + 2 or 4 loaders, one workgroup per CU)
+        case 31: if (k64) return launch_pl<128, 128, 4, 2, 64, 2, 2>(p, st); break;   // 128 KB
+        case 32: if (k64) return launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st); break;   // 128 KB
+        case 33: return launch_pl<128, 128, 2, 4, 32, 3, 4>(p, st);                   // 96 KB
+        case 34: return launch_pl<128, 128, 2, 4, 32, 4, 4>(p, st);                   // 128 KB
+        case 35: if (k64) return launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st); break;   // 128 KB, 64 x 32 per wave
+        case 36: return launch_pl<256, 128, 4, 2, 32, 3, 4>(p, st);                   // 144 KB, 64 x 64 per wave
+        case 37: return launch_pl<128, 128, 4, 2, 32, 4, 2>(p, st);                   // 128 KB
         default: break;
     }
     // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere.  The loader-wave form
@@ -501,8 +513,8 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
     if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
     if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
-    if (p.N >= 512) return k64 && p.act == CBX_ACT_NONE ? launch_pl<128, 128, 4, 2, 64, 2, true>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
-    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, true>(p, st);
+    if (p.N >= 512) return k64 && p.act == CBX_ACT_NONE ? launch_pl<128, 128, 4, 2, 64, 2, 1>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
+    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, 1>(p, st);
     return launch_pl<128, 128, 4, 2, 32>(p, st);
 }
 

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TILES = list(range(0, 20)) + [21, 22, 23, 24, 25, 26, 27, 28]  # 21 .. 25: the loader-wave forms, 26 .. 28: 16-wave workgroups  # 0 = the dispatcher's own choice, 1..17 = the menu of gemm_planes.hip
+TILES = list(range(0, 20)) + [21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 37]  # 21 .. 25: the loader-wave forms, 26 .. 28: 16-wave workgroups  # 0 = the dispatcher's own choice, 1..17 = the menu of gemm_planes.hip
 
 
 def _r(shape, seed, scale=1.0):

@@ -106,7 +106,7 @@ def test_gpu_planes_bodies_on_the_emulator(emu, name, args):
     getattr(test_planes_gpu, name)(CPU, *args)
 
 
-@pytest.mark.parametrize("tile,persist", [(0, 1), (1, 0), (3, 8), (7, 1), (12, 0), (15, 8), (21, 1), (24, 8), (26, 0), (28, 1)])
+@pytest.mark.parametrize("tile,persist", [(0, 1), (1, 0), (3, 8), (7, 1), (12, 0), (15, 8), (21, 1), (24, 8), (26, 0), (28, 1), (31, 8), (32, 1), (33, 0), (34, 8), (36, 1)])
 def test_gemm_planes_tiles_small(emu, tile, persist):
     """tests/test_planes_gpu.py::test_gemm_planes_linear_tiles at emulator-sized shapes: symmetric, loader-wave (21+) and 16-wave (26+) tile
     forms, persistent and one-tile-per-workgroup grids, ragged M and N, bias + GELU + residual, fp32 and plane outputs."""

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 12  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 13  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -46,6 +46,7 @@ class GemmPlParams(ctypes.Structure):
         ("lda", c_long), ("a_lo", c_long), ("a_s1", c_long), ("ldw", c_long), ("w_lo", c_long), ("w_s1", c_long),
         ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long), ("reserved0", c_int),
         ("PT", c_f), ("pt_n0", c_int), ("pt_T", c_int), ("pt_ld", c_long), ("pt_lo", c_long), ("pt_zs", c_long),  # ABI v8
+        ("tile", c_int),  # ABI v13: this call's tile form (0 automatic, -1 = PL_TILE_CORESIDENT)
     ]
 
 
@@ -57,7 +58,8 @@ class GemvParams(ctypes.Structure):
                 ("col_tiles", c_int), ("ssq_out", c_f)]  # ABI v11
 
 
-GEMV_PRE_EPI, GEMV_DEEP = 1, 2  # cbx_gemv_t.flags
+GEMV_PRE_EPI, GEMV_DEEP, GEMV_SHALLOW = 1, 2, 4  # cbx_gemv_t.flags
+PL_TILE_CORESIDENT, ATTN_PL_CORESIDENT = -1, 5  # cbx_gemm_pl_t.tile / cbx_flash_attn_planes_v version: the co-resident forms (ABI v13)
 
 
 class DecodeAttnParams(ctypes.Structure):  # cbx_decode_attn_t (ABI v10)
@@ -124,7 +126,8 @@ class CfmSolve(ctypes.Structure):  # cbx_cfm_t
                    ("fin_c", PlanesRef), ("fin_proj", PlanesRef)]
                 + [(k, c_f) for k in ("fin_c_b", "fin_n_w", "fin_n_b", "fin_proj_b", "tbias", "lens", "xin")]
                 + [("xinP", PlanesRef)] + [(k, c_f) for k in ("ra", "rb", "x", "v")]
-                + [(k, PlanesRef) for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP")])
+                + [(k, PlanesRef) for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP")]
+                + [("gemm_tile", c_int), ("attn_version", c_int)])  # ABI v13
 
 
 class Conformer(ctypes.Structure):  # cbx_conformer_t
@@ -187,6 +190,7 @@ _SIGS = {
     "cbx_layernorm_planes_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_float, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_split_po": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 9 + [c_float, c_int, c_f], c_int),
     "cbx_flash_attn_planes": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_f], c_int),
+    "cbx_flash_attn_planes_v": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_set_attn_planes_version": ([c_int], c_int),
     "cbx_mlp_planes": ([c_f] * 7 + [c_int] * 3 + [c_long] * 9 + [c_int, c_f], c_int),
     "cbx_row_stats_f32": ([c_f, c_f, c_long, c_int, c_long, c_float, c_f], c_int),

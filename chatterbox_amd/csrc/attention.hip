@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
                                                                long head_stride, float scale, float* split_ws, int* split_cnt,
                                                                int split_min_ctx, int qkv_nparts, long qkv_part_stride,
                                                                const float* __restrict__ qkv_ssq, float rms_dim, float rms_eps) {
+    __builtin_amdgcn_s_setprio(3);  // decode-step kernels are latency-bound and issue little: beside a co-resident workgroup of another stream (the throughput schedule, profiles/r05_overlap_*) their waves go first at the SIMD's issue arbiter; alone on the CU it changes nothing
     // gridDim.z = S > 1: the context of a (row, head) is split over S workgroups (on S CUs: one workgroup cannot pull a long context
     // faster than its CU's memory path, 50-60 GB/s); each leaves {max, sum, 64 numerators} in split_ws and the LAST to arrive (a ticket on
     // split_cnt, agent-scope release before it, acquire after it: cdna_hip_programming.md guideline 16) merges them in split order.

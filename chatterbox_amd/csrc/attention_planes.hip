@@ -279,8 +279,19 @@ __device__ __forceinline__ float half_swap(float x) {
 // FREE: the free-running loop -- every wave runs S(t), softmax(t), P V(t) back to back on its own 32 queries and meets the others ONCE per
 // tile (the ring hand-off: tile t + 1 landed, tile t - 1 free); no stagger, no matrix / vector phases.  The two waves of a SIMD drift
 // apart by themselves, which is all the overlap the hardware gives (profiles/r03_mfma_valu_inwave_micro.log).
-template <bool PRIO, bool FREE = false>
-__global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArgs a) {
+// One 1 KiB global -> LDS DMA.  A separate __device__ function on purpose: with the builtin called from a lambda of the kernel template hipcc (ROCm 7.2) can
+// silently drop a kernel instantiation's HOST stub (undefined symbol at dlopen; gemm_planes.hip has the same note).
+__device__ __forceinline__ void pl2_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+// NQW = 4 (round 5, "version 5", FREE only): 4-wave workgroups of 128 queries, ONE per CU (96 KiB of LDS) -- one wave per SIMD holding ~200 VGPRs, so 3/5 of
+// every SIMD's register file and 64 KiB of LDS stay free for the workgroups of ANOTHER stream (the T3 decode step of the next batch in the throughput
+// schedule: profiles/r05_overlap_*).  Each wave then issues its share of BOTH operand tiles (the loads of "virtual waves" wid and wid + 4).  Same
+// arithmetic per query, same key order: bit-identical to the 8-wave form.
+template <bool PRIO, bool FREE = false, int NQW = 8>
+__global__ __launch_bounds__(NQW * 64, 2) void flash_attn_pl2_kernel(const FlashPlArgs a) {
+    static_assert(NQW == 8 || (NQW == 4 && FREE), "4-wave workgroups: the free-running form only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // 3 stages x [K h, K l, V^T h, V^T l] x 8 KiB
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -289,38 +300,47 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pl2_kernel(const FlashPlArg
     const int lr = lane & 31, lh = lane >> 5;
     const int tile = cbx_xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int qt = tile % gridDim.x, head = (tile / gridDim.x) % gridDim.y, z = tile / (gridDim.x * gridDim.y);
-    const int q0 = qt * 256;
-    const int qi = q0 + wid * 32 + lr;  // this lane's query (group g owns queries q0 + 128 g .. + 128)
+    const int q0 = qt * (32 * NQW);
+    const int qi = q0 + wid * 32 + lr;  // this lane's query (8 waves: group g owns queries q0 + 128 g .. + 128)
     const _Float16* qb = a.q + (long)z * a.q_sb + head * 64;
     const _Float16* kb = a.k + (long)z * a.k_sb + head * 64;
     const _Float16* vb = a.vt + (long)z * a.vt_sb + (long)head * 64 * a.vt_sd;
     const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
     const int nt = (klen + PKT - 1) / PKT;
 
-    // ---- DMA: a (K, V^T) tile pair is 32 wave-level loads of 1 KiB; wave w issues loads 4w .. 4w+3: waves 0-3 (group 0) the K tile
-    //      (h rows 0-31, h rows 32-63, l rows 0-31, l rows 32-63), waves 4-7 the V^T tile likewise.
+    // ---- DMA: a (K, V^T) tile pair is 32 wave-level loads of 1 KiB; (virtual) wave w issues loads 4w .. 4w+3: waves 0-3 (group 0) the K tile
+    //      (h rows 0-31, h rows 32-63, l rows 0-31, l rows 32-63), waves 4-7 the V^T tile likewise.  NQW = 4: wave w is virtual waves w and w + 4.
+    constexpr int NG = NQW == 8 ? 1 : 2;  // operand tiles a wave loads a share of
     const int plane = (wid >> 1) & 1, rbase = (wid & 1) * 32;
-    const __amdgpu_buffer_rsrc_t rs = grp == 0
-        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kb), 0, klen > 0 ? (int)((((long)klen - 1) * a.k_st + a.k_lo + 64) * 2) : 0, 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(vb), 0, (int)(64 * a.vt_sd * 2), 0x00020000);
-    int voff[4];
+    __amdgpu_buffer_rsrc_t rs[NG];
+    int voff[NG][4], tstep[NG], lds_w[NG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = rbase + 8 * i + (lane >> 3), pc = lane & 7;
-        const int c = pc ^ ((row >> 1) & 7);
-        if (grp == 0) {  // row slot `row` holds key row with bits 2 and 3 swapped
-            const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
-            voff[i] = (int)((key * a.k_st + plane * a.k_lo) * 2) + c * 16;
-        } else {
-            voff[i] = (int)((row * a.vt_sd + plane * a.vt_lo) * 2) + c * 16;
+    for (int j = 0; j < NG; ++j) {
+        const int gj = NQW == 8 ? grp : j;  // 0: K, 1: V^T
+        rs[j] = gj == 0
+            ? __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kb), 0, klen > 0 ? (int)((((long)klen - 1) * a.k_st + a.k_lo + 64) * 2) : 0, 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(vb), 0, (int)(64 * a.vt_sd * 2), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rbase + 8 * i + (lane >> 3), pc = lane & 7;
+            const int c = pc ^ ((row >> 1) & 7);
+            if (gj == 0) {  // row slot `row` holds key row with bits 2 and 3 swapped
+                const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+                voff[j][i] = (int)((key * a.k_st + plane * a.k_lo) * 2) + c * 16;
+            } else {
+                voff[j][i] = (int)((row * a.vt_sd + plane * a.vt_lo) * 2) + c * 16;
+            }
         }
+        tstep[j] = gj == 0 ? (int)(PKT * a.k_st * 2) : PKT * 2;  // bytes per tile along the key axis
+        lds_w[j] = ((gj ? 2 : 0) + plane) * PL_TILE + rbase * 128;  // this wave's first destination inside a stage
     }
-    const int tstep = grp == 0 ? (int)(PKT * a.k_st * 2) : PKT * 2;  // bytes per tile along the key axis
-    const int lds_w = ((grp ? 2 : 0) + plane) * PL_TILE + rbase * 128;  // this wave's first destination inside a stage
     auto issue = [&](int t) {  // K(t) (group 0) or V^T(t) (group 1) into stage t % 3.  The whole address is in the VECTOR offset: the
-        unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w;  // descriptor's bounds check ignores a scalar offset
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, voff[i] + t * tstep, 0, 0, 0);
+        for (int j = 0; j < NG; ++j) {  // descriptor's bounds check ignores a scalar offset
+            unsigned char* dst = smem2 + (t % 3) * PL_STAGE + lds_w[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pl2_dma16(rs[j], dst + i * 1024, voff[j][i] + t * tstep[j]);
+        }
     };
     if (nt > 0) issue(0);
     if ((FREE || grp == 0) && nt > 1) issue(1);
@@ -517,9 +537,10 @@ extern "C" int cbx_set_attn_planes_version(int v) {
     return 0;
 }
 
-extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
-                                     int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
-                                     long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream) {
+extern "C" int cbx_flash_attn_planes_v(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
+                                       int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
+                                       long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, int version, void* stream) {
+    CBX_REQUIRE(version >= 0 && version <= 5, "flash_attn_planes: version %d (0 = default, 1 .. 5)", version);
     CBX_REQUIRE(q && k && vt && o, "flash_attn_planes: null operand");
     CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn_planes: bad shape");
     CBX_REQUIRE((q_sb | q_st | q_lo | k_sb | k_st | k_lo | vt_sb | vt_sd | vt_lo) % 8 == 0 &&
@@ -535,7 +556,7 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
 #endif
     // versions 2 / 4 (256 queries per workgroup; 4 = the free-running loop, the default) serve the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
     // (or CBX_ATTN_PL_VERSION) keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
-    const int ver = g_attn_pl_version;
+    const int ver = version ? version : g_attn_pl_version;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;
     if (ver >= 2 && v2ok) {
         constexpr int lds = 3 * PL_STAGE;
@@ -545,12 +566,15 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_pl2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>((flash_attn_pl2_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>((flash_attn_pl2_kernel<false, true, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e3 == hipSuccess) e3 = e4;
             if (e2 == hipSuccess) e2 = e3;
             if (e1 != hipSuccess || e2 != hipSuccess) return cbx_set_error((int)(e1 != hipSuccess ? e1 : e2), "flash_attn_planes: cannot reserve %d B of LDS", lds);
             configured |= 1ull << dev;
         }
         dim3 grid2((Tq + 255) / 256, n_heads, nz1);
-        if (ver == 3) hipLaunchKernelGGL(flash_attn_pl2_kernel<true>, grid2, dim3(512), lds, (hipStream_t)stream, a);
+        if (ver == 5) hipLaunchKernelGGL((flash_attn_pl2_kernel<false, true, 4>), dim3((Tq + 127) / 128, n_heads, nz1), dim3(256), lds, (hipStream_t)stream, a);
+        else if (ver == 3) hipLaunchKernelGGL(flash_attn_pl2_kernel<true>, grid2, dim3(512), lds, (hipStream_t)stream, a);
         else if (ver == 4) hipLaunchKernelGGL((flash_attn_pl2_kernel<false, true>), grid2, dim3(512), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(flash_attn_pl2_kernel<false>, grid2, dim3(512), lds, (hipStream_t)stream, a);
         return cbx_check_launch("flash_attn_planes");
@@ -558,4 +582,11 @@ extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* v
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     hipLaunchKernelGGL(flash_attn_pl_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return cbx_check_launch("flash_attn_planes");
+}
+
+extern "C" int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
+                                     int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
+                                     long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream) {
+    return cbx_flash_attn_planes_v(q, k, vt, o, key_lens, nz1, n_heads, Tq, Tk, q_sb, q_st, q_lo, k_sb, k_st, k_lo, vt_sb, vt_sd, vt_lo, o_sb, o_st, o_lo, scale,
+                                   causal, 0, stream);
 }

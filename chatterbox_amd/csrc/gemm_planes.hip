@@ -27,6 +27,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) unsigned char* lds_u8_t;  // LDS addresses stay in their address space: a generic -> LDS cast per DMA costs a null check (s_cmp + s_cselect)
 
 // waves per SIMD the register allocation must leave room for: as many workgroups per CU as the LDS admits (two co-resident workgroups
 // overlap one's epilogue with the other's K loop), at most 4 waves per SIMD (128 VGPRs)
@@ -39,8 +40,83 @@ struct PlOcc {
 
 // One 1 KiB global -> LDS DMA (16 B per lane, LDS destination lane-linear from `lds`).  A separate __device__ function on purpose: with the
 // builtin called from a lambda of the kernel template, hipcc (ROCm 7.2) silently drops the kernel's HOST stub (undefined symbol at dlopen).
-__device__ __forceinline__ void pl_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff) {
+__device__ __forceinline__ void pl_dma16(const __amdgpu_buffer_rsrc_t rs, lds_u8_t lds, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+// One loader wave of the LD > 0 forms: issues DMAs [LB, LB + LPW) of every K tile of this workgroup's tiles (LB a compile-time constant per loader
+// wave: which operand / plane / rows a load moves, its LDS destination and its descriptor are then all immediates or per-lane constants -- with a
+// run-time first load the issue loop of the ONE loader wave of the round-3 form took twice as long per K tile, and that wave is the form's critical
+// path: profiles/r05_bench_planes_loader_waves_first.log, tile 21), waits for them with counted vmcnt, and meets the consumers at the barrier.
+// The address map is the one of the symmetric form below (same slots, same swizzle).
+template <int BM, int BN, int BK, int NS, int LPW, int LB>
+__device__ __forceinline__ void pl_loader_wave(const cbx_gemm_pl_t& p, const lds_u8_t smem, const int lane) {
+    constexpr int CH = BK / 8, RPS = 16 / CH, PLANE_SLOTS = (BM + BN) * CH, STAGE_BYTES = 2 * PLANE_SLOTS * 16;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int tiles_z = ntn * ntm, total = tiles_z * p.nz1;
+    const int nk = p.K / BK;
+    int vbase[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int s = (LB + i) * 64 + lane;
+        const int q = s / PLANE_SLOTS, rs = s % PLANE_SLOTS;
+        const int row = rs / CH, pc = rs % CH;
+        const int c = pc ^ ((row / RPS) & (CH - 1));
+        vbase[i] = row < BM ? (row * p.stride * (int)p.lda + (q ? (int)p.a_lo : 0) + c * 8) * 2
+                            : ((row - BM) * (int)p.ldw + (q ? (int)p.w_lo : 0) + c * 8) * 2;
+    }
+    __amdgpu_buffer_rsrc_t a_rs, w_rs;
+    int offA = 0, offW = 0;
+    const int a_wstep2 = (int)(((long)p.dil * p.lda - p.Cin) * 2);
+    auto load_desc = [&](int vt) {
+        const int z = vt / tiles_z;
+        const int t = cbx_xcd_remap(vt - z * tiles_z, tiles_z);
+        const int n0 = (t % ntn) * BN, m0 = (t / ntn) * BM;
+        const int lim = p.lens ? min(p.Tin, p.lens[z]) : p.Tin;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.A) + (long)z * p.a_s1), 0,
+                                                 lim > 0 ? (int)((long)lim * p.lda * 2) : 0, 0x00020000);
+        w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(reinterpret_cast<const _Float16*>(p.W) + (long)z * p.w_s1), 0,
+                                                 (int)((long)p.N * p.ldw * 2), 0x00020000);
+        offA = (m0 * p.stride - p.pad_left) * (int)p.lda * 2;
+        offW = n0 * (int)p.ldw * 2;
+    };
+    int l_tile = blockIdx.x, l_kt = 0, l_g = 0, ld_c0 = 0, c_g = 0;
+    if (l_tile < total) load_desc(l_tile);
+    auto issue = [&]() {
+        const lds_u8_t dst = smem + (l_g % NS) * STAGE_BYTES + LB * 1024;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const bool isA = ((LB + i) * 64) % PLANE_SLOTS < BM * CH;  // folds: LB, i are constants
+            if (isA) pl_dma16(a_rs, dst + i * 1024, vbase[i] + offA);
+            else pl_dma16(w_rs, dst + i * 1024, vbase[i] + offW);
+        }
+        ++l_g;
+        if (++l_kt == nk) {
+            l_kt = 0;
+            ld_c0 = 0;
+            l_tile += gridDim.x;
+            if (l_tile < total) load_desc(l_tile);
+            return;
+        }
+        ld_c0 += BK;
+        const bool wrap = ld_c0 >= p.Cin;
+        ld_c0 = wrap ? 0 : ld_c0;
+        offA += BK * 2 + (wrap ? a_wstep2 : 0);
+        offW += BK * 2;
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (l_tile < total) issue();
+    for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = l_g - c_g - 1;  // K tiles issued after the one released now: they stay in flight
+            if (NS >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
+            else if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW > 63 ? 63 : LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (l_tile < total) issue();
+            ++c_g;
+        }
 }
 
 // LD > 0 = loader-wave form: the workgroup has LD EXTRA waves that do nothing but issue the DMAs of every K tile and wait for them; the
@@ -70,12 +146,13 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     constexpr int LPW = LD ? NLOAD / LD : NLOAD / NWV;  // DMA instructions per K tile issued by one (loader) wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const lds_u8_t sm3 = (lds_u8_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
     const bool is_loader = LD && wid >= NWV;
-    const int lbase = LD ? (is_loader ? wid - NWV : 0) * LPW : wid * LPW;  // first DMA instruction (of a stage) this wave issues
+    const int lbase = LD ? 0 : wid * LPW;  // first DMA instruction (of a stage) this wave issues (symmetric form; the loader waves: pl_loader_wave)
     // ---- persistent tile loop: workgroup b owns the virtual tiles b, b + gridDim.x, ...; the LOADER side (DMA issue) runs NS - 1 K tiles ahead
     //      of the CONSUMER side (MFMA + epilogue) straight across tile boundaries, so the first K tiles of the next output tile are in flight
     //      while this one's epilogue computes and stores, and no tile but a workgroup's first pays the load latency.  With gridDim.x = number
@@ -121,9 +198,9 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     };
     int l_tile = blockIdx.x, l_kt = 0, l_g = 0;  // loader position: tile, K tile inside it, K tiles issued so far (ring position)
     int ld_c0 = 0;                               // channel block inside the current conv tap
-    if ((!LD || is_loader) && l_tile < total) load_desc(l_tile);
+    if (!LD && l_tile < total) load_desc(l_tile);  // (the loader waves of the LD forms keep their own descriptors: pl_loader_wave)
     auto issue = [&]() {  // the loader's next K tile into ring stage l_g % NS
-        unsigned char* dst = smem + (l_g % NS) * STAGE_BYTES + lbase * 1024;
+        const lds_u8_t dst = sm3 + (l_g % NS) * STAGE_BYTES + lbase * 1024;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
             const bool isA = ((lbase + i) * 64) % PLANE_SLOTS < BM * CH;
@@ -199,20 +276,15 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     [[maybe_unused]] constexpr int W_EPI1T = LPW + EPI_OPS_T > 63 ? 63 : LPW + EPI_OPS_T;
     bool prev_t = false;  // the previous tile of this workgroup was a transposed one
     int c_g = 0;  // consumer ring position
-    if (is_loader) {  // ---- the loader wave: wait for K tile g, release it to the consumers at the barrier, issue K tile g + NS - 1
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (l_tile < total) issue();
-        for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x)
-            for (int kt = 0; kt < nk; ++kt) {
-                const int younger = l_g - c_g - 1;  // K tiles issued after the one released now: they stay in flight
-                if (NS >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW > 63 ? 63 : 2 * LPW) : "memory");
-                else if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW > 63 ? 63 : LPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (l_tile < total) issue();
-                ++c_g;
-            }
+    if (is_loader) {  // ---- a loader wave: wait for ITS share of K tile g, release it to the consumers at the barrier, issue its share of K tile g + NS - 1
+        if constexpr (LD > 0) {
+            constexpr int LL = NLOAD / (LD > 0 ? LD : 1);
+            const int li = wid - NWV;
+            if (li == 0) pl_loader_wave<BM, BN, BK, NS, LL, 0>(p, sm3, lane);
+            if constexpr (LD >= 2) { if (li == 1) pl_loader_wave<BM, BN, BK, NS, LL, LL>(p, sm3, lane); }
+            if constexpr (LD >= 3) { if (li == 2) pl_loader_wave<BM, BN, BK, NS, LL, 2 * LL>(p, sm3, lane); }
+            if constexpr (LD >= 4) { if (li == 3) pl_loader_wave<BM, BN, BK, NS, LL, 3 * LL>(p, sm3, lane); }
+        }
         return;
     }
     if (!LD) {
@@ -434,6 +506,7 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     if (p.Cin <= 0) p.Cin = p.K / p.taps;
     if (p.Tin <= 0) p.Tin = p.M;
     CBX_REQUIRE(p.alpha == 0.f || p.alpha == 1.f, "gemm_planes: alpha is not supported (must be 0 or 1)");
+    CBX_REQUIRE(p.tile >= CBX_PL_TILE_CORESIDENT && p.tile <= 64, "gemm_planes: tile=%d (0 automatic, 1 .. the tile menu, -1 co-resident)", p.tile);
     CBX_REQUIRE(p.act == CBX_ACT_NONE || p.act == CBX_ACT_GELU_ERF || p.act == CBX_ACT_SILU, "gemm_planes: activation %d is not served (none, GELU (erf), SiLU)", p.act);
     CBX_REQUIRE(p.A && p.W && (p.C || p.P), "gemm_planes: null operand");
     CBX_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.K == p.taps * p.Cin, "gemm_planes: bad shape M=%d N=%d K=%d taps=%d Cin=%d", p.M, p.N, p.K, p.taps, p.Cin);
@@ -463,8 +536,12 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE((!p.C || p.ldc >= Np) && (!p.R || p.ldr >= Np) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + Np)),
                 "gemm_planes: rows must not overlap (ldc, ldr >= N; plane output rows hold [h | l]: ldp >= p_lo + N)");
     hipStream_t st = (hipStream_t)stream;
-    const int force = g_pl_tile;
     const bool k64 = p.Cin % 64 == 0;
+    int force = p.tile ? p.tile : g_pl_tile;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
+    if (force == CBX_PL_TILE_CORESIDENT) {    // one 8-wave workgroup per CU (96 KiB of LDS, <= 120 VGPRs); small grids / narrow outputs keep their forms (they never fill a CU)
+        const long g128c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
+        force = (g128c < 64 || p.N <= 96) ? 0 : 17;
+    }
     // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log
     switch (force) {
         case 1: return launch_pl<128, 64, 4, 2, 32>(p, st);       // 8 waves 32x32, 48 KB
@@ -506,15 +583,15 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 37: return launch_pl<128, 128, 4, 2, 32, 4, 2>(p, st);                   // 128 KB
         default: break;
     }
-    // automatic choice (profiles/r03_bench_planes_tiles.log, rows 16 x T 1000): 8-wave workgroups everywhere.  The loader-wave form
-    // (128 x 128 x 64, one workgroup of 8 + 1 waves per CU) wins wherever the epilogue is light: wide plain outputs (-5..-12 %) and narrow
-    // outputs with a long K (-3 %); an epilogue with a GELU wants two co-resident workgroups (the symmetric 2 x 4 waves of 64 x 32);
-    // N <= 96 takes half-width tiles, small grids 64 x 64.
+    // automatic choice (rows 16 x T 1000; profiles/r03_bench_planes_tiles.log, round 5: profiles/r05_bench_planes_loader_waves.log): 8 consumer waves
+    // everywhere.  The loader-wave forms (128 x 128 x 64, one workgroup per CU) win wherever K % 64 == 0 -- with FOUR loader waves (one per SIMD, each
+    // streaming one of {A.h, W.h, A.l, W.l}) since round 5: 2-5 % under the one-loader form on every CFM shape, and now also ahead of the symmetric two-
+    // workgroup form for the GELU epilogue (ff1: 43.7 against 46.1 us); N <= 96 takes half-width tiles, small grids 64 x 64.
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
     if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
     if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
-    if (p.N >= 512) return k64 && p.act == CBX_ACT_NONE ? launch_pl<128, 128, 4, 2, 64, 2, 1>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
-    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, 1>(p, st);
+    if (p.N >= 512) return k64 ? launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
+    if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st);
     return launch_pl<128, 128, 4, 2, 32>(p, st);
 }
 

@@ -40,8 +40,12 @@ __host__ __device__ __forceinline__ int gemv_tile_cols(int half_tile) { return h
 
 // D8: eight K blocks (instead of four) requested before the first MFMA -- for a wave whose K slice is >= 256 deep (the down projection
 // without split-K partials: K = 4096 over 16 waves) the whole slice is then ONE batch of loads instead of two dependent ones.
-template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false, bool D8 = false>
+// D2 (round 5, cbx_gemv_t.flags & CBX_GEMV_SHALLOW): TWO K blocks per batch -- the SwiGLU launch then needs <= 128 VGPRs instead of 162, so its workgroups (2 waves per
+// SIMD) fit on a CU beside a workgroup of another stream that leaves half of the register file free (the throughput schedule: profiles/r05_overlap_*).
+// Same loads, same MFMA order: bit-identical results.
+template <int MT, int NW, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP, bool WB = false, bool D8 = false, bool D2 = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
+    __builtin_amdgcn_s_setprio(3);  // decode-step kernels are latency-bound and issue little: beside a co-resident workgroup of another stream (the throughput schedule, profiles/r05_overlap_*) their waves go first at the SIMD's issue arbiter; alone on the CU it changes nothing
     static_assert(NP == 0 || (RMS && MT == 1), "partial-sum operand: RMS variant, one row tile");
     static_assert(!WB || (PK && XPK), "bf16 weights: packed operands only");
     __shared__ __attribute__((aligned(16))) float red[(SWIGLU ? 2 : 1) * NW * MT * 256];
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             for (int j = 0; j < EIT; ++j) e_cw[j] = p.ln_cw[e_n[j]], e_cb[j] = p.ln_cb[e_n[j]];
         }
     }
-    constexpr int DEPTH = D8 ? 8 : (MT == 1) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
+    constexpr int DEPTH = D8 ? 8 : (MT == 1 && !D2) ? 4 : 2;  // K blocks (2 KiB of W per wave each) issued before the first MFMA
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // Loads are UNCONDITIONAL (out-of-range lanes / K blocks re-read a valid address and are zeroed by a select): a predicated
     // load makes hipcc join all of them behind one vmcnt(0); unconditional ones get counted waits, so the MFMAs of K block d
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 // epilogue as above.  Same MFMA, same fixed-order LDS reduction over the 8 waves; deterministic.
 template <int CT, int NP, int DEPTH>
 __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
+    __builtin_amdgcn_s_setprio(3);  // decode-step kernels are latency-bound and issue little: beside a co-resident workgroup of another stream (the throughput schedule, profiles/r05_overlap_*) their waves go first at the SIMD's issue arbiter; alone on the CU it changes nothing
     constexpr int NW = 8;
     __shared__ __attribute__((aligned(16))) float red[NW * CT * 256];
     __shared__ float ssq[NW * 16];
@@ -516,6 +521,12 @@ int launch_nw(const cbx_gemv_t& p, hipStream_t st) {
         }
         if (p.nw == 16) {  // 16 K-slices per workgroup: projections whose output tile count (N / 16) is small
             hipLaunchKernelGGL((gemv_kernel<1, 16, false, PK, XPK, false, 0, WB>), grid, dim3(1024), 0, st, p);
+            return cbx_check_launch("gemv");
+        }
+    }
+    if constexpr (MT == 1 && SWIGLU && PK && XPK && RMS && NP == 0 && !WB) {
+        if ((p.flags & CBX_GEMV_SHALLOW) && p.nw >= 8) {
+            hipLaunchKernelGGL((gemv_kernel<1, 8, true, true, true, true, 0, false, false, true>), grid, dim3(512), 0, st, p);
             return cbx_check_launch("gemv");
         }
     }
@@ -761,7 +772,7 @@ extern "C" int cbx_gemv_f32(const cbx_gemv_t* pp, void* stream) {
     cbx_gemv_t p = *pp;
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.nw != 8 && p.nw != 16) p.nw = 4;
-    p.flags = (p.flags & (CBX_GEMV_PRE_EPI | CBX_GEMV_DEEP)) | (g_gemv_pre_epi ? CBX_GEMV_PRE_EPI : 0) | (g_gemv_deep ? CBX_GEMV_DEEP : 0);
+    p.flags = (p.flags & (CBX_GEMV_PRE_EPI | CBX_GEMV_DEEP | CBX_GEMV_SHALLOW)) | (g_gemv_pre_epi ? CBX_GEMV_PRE_EPI : 0) | (g_gemv_deep ? CBX_GEMV_DEEP : 0);
     CBX_REQUIRE(p.x && p.W && p.out, "gemv: null operand");
     CBX_REQUIRE(p.M >= 1 && p.M <= 64 && p.N > 0 && p.K > 0, "gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     CBX_REQUIRE(p.col_tiles > 0 || p.K % (32 * p.ksplit * p.nw) == 0, "gemv: K=%d must be a multiple of 32*ksplit*nw=%d", p.K, 32 * p.ksplit * p.nw);

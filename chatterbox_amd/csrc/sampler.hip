@@ -123,6 +123,7 @@ __device__ void top_k_filter(float* l, int V, int k, float* red) {
 }
 
 __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
+    __builtin_amdgcn_s_setprio(3);  // decode-step kernels are latency-bound and issue little: beside a co-resident workgroup of another stream (the throughput schedule, profiles/r05_overlap_*) their waves go first at the SIMD's issue arbiter; alone on the CU it changes nothing
     __shared__ float l[MAXV];
     __shared__ float red[NT / 64];
     __shared__ double redd[NT / 64];

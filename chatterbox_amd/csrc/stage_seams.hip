@@ -30,6 +30,7 @@ struct CfmCtx {
         if (out) g.ldc = N, g.c_s1 = T * N;
         if (R) g.ldr = N, g.r_s1 = T * N;
         if (outp) g.ldp = outp->ld, g.p_lo = outp->lo, g.p_s1 = T * outp->ld;
+        g.tile = d->gemm_tile;
         return cbx_gemm_planes(&g, stream);
     }
     // F.linear over all M rows as one batch (ops.linear_planes)
@@ -43,6 +44,7 @@ struct CfmCtx {
         if (out) g.ldc = N;
         if (R) g.ldr = N;
         if (outp) g.ldp = outp->ld, g.p_lo = outp->lo;
+        g.tile = d->gemm_tile;
         return cbx_gemm_planes(&g, stream);
     }
     int ln_planes(const float* x, const cbx_planes_t& out, const float* w, const float* b, const float* post_add, int act) const {
@@ -71,6 +73,7 @@ struct CfmCtx {
             g.M = (int)M, g.N = 1536, g.K = 256, g.Cin = 256, g.taps = 1, g.dil = 1, g.stride = 1, g.nz1 = 1, g.alpha = 1.0f;
             g.lda = d->hP.ld, g.a_lo = d->hP.lo, g.ldw = t.wqkv.ld, g.w_lo = t.wqkv.lo, g.ldp = d->qkP.ld, g.p_lo = d->qkP.lo;
             g.PT = d->vtP.p, g.pt_n0 = 1024, g.pt_T = (int)T, g.pt_ld = d->vtP.ld, g.pt_lo = d->vtP.lo, g.pt_zs = 512 * d->vtP.ld;
+            g.tile = d->gemm_tile;
             if ((rc = cbx_gemm_planes(&g, stream))) return rc;
         } else {
             if ((rc = linear(d->hP, t.wqkv, 1024, 256, nullptr, &d->qkP, nullptr, nullptr, CBX_ACT_NONE))) return rc;
@@ -80,11 +83,12 @@ struct CfmCtx {
             g.M = 512, g.N = (int)T, g.K = 256, g.Cin = 256, g.taps = 1, g.dil = 1, g.stride = 1, g.nz1 = rows, g.alpha = 1.0f;
             g.lda = wv.ld, g.a_lo = wv.lo, g.ldw = d->hP.ld, g.w_lo = d->hP.lo, g.w_s1 = T * d->hP.ld;
             g.ldp = d->vtP.ld, g.p_lo = d->vtP.lo, g.p_s1 = 512 * d->vtP.ld;
+            g.tile = d->gemm_tile;
             if ((rc = cbx_gemm_planes(&g, stream))) return rc;
         }
         const cbx_planes_t q = d->qkP, k = cols(d->qkP, 512);
-        if ((rc = cbx_flash_attn_planes(q.p, k.p, d->vtP.p, d->attP.p, d->lens, rows, 8, (int)T, (int)T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo,
-                                        512 * d->vtP.ld, d->vtP.ld, d->vtP.lo, T * d->attP.ld, d->attP.ld, d->attP.lo, 0.125f, 0, stream)))
+        if ((rc = cbx_flash_attn_planes_v(q.p, k.p, d->vtP.p, d->attP.p, d->lens, rows, 8, (int)T, (int)T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo,
+                                          512 * d->vtP.ld, d->vtP.ld, d->vtP.lo, T * d->attP.ld, d->attP.ld, d->attP.lo, 0.125f, 0, d->attn_version, stream)))
             return rc;
         if ((rc = linear(d->attP, t.wo, 256, 512, x, nullptr, t.bo, x, CBX_ACT_NONE))) return rc;
         if ((rc = ln_planes(x, d->hP, t.n3_w, t.n3_b, nullptr, CBX_ACT_NONE))) return rc;

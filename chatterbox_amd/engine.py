@@ -120,6 +120,7 @@ class ChatterboxEngine:
                    repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False, ban_from=0, z=None, phase=None,
                    noise=None, n_cfm_timesteps=10, drop_last_token=True):
         """Full hot path for B utterances.  Returns (wavs: list of 1-D device tensors, speech_tokens: list)."""
+        self.co_resident(False)  # the serial schedule runs every kernel on its fastest-alone form (a no-op unless synthesize_pipelined ran before)
         t0 = time.perf_counter()
         toks = self.t3.generate(t3_conds, text_tokens, max_new_tokens=max_new_tokens, temperature=temperature, top_p=top_p,
                    min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms,
@@ -134,42 +135,76 @@ class ChatterboxEngine:
         return wavs, st
 
 
+    def co_resident(self, on):
+        """Both stages on (or off) the kernel forms whose workgroups can share a CU with the other stage's (T3Engine.co_resident, FlowEngine.co_resident)."""
+        if self.t3 is not None and hasattr(self.t3, "co_resident"):
+            self.t3.co_resident(on)
+        self.flow.co_resident(on)
+
     @torch.inference_mode()
-    def synthesize_pipelined(self, jobs, **kw):
+    def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, **kw):
         """Throughput mode for a stream of batches: T3 of batch k+1 runs on a high-priority HIP stream WHILE the flow
-        matching + vocoder of batch k run on a second stream.  The AR decode is a chain of small latency-bound kernels
-        (HBM-bound GEMVs on a fraction of the CUs); the CFM is MFMA-bound on wide grids -- the two fill each other's
-        idle resources.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields (wavs, tokens, latency_s)
-        per job in order.  Results are identical to synthesize() called per job."""
+        matching + vocoder of batch k run on a second stream.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields
+        (wavs, tokens, latency_s) per job in order.  Results are identical to synthesize() called per job.
+
+        What makes the two stages actually overlap (round 5, profiles/r05_overlap_*; none of it changes a result):
+          * co_resident: a chain of small dependent kernels keeps its pace beside chip-filling kernels of another stream only if its workgroups FIT
+            on the CUs beside theirs (scripts/micro/concur.hip: 1.0x when they fit, 6-7x slower when every launch has to wait for workgroups to retire).
+            The CFM runs its plane GEMMs / attention on one-workgroup-per-CU forms (8 waves x <= 120 VGPRs + 96 KiB LDS; 4 waves x 200 VGPRs), the
+            decode step on launches of <= 8 waves x <= 128 VGPRs; the decode kernels raise their wave priority (s_setprio 3).
+          * host_threads: the decode loop is 250 hipGraph launches of 153 kernel nodes -- ~0.6 ms of HOST time each, invisible in the serial schedule
+            (the GPU needs 1.1 ms per token) but 150-180 ms per batch in front of the flow's own ~130 ms of launches when one thread enqueues both
+            (scripts/overlap_probe.py: the flow started 180 ms late).  The T3 enqueue runs on a second host thread (graph launches and the ctypes
+            calls of the C stage seams release the GIL)."""
+        import threading
         torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
         if not hasattr(self, "_s_t3"):
             self._s_t3 = torch.cuda.Stream(device=self.dev, priority=-1)
             self._s_voc = torch.cuda.Stream(device=self.dev)
         t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
                                     "ban_from") if k in kw}
+        self.co_resident(bool(co_resident))
         torch.cuda.synchronize()
+
+        def enqueue_t3(job, box):
+            try:
+                torch.cuda.set_device(self.dev)
+                with torch.inference_mode(), torch.cuda.stream(self._s_t3):
+                    box["handle"] = self.t3.generate(job["t3_conds"], job["text_tokens"], async_mode=True, uniforms=job.get("uniforms"), **t3_kw)
+            except BaseException as e:  # re-raised by the consumer thread
+                box["error"] = e
+
         pending = None  # (job, speech tokens, t_start)
         for k in range(len(jobs) + 1):
-            handle = None
+            box, th = {}, None
             if k < len(jobs):
                 t_start = time.perf_counter()
-                with torch.cuda.stream(self._s_t3):
-                    handle = self.t3.generate(jobs[k]["t3_conds"], jobs[k]["text_tokens"], async_mode=True,
-                                              uniforms=jobs[k].get("uniforms"), **t3_kw)
+                if host_threads:
+                    th = threading.Thread(target=enqueue_t3, args=(jobs[k], box), name="cbx-t3-enqueue")
+                    th.start()
+                else:
+                    enqueue_t3(jobs[k], box)
+            try:
+                if pending is not None:
+                    job, st, t0 = pending
+                    with torch.cuda.stream(self._s_voc):
+                        def voc():
+                            wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
+                                                  n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
+                                                  drop_last_token=kw.get("drop_last_token", True), sync=False)
+                            return [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
+                        host = _range_checked(self, voc)
+            finally:
+                if th is not None:
+                    th.join()
+            if "error" in box:
+                raise box["error"]
             if pending is not None:
-                job, st, t0 = pending
-                with torch.cuda.stream(self._s_voc):
-                    def voc():
-                        wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
-                                              n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
-                                              drop_last_token=kw.get("drop_last_token", True), sync=False)
-                        return [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
-                    host = _range_checked(self, voc)
                 yield host, st, time.perf_counter() - t0
             pending = None
-            if handle is not None:
+            if "handle" in box:
                 with torch.cuda.stream(self._s_t3):
-                    toks = self.t3.collect(handle)
+                    toks = self.t3.collect(box["handle"])
                 st = [drop_invalid_tokens(t) for t in toks]
                 st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
                 pending = (jobs[k], st, t_start)

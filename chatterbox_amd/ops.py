@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import GEMV_DEEP, GEMV_PRE_EPI, DecodeAttnParams, GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
+from ._lib import ATTN_PL_CORESIDENT, GEMV_DEEP, GEMV_PRE_EPI, GEMV_SHALLOW, PL_TILE_CORESIDENT, DecodeAttnParams, GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -268,8 +268,25 @@ def layernorm_planes(x, w, b, out, eps=1e-5, act=NONE, post_add=None, scale=1.0)
     return out
 
 
+# launch geometry of the plane-format kernels issued inside `with planes_geometry(tile, attn_version)` (cbx_gemm_pl_t.tile / the version argument of
+# cbx_flash_attn_planes_v: per-call descriptor fields since ABI v13, nothing process-wide); (0, 0) = the library's measured defaults
+_PLANES_GEOM = [0, 0]
+
+
+class planes_geometry:
+    def __init__(self, tile=0, attn_version=0):
+        self.new = [int(tile), int(attn_version)]
+
+    def __enter__(self):
+        self.old = list(_PLANES_GEOM)
+        _PLANES_GEOM[:] = self.new
+
+    def __exit__(self, *a):
+        _PLANES_GEOM[:] = self.old
+
+
 def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, act_slope=0.0, alpha=1.0, lens=None, Cin=0, taps=1, dil=1,
-                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0, PT=None, pt_n0=0, pt_T=0, pt_zs=0):
+                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0, PT=None, pt_n0=0, pt_T=0, pt_zs=0, tile=None):
     """Raw access to cbx_gemm_planes (include/cbx.h): A, W, P are Planes operands, C / R fp32 tensors (their data_ptr() is the base).
     PT (Planes over (groups * (N - pt_n0), >= pt_T) rows): output columns n >= pt_n0 are written TRANSPOSED per group of pt_T rows."""
     p = GemmPlParams()
@@ -286,6 +303,7 @@ def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, a
     if P is not None:
         p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
     p.reserved0 = GEMM_DIAG
+    p.tile = _PLANES_GEOM[0] if tile is None else int(tile)
     if PT is not None:
         p.PT, p.pt_n0, p.pt_T, p.pt_ld, p.pt_lo, p.pt_zs = PT.ptr, pt_n0, pt_T, PT.ld, PT.lo, pt_zs
     _timed("gemm_planes", 2.0 * M * N * K * nz1, 4.0 * nz1 * (M * K / max(1, taps) + N * K + M * N),
@@ -323,13 +341,13 @@ def mlp_planes(h, w1, w2, b1, b2, x, outp=None, write_x=True):
     return x
 
 
-def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, causal=False):
+def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, causal=False, version=None):
     """q, k: Planes column ranges (Z * T rows, H * 64 columns); vt: Planes over (Z * H * 64 rows, >= T rounded up to 8 columns) = V^T
     (batch stride vt_sb halves); out: Planes (Z * T rows, H * 64)."""
     args = (q.ptr, k.ptr, vt.ptr, out.ptr, _p(key_lens), Z, H, T, T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo, vt_sb, vt.ld, vt.lo,
             T * out.ld, out.ld, out.lo, scale, int(causal))
     _timed("flash_attn_planes", 4.0 * Z * H * T * T * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * 4 * T,
-           lambda: check(lib.cbx_flash_attn_planes(*args, _stream()), "cbx_flash_attn_planes"))
+           lambda: check(lib.cbx_flash_attn_planes_v(*args, _PLANES_GEOM[1] if version is None else int(version), _stream()), "cbx_flash_attn_planes_v"))
     return out
 
 
@@ -537,8 +555,8 @@ def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packe
     return out
 
 
-def gemv_flags(pre_epi=0, deep=0):
-    return (GEMV_PRE_EPI if pre_epi else 0) | (GEMV_DEEP if deep else 0)
+def gemv_flags(pre_epi=0, deep=0, shallow=0):
+    return (GEMV_PRE_EPI if pre_epi else 0) | (GEMV_DEEP if deep else 0) | (GEMV_SHALLOW if shallow else 0)
 
 
 def softmax_relpos(ac, bd, p, scale, key_lens=None):

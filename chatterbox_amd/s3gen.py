@@ -125,6 +125,15 @@ class FlowEngine:
         # the per-kernel-timed path (ops.TIMER) and as the other side of the identity tests (which flip this attribute).
         self.c_seam = True
         self._cfm_static = self._enc_static = None
+        # launch geometry of the estimator's plane GEMMs / attention (cbx_gemm_pl_t.tile, cbx_flash_attn_planes_v: per call since ABI v13).  (0, 0) = the
+        # library's measured defaults; co_resident(True) = the forms that leave half of every CU to another stream (engine.synthesize_pipelined)
+        self.gemm_tile = self.attn_version = 0
+
+    def co_resident(self, on):
+        """The CFM estimator's kernels on their co-resident forms (one 8-wave / 4-wave workgroup per CU: profiles/r05_overlap_*) or back on the defaults.
+        Same arithmetic, bit-identical mel."""
+        from ._lib import ATTN_PL_CORESIDENT, PL_TILE_CORESIDENT
+        self.gemm_tile, self.attn_version = (PL_TILE_CORESIDENT, ATTN_PL_CORESIDENT) if on else (0, 0)
 
     # ------------------------------------------------------------------ conformer encoder
     def _rel_pos_table(self, T, dev=None, dm=512):
@@ -461,6 +470,7 @@ class FlowEngine:
         assert tb.is_contiguous() and tb.shape == (n_steps, len(self.stages), 256) and lens_r.dtype == torch.int32 and lens_r.numel() == rows
         d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.fused_mlp, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), int(self.fused_mlp), T
         d.cfg_rate, d.dt = cfg_rate, dt
+        d.gemm_tile, d.attn_version = int(self.gemm_tile), int(self.attn_version)
         d.tbias, d.lens, d.xin, d.xinP = ops._p(tb), ops._p(lens_r), ops._p(xin), ref(xinP)
         d.ra, d.rb, d.x, d.v = ops._p(ws["ra"]), ops._p(ws["rb"]), ops._p(ws["x"]), ops._p(ws["v"])
         for k in ("aP", "hP", "qkP", "attP", "ffP", "xP", "yP", "catP", "vtP"):
@@ -545,7 +555,8 @@ class FlowEngine:
             if planes:
                 if k:
                     ops.split_planes(xin2[:, :80], xinP.cols(0, 80))
-                v = self._estimator_pl(xinP, rows, T, lens_r, tb[k], ws)
+                with ops.planes_geometry(self.gemm_tile, self.attn_version):
+                    v = self._estimator_pl(xinP, rows, T, lens_r, tb[k], ws)
             else:
                 v = self._estimator(xin, rows, T, lens_r, tb[k], ws)
             ops.cfm_euler(xin, v, B, T, 80, float(t_span[k + 1] - t_span[k]), cfg_rate, cfg=cfg)

@@ -164,7 +164,7 @@ class T3Engine:
         return env_knobs()
 
     def _gf(self):
-        return ops.gemv_flags(self.knobs.get("pre_epi"), self.knobs.get("deep"))
+        return ops.gemv_flags(self.knobs.get("pre_epi"), self.knobs.get("deep"), self.knobs.get("shallow"))
 
     def _sync_geom(self, st):
         st["da"].unroll, st["da"].pipeline = (0 if int(self.knobs["da_u"]) == 4 else int(self.knobs["da_u"])), int(self.knobs["da_pipe"])
@@ -215,6 +215,20 @@ class T3Engine:
             st["graph"] = None
             st.pop("cstep", None)
             self._sync_geom(st)
+
+    def co_resident(self, on):
+        """The decode step on the geometry whose workgroups fit on a CU BESIDE a co-resident flow workgroup (engine.synthesize_pipelined; profiles/r05_overlap_*):
+        every launch <= 8 waves x <= 128 VGPRs -- the down projection on 512-thread workgroups with 4 split-K partial images (a member of the hardware-green
+        allow-list: decode_green.json {d_ks2: 4, d_nw2: 8, half_tiles: 0}), gate | up on its 2-deep load batches (CBX_GEMV_SHALLOW: same products, same order).
+        on=False: back to the engine's default geometry.  Switching drops the captured decode graphs."""
+        if getattr(self, "_co_res", False) == bool(on):
+            return
+        if on:
+            self._co_saved = (dict(self.tune), dict(self.knobs))
+            self.apply_variant(dict(self.tune, half_tiles=0, d_ks2=4, d_nw2=8), dict(self.knobs, shallow=1))
+        else:
+            self.apply_variant(*self._co_saved)
+        self._co_res = bool(on)
 
     @ops.on_device
     @torch.inference_mode()

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 12 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 13 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
@@ -26,7 +26,10 @@ extern "C" {
                               11: cbx_gemv_t.col_tiles / ssq_out (column-tile / split-K form of the RMSNorm-folded decode GEMV), cbx_decode_attn_t.qkv_nparts /
                                   qkv_part_stride / qkv_ssq / rms_dim / rms_eps (the attention adds the q/k/v partial sums and applies rstd),
                                   cbx_t3_step_t.qkv_ksplit / qkv_ct / head_ct / qkv_ssq, cbx_t3_prefill;
-                              12: stage-level seams of the flow and the vocoder: cbx_planes_t, cbx_s3gen_encode, cbx_cfm_solve, cbx_hift_f0_source, cbx_hift_decode */
+                              12: stage-level seams of the flow and the vocoder: cbx_planes_t, cbx_s3gen_encode, cbx_cfm_solve, cbx_hift_f0_source, cbx_hift_decode;
+                              13: per-call launch geometry of the plane-format kernels (cbx_gemm_pl_t.tile, cbx_flash_attn_planes_v, cbx_cfm_t.gemm_tile /
+                                  attn_version: no process-wide state on the flow path either) incl. the CO-RESIDENT forms of the throughput schedule
+                                  (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -133,7 +136,13 @@ typedef struct cbx_gemm_pl_t {
      * l plane pt_lo halves further), i.e. one (N - pt_n0) x pt_T matrix per group of pt_T rows.  Needs P for the columns below pt_n0,
      * pt_n0 % 256 == 0, pt_T % 4 == 0, M % 4 == 0, no C / R / activation, nz1 == 1. */
     void* PT; int pt_n0, pt_T; long pt_ld, pt_lo, pt_zs;   /* halves */
+    /* ABI v13 -- launch geometry of THIS call: 0 = the library's measured choice (or the cbx_set_planes_tile test hook); n > 0 = form n of the tile menu
+     * (gemm_planes.hip); CBX_PL_TILE_CORESIDENT (-1) = the measured choice among the forms that leave room on the CU: ONE workgroup of 8 waves and <= 120
+     * VGPRs per CU with 96 KiB of LDS (form 17), so that the workgroups of a latency-bound kernel chain on ANOTHER stream (the T3 decode step of the next
+     * batch) stay co-resident instead of waiting for these to retire (profiles/r05_overlap_*).  Same arithmetic in every form. */
+    int tile;
 } cbx_gemm_pl_t;
+#define CBX_PL_TILE_CORESIDENT (-1)
 int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
 /* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */
 int cbx_set_planes_tile(int t);
@@ -212,6 +221,10 @@ int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
  *   instead of 4 -- half the dependent load batches.  Both: results unchanged bit for bit (tests/test_zz_abi_v9_gpu.py, on hardware). */
 #define CBX_GEMV_PRE_EPI 1
 #define CBX_GEMV_DEEP 2
+/* CBX_GEMV_SHALLOW (ABI v13): the RMSNorm-folded SwiGLU launch (gate | up of the decode step) requests 2 K blocks per batch instead of 4: <= 128 VGPRs instead of
+ * 162, so that its workgroups fit on a CU beside a workgroup of ANOTHER stream that leaves half of the register file free (the throughput schedule of
+ * ChatterboxEngine.synthesize_pipelined: T3 of batch k + 1 beside flow + vocoder of batch k).  Same products, same order: bit-identical. */
+#define CBX_GEMV_SHALLOW 4
 /* TEST HOOKS (env CBX_GEMV_DEEP / CBX_GEMV_PRE_EPI, default 0): OR the bit into the flags of EVERY cbx_gemv_f32 launch of the process. */
 int cbx_set_gemv_deep_batches(int on);
 int cbx_set_gemv_epilogue_prefetch(int on);
@@ -271,6 +284,12 @@ int cbx_mlp_planes(const void* h, const void* w1, const void* w2, const float* b
 int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
                           int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
                           long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
+/* ABI v13: the same with the kernel version chosen PER CALL (0 = the library default, else 1 .. 5 as cbx_set_attn_planes_version).  5 = the CO-RESIDENT form:
+ * the free-running loop of version 4 on 4-wave workgroups of 128 queries, one per CU (96 KiB of LDS, one wave of ~200 VGPRs per SIMD): 3/5 of the register
+ * file stay free for another stream's workgroups; bit-identical to version 4; +8 % per launch when alone (profiles/r05_overlap_*). */
+int cbx_flash_attn_planes_v(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
+                            int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
+                            long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, int version, void* stream);
 /* tuning knob (A/B hook, no engine calls it): kernel version of cbx_flash_attn_planes (4 = default since round 4: free-running loop, every wave
  * meets the others once per key tile; 2 = two wave groups alternating matrix / vector blocks; 1 = one group; 3 = version 2 with wave priorities) */
 int cbx_set_attn_planes_version(int v);
@@ -498,6 +517,8 @@ typedef struct cbx_cfm_t {
     float *ra, *rb, *x, *v;               /* workspaces (rows, T, 256) x 3, estimator output (rows, T, 80) */
     cbx_planes_t aP, hP, qkP, attP, ffP, xP, yP, catP;   /* plane workspaces over rows * T rows: 256, 256, 1024, 512, 1024, 256, 256, 512 columns */
     cbx_planes_t vtP;                     /* V^T: (rows * 512) rows x (T rounded up to 8) columns, the padding zero */
+    int gemm_tile, attn_version;          /* ABI v13: cbx_gemm_pl_t.tile of every plane GEMM / version of every attention launch (0, 0 = the defaults;
+                                           * CBX_PL_TILE_CORESIDENT, 5 = the co-resident forms of the throughput schedule) */
 } cbx_cfm_t;
 int cbx_cfm_solve(const cbx_cfm_t* d, void* stream);
 

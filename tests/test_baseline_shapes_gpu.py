@@ -161,6 +161,10 @@ def test_flow_t1000_b2_vs_reference(dev, s3_sd, prec):
         err = (mel[b] - torch.from_numpy(g["mel"][b]).t()).abs()
         tol = TOL_MEL[prec]
         assert err.mean() <= tol[0] and err.max() <= tol[1], f"mode {prec} utt {b}: mel L1 {err.mean():.3e} max {err.max():.3e} (T = {2 * (P + N)})"
+    if prec == 16:  # the CO-RESIDENT forms of the throughput schedule (ABI v13: plane GEMMs on tile 17, the 4-wave plane attention): same arithmetic, same mel
+        eng.co_resident(True)
+        mel2 = eng.inference(toks, torch.tensor([N] * B), synth.s3gen_ref(n_prompt_tokens=P), z=z, n_steps=int(g["n_steps"])).cpu()
+        assert torch.equal(mel2, mel), f"co-resident kernel forms changed the mel: max |d| {(mel2 - mel).abs().max():.3e}"
 
 
 def _window_rmse(wav, g, b):

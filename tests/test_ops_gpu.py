@@ -600,6 +600,10 @@ def test_gemv_packed_rms_fused(dev, M, N, K, swiglu, nw):
         wp = ops.pack_gemv_weight(torch.cat([g, u]).to(dev), swiglu=True)
         ops.gemv(xp, wp, out, N=N, M=M, K=K, swiglu=True, nw=nw, w_packed=True, x_packed=True, norm_w=nwt.to(dev))
         ref = F.silu(F.linear(hn, g)) * F.linear(hn, u)
+        if nw >= 8:  # CBX_GEMV_SHALLOW (ABI v13): 2-deep load batches (<= 128 VGPRs: the co-resident form of the gate | up launch) -- same products, same order
+            sh = torch.empty(M, N, device=dev)
+            ops.gemv(xp, wp, sh, N=N, M=M, K=K, swiglu=True, nw=nw, w_packed=True, x_packed=True, norm_w=nwt.to(dev), flags=ops.GEMV_SHALLOW)
+            assert torch.equal(sh, out), "the shallow form must equal the default one bit for bit"
         # no-norm variants: packed W (+ packed x) == row-major image, bit for bit
         o1, o2, o3 = (torch.empty(M, N, device=dev) for _ in range(3))
         ops.gemv(x.to(dev), weights.pack_swiglu(g, u).to(dev), o1, swiglu=True, nw=nw)

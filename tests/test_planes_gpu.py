@@ -184,7 +184,7 @@ def test_layernorm_planes(dev):
     assert (out.float() - plain).abs().max() <= 2.0 ** -21 * plain.abs().max(), "planes = split of the fp32 LayerNorm kernel's result"
 
 
-@pytest.fixture(params=[2, 1, 3, 4])
+@pytest.fixture(params=[2, 1, 3, 4, 5])
 def attn_version(request):
     from chatterbox_amd import ops
     ops.lib.cbx_set_attn_planes_version(request.param)

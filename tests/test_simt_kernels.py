@@ -185,7 +185,7 @@ def test_gemm_planes_transposed_walk_small(emu, tile):
         emu.cbx_set_planes_persist(1)
 
 
-@pytest.mark.parametrize("version", [2, 1, 4])
+@pytest.mark.parametrize("version", [2, 1, 4, 5])
 def test_flash_attn_planes_small(emu, version):
     """tests/test_planes_gpu.py::test_flash_attn_planes at emulator-sized shapes (ragged key lengths incl. an empty utterance)."""
     import test_planes_gpu

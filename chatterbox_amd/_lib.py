@@ -190,6 +190,7 @@ _SIGS = {
     "cbx_layernorm_planes_f32": ([c_f, c_f, c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_long, c_float, c_int, c_float, c_f], c_int),
     "cbx_flash_attn_split_po": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 9 + [c_float, c_int, c_f], c_int),
     "cbx_flash_attn_planes": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_f], c_int),
+    "cbx_set_stream_coresident": ([c_f, c_int], c_int),
     "cbx_flash_attn_planes_v": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_set_attn_planes_version": ([c_int], c_int),
     "cbx_mlp_planes": ([c_f] * 7 + [c_int] * 3 + [c_long] * 9 + [c_int, c_f], c_int),

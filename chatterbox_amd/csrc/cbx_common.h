@@ -36,6 +36,17 @@ static inline int cbx_device() {
     return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
 }
 
+// ---- CO-RESIDENT streams (ABI v13, cbx_set_stream_coresident): a stream ATTRIBUTE, like its priority.  Launches on such a stream that would otherwise fill a CU
+// with several workgroups of one kernel (LayerNorm: 5 per CU; the split GEMM: 2) reserve enough dynamic LDS that at most `max_wg` fit, so that half of every
+// SIMD's register file stays free for the workgroups of another stream's latency-bound kernel chain (engine.synthesize_pipelined; profiles/r05_overlap_*).
+// Returns the dynamic LDS bytes to request for a kernel that itself needs `own` bytes per workgroup.
+int cbx_stream_coresident(hipStream_t st);
+static inline size_t cbx_coresident_lds(hipStream_t st, size_t own, int max_wg) {
+    if (!cbx_stream_coresident(st)) return own;
+    const size_t want = (size_t)(160 * 1024) / (size_t)(max_wg + 1) + 1024;  // more than a (max_wg + 1)-th of the CU's 160 KiB
+    return own > want ? own : want;
+}
+
 // ---- CBX_TRACE: launch-timeline instrumentation of a SIDE build (scripts/trace_decode.sh -> build/libcbx_hip_trace.so; the product library is
 // compiled without it and its instruction streams do not change).  Thread 0 of every workgroup of an instrumented kernel reads the chip-wide
 // 100 MHz counter (s_memrealtime) at up to 7 points and appends ONE 64-byte record {tag, t0 .. t6} to a device log at exit; the host sorts the

@@ -20,6 +20,30 @@ int cbx_check_launch(const char* what) {
 }
 
 extern "C" int cbx_abi_version(void) { return CBX_ABI_VERSION; }
+
+// co-resident streams (cbx_common.h): a handful of registered stream handles; registration happens once, before the stream is used
+static void* volatile g_cores_streams[16];
+extern "C" int cbx_set_stream_coresident(void* stream, int on) {
+    CBX_REQUIRE(stream != nullptr, "set_stream_coresident: the NULL stream cannot be marked (create a stream for the throughput schedule)");
+    int free_slot = -1;
+    for (int i = 0; i < 16; ++i) {
+        if (g_cores_streams[i] == stream) {
+            if (!on) g_cores_streams[i] = nullptr;
+            return 0;
+        }
+        if (free_slot < 0 && g_cores_streams[i] == nullptr) free_slot = i;
+    }
+    if (!on) return 0;
+    CBX_REQUIRE(free_slot >= 0, "set_stream_coresident: more than 16 co-resident streams");
+    g_cores_streams[free_slot] = stream;
+    return 0;
+}
+int cbx_stream_coresident(hipStream_t st) {
+    if (!st) return 0;
+    for (int i = 0; i < 16; ++i)
+        if (g_cores_streams[i] == (void*)st) return 1;
+    return 0;
+}
 extern "C" const char* cbx_last_error(void) { return cbx_err_buf; }
 
 namespace {

@@ -540,7 +540,8 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     int force = p.tile ? p.tile : g_pl_tile;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     if (force == CBX_PL_TILE_CORESIDENT) {    // one 8-wave workgroup per CU (96 KiB of LDS, <= 120 VGPRs); small grids / narrow outputs keep their forms (they never fill a CU)
         const long g128c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
-        force = (g128c < 64 || p.N <= 96) ? 0 : 17;
+        static const int co_k64 = getenv("CBX_PL_CORES_K64") ? atoi(getenv("CBX_PL_CORES_K64")) : 8;  // 8 = the 128 x 128 x 64 two-stage form (128 KiB, 8 waves x 117 VGPRs): 214.5x against 211.3x for form 17 in the throughput schedule, same box (A/B hook)
+        force = (g128c < 64 || p.N <= 96) ? 0 : (k64 ? co_k64 : 17);
     }
     // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log
     switch (force) {

@@ -394,12 +394,13 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
     static unsigned long long configured = 0;  // > 64 KiB of dynamic LDS has to be opted into once per kernel AND device (one bit per ordinal)
     const int dev = cbx_device();
     if (!(configured >> dev & 1)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return cbx_set_error((int)e, "gemm_split: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        const size_t most = lds > 96 * 1024 ? lds : 96 * 1024;  // (a co-resident stream asks for up to 81 KiB: one workgroup per CU)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+        if (e != hipSuccess) return cbx_set_error((int)e, "gemm_split: cannot reserve %zu B of LDS: %s", most, hipGetErrorString(e));
         configured |= 1ull << dev;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz1 * p.nz2);
-    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds, st, p, cbx_range_flag());
+    hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), cbx_coresident_lds(st, lds, 1), st, p, cbx_range_flag());
     return cbx_check_launch("gemm_split");
 }
 

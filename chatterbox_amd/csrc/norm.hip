@@ -188,14 +188,14 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     static const int narrow = getenv("CBX_LN_NARROW") ? atoi(getenv("CBX_LN_NARROW")) : 1;
     if (narrow && C == 256 && rows >= 64) {
         if (narrow == 2)
-            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 2>), dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 2>), dim3((unsigned)((rows + 31) / 32)), dim3(256), cbx_coresident_lds((hipStream_t)stream, 0, 2), (hipStream_t)stream, x, y, w,
                                b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
         else
-            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, y, w,
+            hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1>), dim3((unsigned)((rows + 15) / 16)), dim3(256), cbx_coresident_lds((hipStream_t)stream, 0, 2), (hipStream_t)stream, x, y, w,
                                b, post_add, rows, ldx, ldy, eps, rms, act, out_scale);
         return cbx_check_launch("layernorm");
     }
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b,
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cbx_coresident_lds((hipStream_t)stream, 0, 2), (hipStream_t)stream, x, y, w, b,
                        post_add, rows, C, ldx, ldy, eps, rms, act, out_scale);
     return cbx_check_launch("layernorm");
 }
@@ -205,7 +205,7 @@ extern "C" int cbx_layernorm_planes_f32(const float* x, void* planes, const floa
     CBX_REQUIRE(x && planes && w, "layernorm_planes: null operand");
     CBX_REQUIRE(C == 256 && ldx % 4 == 0 && ldp % 4 == 0 && p_lo % 4 == 0, "layernorm_planes: C must be 256 (got %d); strides multiples of 4", C);
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1, false, true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL((layernorm_narrow_kernel<4, 1, false, true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), cbx_coresident_lds((hipStream_t)stream, 0, 2), (hipStream_t)stream, x,
                        reinterpret_cast<float*>(planes), w, b, post_add, rows, ldx, ldp, eps, 0, act, out_scale, p_lo, cbx_range_flag());
     return cbx_check_launch("layernorm_planes");
 }

@@ -142,7 +142,7 @@ class ChatterboxEngine:
         self.flow.co_resident(on)
 
     @torch.inference_mode()
-    def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, **kw):
+    def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, t3_in_flight=2, **kw):
         """Throughput mode for a stream of batches: T3 of batch k+1 runs on a high-priority HIP stream WHILE the flow
         matching + vocoder of batch k run on a second stream.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields
         (wavs, tokens, latency_s) per job in order.  Results are identical to synthesize() called per job.
@@ -160,10 +160,20 @@ class ChatterboxEngine:
         torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
         if not hasattr(self, "_s_t3"):
             self._s_t3 = torch.cuda.Stream(device=self.dev, priority=-1)
+            self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=-1) for _ in range(2)]  # one per T3 state in flight
             self._s_voc = torch.cuda.Stream(device=self.dev)
         t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
                                     "ban_from") if k in kw}
+        if os.environ.get("CBX_PIPE_CORES") is not None:  # A/B hook
+            co_resident = os.environ["CBX_PIPE_CORES"] != "0"
         self.co_resident(bool(co_resident))
+        # ... and the flow + vocoder stream carries the co-resident ATTRIBUTE: its LayerNorm / split-GEMM launches (encoder, vocoder) keep to one or two
+        # workgroups per CU as well (cbx_set_stream_coresident; no effect on results)
+        from ._lib import check, lib
+        # (with TWO T3 batches in flight the flow stream is the critical one and T3 has slack: capping its short LayerNorm launches costs more than the
+        # decode chains gain -- 217.2x with the attribute, 220.8x without, same box; it stays on for t3_in_flight = 1.  CBX_PIPE_STREAM_ATTR: A/B hook)
+        attr = bool(co_resident) and os.environ.get("CBX_PIPE_STREAM_ATTR", "1" if t3_in_flight < 2 else "0") != "0"
+        check(lib.cbx_set_stream_coresident(self._s_voc.cuda_stream, int(attr)), "cbx_set_stream_coresident")
         torch.cuda.synchronize()
 
         def enqueue_t3(job, box):
@@ -174,40 +184,85 @@ class ChatterboxEngine:
             except BaseException as e:  # re-raised by the consumer thread
                 box["error"] = e
 
-        pending = None  # (job, speech tokens, t_start)
-        for k in range(len(jobs) + 1):
-            box, th = {}, None
-            if k < len(jobs):
-                t_start = time.perf_counter()
-                if host_threads:
-                    th = threading.Thread(target=enqueue_t3, args=(jobs[k], box), name="cbx-t3-enqueue")
-                    th.start()
-                else:
+        def voc_of(job, st):
+            with torch.cuda.stream(self._s_voc):
+                def voc():
+                    wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
+                                          n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
+                                          drop_last_token=kw.get("drop_last_token", True), sync=False)
+                    return [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
+                return _range_checked(self, voc)
+
+        def tokens_of(toks):
+            st = [drop_invalid_tokens(t) for t in toks]
+            return [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
+
+        if not host_threads:  # round 4's form: one host thread enqueues T3(k + 1), then flow + vocoder(k)
+            pending = None  # (job, speech tokens, t_start)
+            for k in range(len(jobs) + 1):
+                box = {}
+                if k < len(jobs):
+                    t_start = time.perf_counter()
                     enqueue_t3(jobs[k], box)
-            try:
+                    if "error" in box:
+                        raise box["error"]
                 if pending is not None:
                     job, st, t0 = pending
-                    with torch.cuda.stream(self._s_voc):
-                        def voc():
-                            wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"),
-                                                  n_cfm_timesteps=kw.get("n_cfm_timesteps", 10),
-                                                  drop_last_token=kw.get("drop_last_token", True), sync=False)
-                            return [w.cpu() for w in wavs]  # D2H on the vocoder stream: returns when this batch's audio is on the host
-                        host = _range_checked(self, voc)
-            finally:
-                if th is not None:
-                    th.join()
-            if "error" in box:
-                raise box["error"]
-            if pending is not None:
+                    host = voc_of(job, st)
+                    yield host, st, time.perf_counter() - t0
+                pending = None
+                if "handle" in box:
+                    with torch.cuda.stream(self._s_t3):
+                        toks = self.t3.collect(box["handle"])
+                    pending = (jobs[k], tokens_of(toks), t_start)
+            return
+
+        # ---- two host threads, two T3 states: the worker enqueues T3(k) into state k % 2 as soon as batch k - 2's tokens were collected, so the T3 stream
+        #      runs T3(0), T3(1), ... back to back (the Python prologue of a generate() call -- conditioning, embeddings, ~10 ms -- and the per-batch host
+        #      round trip are off its critical path); this thread waits for T3(k)'s END EVENT on the vocoder stream, fetches its tokens there (a copy on the
+        #      T3 stream would queue behind T3(k + 1)) and enqueues flow + vocoder(k) beside T3(k + 1).
+        import queue
+        n_t3 = max(1, min(3, int(os.environ.get("CBX_PIPE_T3_STREAMS", t3_in_flight))))
+        q, stop = queue.Queue(), threading.Event()
+        n_slots = max(2, n_t3)
+        slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
+
+        def worker():
+            try:
+                torch.cuda.set_device(self.dev)
+                for k, job in enumerate(jobs):
+                    slot_free[k % n_slots].acquire()
+                    if stop.is_set():
+                        return
+                    t_start = time.perf_counter()
+                    with torch.inference_mode(), torch.cuda.stream(self._s_t3x[k % n_t3]):
+                        h = self.t3.generate(job["t3_conds"], job["text_tokens"], async_mode=True, uniforms=job.get("uniforms"), slot=k % n_slots, **t3_kw)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    q.put((h, ev, t_start))
+            except BaseException as e:  # re-raised by the consumer thread
+                q.put(e)
+
+        th = threading.Thread(target=worker, name="cbx-t3-enqueue", daemon=True)
+        th.start()
+        try:
+            for k, job in enumerate(jobs):
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                h, ev, t0 = item
+                with torch.cuda.stream(self._s_voc):
+                    self._s_voc.wait_event(ev)
+                    toks = self.t3.collect(h)  # blocks this thread until T3(k) is done; T3(k + 1) is already enqueued behind it
+                slot_free[k % n_slots].release()
+                st = tokens_of(toks)
+                host = voc_of(job, st)
                 yield host, st, time.perf_counter() - t0
-            pending = None
-            if "handle" in box:
-                with torch.cuda.stream(self._s_t3):
-                    toks = self.t3.collect(box["handle"])
-                st = [drop_invalid_tokens(t) for t in toks]
-                st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
-                pending = (jobs[k], st, t_start)
+        finally:
+            stop.set()
+            for sem in slot_free:
+                sem.release()
+            th.join()
 
 
 def _stream_plan(n_tokens, done, exhausted, lookahead):

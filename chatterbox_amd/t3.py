@@ -728,7 +728,9 @@ class T3Engine:
             saved = {k: st[k].clone() for k in ("seen", "step", "done", "n_generated", "out_tokens", "next_ids",
                                                 "next_pos_ids", "positions", "ctx_lens", "logits")}
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: a capture on the T3-enqueue thread of synthesize_pipelined must not make the OTHER host thread's allocations / launches
+            # (flow + vocoder of the previous batch, on their own stream) illegal
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._decode_step(st)
             for k, v in saved.items():  # the capture warm-up must not leak into the real sequence
                 st[k].copy_(v)

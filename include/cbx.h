@@ -143,6 +143,10 @@ typedef struct cbx_gemm_pl_t {
     int tile;
 } cbx_gemm_pl_t;
 #define CBX_PL_TILE_CORESIDENT (-1)
+/* ABI v13: a stream ATTRIBUTE (like its priority): launches on a co-resident stream that would otherwise put several workgroups of one kernel on a CU
+ * (LayerNorm, the split-operand GEMM of the encoder / vocoder) reserve enough LDS that at most one or two fit, so half of every SIMD's register file stays free
+ * for another stream's kernels.  No effect on results.  Mark a stream once, before using it (ChatterboxEngine marks its flow + vocoder stream). */
+int cbx_set_stream_coresident(void* stream, int on);
 int cbx_gemm_planes(const cbx_gemm_pl_t* p, void* stream);
 /* tuning knob: tile shape of cbx_gemm_planes (0 = automatic; see gemm_planes.hip) */
 int cbx_set_planes_tile(int t);

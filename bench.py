@@ -253,7 +253,7 @@ def pmc_traffic(kernel_substr, source="flow_only"):
     import csv
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
+        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r05", "r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
         if f is None:
             return None, None
         used = os.path.basename(f)[:3]

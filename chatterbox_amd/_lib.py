@@ -121,7 +121,7 @@ class CfmStage(ctypes.Structure):  # cbx_cfm_stage_t
 
 
 class CfmSolve(ctypes.Structure):  # cbx_cfm_t
-    _fields_ = ([(k, c_int) for k in ("n_stages", "rows", "B", "n_steps", "cfg", "fused_qkv", "fused_mlp")]
+    _fields_ = ([(k, c_int) for k in ("n_stages", "rows", "B", "n_steps", "cfg", "fused_qkv", "reserved1")]
                 + [("T", c_long), ("cfg_rate", c_float), ("dt", ctypes.POINTER(c_float)), ("stages", ctypes.POINTER(CfmStage)),
                    ("fin_c", PlanesRef), ("fin_proj", PlanesRef)]
                 + [(k, c_f) for k in ("fin_c_b", "fin_n_w", "fin_n_b", "fin_proj_b", "tbias", "lens", "xin")]
@@ -193,7 +193,6 @@ _SIGS = {
     "cbx_set_stream_coresident": ([c_f, c_int], c_int),
     "cbx_flash_attn_planes_v": ([c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_int, c_f], c_int),
     "cbx_set_attn_planes_version": ([c_int], c_int),
-    "cbx_mlp_planes": ([c_f] * 7 + [c_int] * 3 + [c_long] * 9 + [c_int, c_f], c_int),
     "cbx_row_stats_f32": ([c_f, c_f, c_long, c_int, c_long, c_float, c_f], c_int),
     "cbx_softmax_relpos_f32": ([c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_float, c_f], c_int),
     "cbx_act_f32": ([c_f, c_f, c_f, c_long, c_int, c_long, c_long, c_int, c_float, c_f], c_int),

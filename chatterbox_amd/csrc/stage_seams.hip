@@ -92,9 +92,6 @@ struct CfmCtx {
             return rc;
         if ((rc = linear(d->attP, t.wo, 256, 512, x, nullptr, t.bo, x, CBX_ACT_NONE))) return rc;
         if ((rc = ln_planes(x, d->hP, t.n3_w, t.n3_b, nullptr, CBX_ACT_NONE))) return rc;
-        if (d->fused_mlp)
-            return cbx_mlp_planes(d->hP.p, t.w1.p, t.w2.p, t.b1, t.b2, x, outP ? outP->p : nullptr, (int)M, 256, 1024, d->hP.ld, d->hP.lo, t.w1.ld, t.w1.lo,
-                                  t.w2.ld, t.w2.lo, 256, outP ? outP->ld : 0, outP ? outP->lo : 0, outP ? 0 : 1, stream);
         if ((rc = linear(d->hP, t.w1, 1024, 256, nullptr, &d->ffP, t.b1, nullptr, CBX_ACT_GELU_ERF))) return rc;
         return linear(d->ffP, t.w2, 256, 1024, outP ? nullptr : x, outP, t.b2, x, CBX_ACT_NONE);
     }

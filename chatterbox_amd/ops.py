@@ -79,7 +79,22 @@ def _f32(t, name):
     return t
 
 
-GEMM_PRECISION = 0  # cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued while set: 0 default, 1 exact, 3 / 6 split-bf16, 16 split-fp16
+# cbx_gemm_t.precision of every gemm()/linear()/conv1d() issued inside `with gemm_precision(p)`: 0 default, 1 exact, 3 / 6 split-bf16, 16 split-fp16.
+# PER HOST THREAD (round 5): synthesize_pipelined enqueues T3 (exact) on one thread while the flow + vocoder (16) are enqueued on another; a module
+# global would let the flow's scope leak into T3's conditioning / head GEMMs.  `ops.GEMM_PRECISION` reads the calling thread's value (module __getattr__).
+import threading as _threading
+
+_TLS = _threading.local()
+
+
+def _prec():
+    return getattr(_TLS, "prec", 0)
+
+
+def __getattr__(name):
+    if name == "GEMM_PRECISION":
+        return _prec()
+    raise AttributeError(name)
 
 
 GEMM_DIAG = 0  # cbx_gemm_t.reserved0: only read by a -DCBX_DIAG build of gemm_split.hip (scripts/diag_gemm.sh)
@@ -93,12 +108,10 @@ class gemm_precision:
         self.precision = int(precision)
 
     def __enter__(self):
-        global GEMM_PRECISION
-        self._prev, GEMM_PRECISION = GEMM_PRECISION, self.precision
+        self._prev, _TLS.prec = _prec(), self.precision
 
     def __exit__(self, *exc):
-        global GEMM_PRECISION
-        GEMM_PRECISION = self._prev
+        _TLS.prec = self._prev
 
 
 LN_FUSION = os.environ.get("CBX_LN_FUSION", "1") != "0"  # CFM transformer blocks: LayerNorm folded into the consuming Linear
@@ -153,12 +166,12 @@ def gemm(A, W, C, *, M, N, K, lda, ldw, ldc, bias=None, R=None, ldr=0, C2=None, 
     p.ldc, p.c_s1, p.c_s2 = ldc, c_s[0], c_s[1]
     p.ldr, p.r_s1, p.r_s2 = ldr, r_s[0], r_s[1]
     p.ldc2, p.c2_s1, p.c2_s2 = ldc2, c2_s[0], c2_s[1]
-    p.precision = GEMM_PRECISION
+    p.precision = _prec()
     p.reserved0 = GEMM_DIAG
     if ln is not None:  # (stats (M, 2), ln_w (K,), ln_b (K,)): LayerNorm folded into the A operand (ln_fusable())
         p.ln_stats, p.ln_w, p.ln_b = _p(_f32(ln[0], "ln stats")), _p(_f32(ln[1], "ln_w")), _p(_f32(ln[2], "ln_b"))
     nz = nz1 * nz2
-    split = GEMM_PRECISION in (3, 6, 16) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
+    split = _prec() in (3, 6, 16) and M > 32 and not w_kn and not swiglu and (taps == 1 or (Cin or K // taps) % 32 == 0)
     kind = "gemm_f32_skinny" if M <= 32 else ("gemm_split" if split else "gemm_f32")  # mirrors the dispatch in gemm_f32.hip
     _timed(kind, 2.0 * M * N * K * nz, 4.0 * nz * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_f32(ctypes.byref(p), _stream()), "cbx_gemm_f32"))
@@ -170,7 +183,7 @@ def ln_fusable(M, K, lda=None):
     statistics kernel: the CFM transformer blocks).  The library is asked (cbx_gemm_ln_fusable mirrors the dispatcher's own conditions:
     no forced tile / generic-loader knob, 31-bit byte offsets), so a tuning knob or a > 2 GiB activation falls back to layernorm + linear
     instead of raising."""
-    if not (GEMM_PRECISION == 16 and K == 256 and M > 32 and LN_FUSION):
+    if not (_prec() == 16 and K == 256 and M > 32 and LN_FUSION):
         return False
     return bool(lib.cbx_gemm_ln_fusable(int(M), int(K), int(K if lda is None else lda)))
 
@@ -270,7 +283,7 @@ def layernorm_planes(x, w, b, out, eps=1e-5, act=NONE, post_add=None, scale=1.0)
 
 # launch geometry of the plane-format kernels issued inside `with planes_geometry(tile, attn_version)` (cbx_gemm_pl_t.tile / the version argument of
 # cbx_flash_attn_planes_v: per-call descriptor fields since ABI v13, nothing process-wide); (0, 0) = the library's measured defaults
-_PLANES_GEOM = [0, 0]
+_PLANES_GEOM = [0, 0]  # (only the flow's own host thread enters planes_geometry)
 
 
 class planes_geometry:
@@ -327,18 +340,6 @@ def conv1d_planes(x, w, *, B, T, taps, cin, out=None, outp=None, bias=None, pad_
                 C=out, P=outp, bias=bias, R=residual, act=act, ldc=0 if out is None else out.stride(1), c_s1=0 if out is None else out.stride(0),
                 ldr=0 if residual is None else residual.stride(1), r_s1=0 if residual is None else residual.stride(0),
                 p_s1=0 if outp is None else T * outp.ld)
-
-
-def mlp_planes(h, w1, w2, b1, b2, x, outp=None, write_x=True):
-    """x (M, 256) fp32 (+)= W2 GELU(W1 h + b1) + b2 (one launch): h Planes (M, 256), w1 Planes (F, 256), w2 Planes (256, F); the result goes to x
-    (write_x) and / or to the Planes outp."""
-    M, D, F = h.rows, h.C, w1.rows
-    assert w1.C == D and w2.rows == D and w2.C == F and x.shape == (M, D) and x.stride(1) == 1
-    _timed("mlp_planes", 4.0 * M * D * F, 4.0 * (3 * M * D + 2 * D * F),
-           lambda: check(lib.cbx_mlp_planes(h.ptr, w1.ptr, w2.ptr, _p(b1), _p(b2), _p(_f32(x, "x")), None if outp is None else outp.ptr, M, D, F,
-                                            h.ld, h.lo, w1.ld, w1.lo, w2.ld, w2.lo, x.stride(0), 0 if outp is None else outp.ld,
-                                            0 if outp is None else outp.lo, int(write_x), _stream()), "cbx_mlp_planes"))
-    return x
 
 
 def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, causal=False, version=None):
@@ -464,8 +465,9 @@ def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
         assert t.stride(3) == 1 and t.stride(2) == 64
     args = (_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
             v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale, int(causal))
-    if GEMM_PRECISION in (3, 6, 16):  # same numerics policy as the GEMMs issued in this scope
-        fn = lambda: check(lib.cbx_flash_attn_split_f32(*args, GEMM_PRECISION, _stream()), "cbx_flash_attn_split_f32")
+    if _prec() in (3, 6, 16):  # same numerics policy as the GEMMs issued in this scope
+        prec = _prec()
+        fn = lambda: check(lib.cbx_flash_attn_split_f32(*args, prec, _stream()), "cbx_flash_attn_split_f32")
     else:
         fn = lambda: check(lib.cbx_flash_attn_f32(*args, _stream()), "cbx_flash_attn_f32")
     _timed("flash_attn_f32", 4.0 * Z * H * Tq * Tk * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * (2 * Tq + 2 * Tk), fn)

@@ -113,10 +113,6 @@ class FlowEngine:
         # CFM estimator on plane-format operands (round 3; gemm_planes.hip / attention_planes.hip): the f16x3 arithmetic with weights
         # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
         self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
-        # ff1 + GELU + ff2 + residual in one launch (cbx_mlp_planes): measured EQUAL to the two GEMMs it replaces at the bench shape (81.6 vs 80 us:
-        # with 64 tokens per workgroup it re-streams W1 / W2 through L2 -> LDS once per token tile, 640 MB per call) and 18-27 % SLOWER on the flow stage at
-        # batch 1 (profiles/r04_batch1_seams_and_fused_mlp.log) -- opt-in, not the default
-        self.fused_mlp = os.environ.get("CBX_FUSED_MLP", "0") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
         self._pw = None
         # the token encoder (flash rel-pos form) and the Euler loop (plane-format path) through the stage-level C entry points cbx_s3gen_encode /
@@ -397,11 +393,8 @@ class FlowEngine:
         ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=rows, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125, key_lens=lens)
         ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
         ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)
-        if self.fused_mlp:  # ff1 + GELU + ff2 + residual in one launch: the 1024-wide intermediate never leaves the chip
-            ops.mlp_planes(hP, pw["w1"], pw["w2"], tw["b1"], tw["b2"], x2, outp=outP, write_x=outP is None)
-        else:
-            ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
-            ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
+        ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
+        ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
 
     def _estimator_pl(self, xinP, rows, T, lens, tbias, ws):
         """ConditionalDecoder.forward (decoder.py:243-333) on plane operands: xinP Planes (rows*T, 320) -> ws['v'] (rows,T,80) fp32."""
@@ -471,7 +464,7 @@ class FlowEngine:
         ref = lambda P: PlanesRef(P.ptr, P.ld, P.lo)
         dt = (ctypes.c_float * n_steps)(*[float(t_span[k + 1] - t_span[k]) for k in range(n_steps)])
         assert tb.is_contiguous() and tb.shape == (n_steps, len(self.stages), 256) and lens_r.dtype == torch.int32 and lens_r.numel() == rows
-        d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.fused_mlp, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), int(self.fused_mlp), T
+        d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), T
         d.cfg_rate, d.dt = cfg_rate, dt
         d.gemm_tile, d.attn_version = int(self.gemm_tile), int(self.attn_version)
         d.tbias, d.lens, d.xin, d.xinP = ops._p(tb), ops._p(lens_r), ops._p(xin), ref(xinP)

@@ -271,15 +271,7 @@ int cbx_flash_attn_split_po(const float* q, const float* k, const float* v, void
                             int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                             long v_sb, long v_st, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
 
-/* Fused feed-forward of a CFM transformer block on plane-format operands, one launch:
- *     x[m][:] (+)= W2 . GELU_erf(W1 . h[m][:] + b1) + b2 + x[m][:]       D = 256, F % 128 == 0
- * h planes (M x D: the LayerNorm output, cbx_layernorm_planes_f32), w1 planes (F x D), w2 planes (D x F), x fp32 residual in / result out
- * (write_x) and / or the result in plane format (out_planes).  The F-wide intermediate stays on the chip.  Replaces FeedForward
- * (GELU(proj) -> Linear) + residual of BasicTransformerBlock (matcha/transformer.py:243-316; diffusers GELU = F.gelu, exact erf form). */
-int cbx_mlp_planes(const void* h, const void* w1, const void* w2, const float* b1, const float* b2, float* x, void* out_planes,
-                   int M, int D, int F, long ldh, long h_lo, long ldw1, long w1_lo, long ldw2, long w2_lo, long ldx, long ldp,
-                   long p_lo, int write_x, void* stream);
-
+/* (cbx_mlp_planes -- the fused feed-forward launch of ABI v7-v12 -- is gone: measured equal at B = 8 and 18-27 % behind at batch 1, no configuration wanted it) */
 /* Flash attention (head_dim 64, f16x3 arithmetic) on plane-format operands: q, k [token][d] planes as a cbx_gemm_planes P output holds them,
  * vt = V^T [d][token] planes (the v projection computed with swapped operands: A = W_v, W = the activations; row stride vt_sd >= Tk rounded
  * up to 8, tails finite), o [token][d] planes.  All strides / plane offsets in halves; heads are 64 columns (q, k, o) or 64 rows (vt) apart.
@@ -507,7 +499,7 @@ typedef struct cbx_cfm_stage_t {
  * Needs T even, rows * T > 32, (rows * T + 512) * 4096 < 2^31.  Sequences kernel-level entry points only (results bit-identical to issuing them one by one):
  * no allocation, no synchronisation, hipGraph-capturable. */
 typedef struct cbx_cfm_t {
-    int n_stages, rows, B, n_steps, cfg, fused_qkv, fused_mlp;
+    int n_stages, rows, B, n_steps, cfg, fused_qkv, reserved1;   /* reserved1: 0 (was fused_mlp, ABI v12) */
     long T;
     float cfg_rate;
     const float* dt;                      /* HOST [n_steps] */

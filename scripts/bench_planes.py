@@ -128,12 +128,6 @@ for ver in (1, 2, 3, 4):
 ops.lib.cbx_set_attn_planes_version(4)
 print(line, flush=True)
 
-# fused feed-forward
-hP2, w1P, w2P = ops.split_planes(torch.randn(M, 256, device=dev)), ops.split_planes(torch.randn(1024, 256, device=dev) * 0.05), ops.split_planes(torch.randn(256, 1024, device=dev) * 0.03)
-bb1, bb2, xx = torch.randn(1024, device=dev), torch.randn(256, device=dev), torch.randn(M, 256, device=dev)
-us = timeit(lambda: ops.mlp_planes(hP2, w1P, w2P, bb1, bb2, xx))
-print(f"fused mlp (ff1 + GELU + ff2 + residual): {us:6.1f} us  {4.0 * M * 256 * 1024 / us / 1e6:6.1f} TF fp32-equivalent", flush=True)
-
 # LayerNorm
 x = torch.randn(M, 256, device=dev)
 w1, b1, y, st = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.empty(M, 256, device=dev), torch.empty(M, 2, device=dev)

@@ -66,6 +66,24 @@ def test_gemm_precision_scope_nests_and_restores():
     assert ops.GEMM_PRECISION == 0
 
 
+def test_gemm_precision_scope_is_per_host_thread():
+    """synthesize_pipelined enqueues T3 (exact fp32) on a worker thread while the flow + vocoder are enqueued inside gemm_precision(16) on the caller's:
+    the scope must not leak across threads (it was a module global until round 5)."""
+    import threading
+    from chatterbox_amd import ops
+    seen = {}
+    with ops.gemm_precision(16):
+        def other():
+            seen["in_thread"] = ops.GEMM_PRECISION
+            with ops.gemm_precision(6):
+                seen["nested"] = ops.GEMM_PRECISION
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert ops.GEMM_PRECISION == 16
+    assert seen == {"in_thread": 0, "nested": 6} and ops.GEMM_PRECISION == 0
+
+
 def test_range_checked_repeats_at_bf16x6_and_restores(monkeypatch):
     """engine._range_checked (host logic of the default f16x3 numerics): a tripped range flag repeats the S3Gen work once at precision 6
     with a warning, the engines' precisions are restored, an untripped flag or check=False runs once."""

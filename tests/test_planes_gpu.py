@@ -236,30 +236,6 @@ def test_flash_attn_planes_forced_rescale(dev, attn_version):
     _close(out.float(), ref, 2e-5, "rescale branch")
 
 
-@pytest.mark.parametrize("M", [64, 1000, 16000 + 37])
-def test_mlp_planes_vs_fp64_and_vs_two_gemms(dev, M):
-    """The fused feed-forward (one launch) against fp64 on the values the planes hold, and against the two-GEMM form it replaces; fp32 output,
-    plane output, ragged M."""
-    from chatterbox_amd import ops
-    D, Fh = 256, 1024
-    h, w1, w2 = _r((M, D), 1), _r((Fh, D), 2, 1 / 16), _r((D, Fh), 3, 1 / 32)
-    b1, b2, x0 = _r((Fh,), 4, 0.5), _r((D,), 5, 0.5), _r((M, D), 6)
-    hP, w1P, w2P = ops.split_planes(h.to(dev)), ops.split_planes(w1.to(dev)), ops.split_planes(w2.to(dev))
-    mid = F.gelu(F.linear(_planes_exact(h), _planes_exact(w1), b1.double()))
-    ref = F.linear(_planes_exact(mid.float()), _planes_exact(w2), b2.double()) + x0.double()
-    x = x0.clone().to(dev)
-    ops.mlp_planes(hP, w1P, w2P, b1.to(dev), b2.to(dev), x)
-    _close(x, ref, 4e-5, f"fused mlp M={M}")
-    xb, outP = x0.clone().to(dev), ops.Planes(M, D, dev, zero=True)
-    ops.mlp_planes(hP, w1P, w2P, b1.to(dev), b2.to(dev), xb, outp=outP, write_x=False)
-    assert torch.equal(xb.cpu(), x0), "write_x = False leaves the residual untouched"
-    assert (outP.float() - x).abs().max() <= 2.0 ** -21 * x.abs().max()
-    ffP, x2 = ops.Planes(M, Fh, dev), x0.clone().to(dev)
-    ops.linear_planes(hP, w1P, outp=ffP, bias=b1.to(dev), act=ops.GELU_ERF)
-    ops.linear_planes(ffP, w2P, out=x2, bias=b2.to(dev), residual=x2)
-    assert (x - x2).abs().max() <= 2e-6 * (1 + x2.abs().max()), f"fused vs two GEMMs: {(x - x2).abs().max():.3e}"
-
-
 def test_estimator_planes_path_matches_fp32_operand_path(dev, monkeypatch):
     """The plane-format CFM estimator against the fp32-operand f16x3 path (CBX_PLANES = 0) of the same engine: the same arithmetic on the
     same operand values, so the mels agree far inside the parity tolerance; ragged batch of two."""

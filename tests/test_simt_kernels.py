@@ -197,11 +197,6 @@ def test_flash_attn_planes_small(emu, version):
         emu.cbx_set_attn_planes_version(4)  # the library default
 
 
-def test_mlp_planes_small(emu):
-    import test_planes_gpu
-    test_planes_gpu.test_mlp_planes_vs_fp64_and_vs_two_gemms(CPU, 64)
-
-
 def test_split_gemm_small(emu):
     """gemm_split.hip (encoder / HiFT / range-check fallback path): the three split precisions and the LayerNorm-folded loader, small shapes."""
     from chatterbox_amd import ops
@@ -447,7 +442,7 @@ def _rerun(env, select):
     return r.returncode, (r.stdout + r.stderr)[-1500:]
 
 
-_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or mlp_planes_small or conv_and_transposed_columns or transposed_walk"
+_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or conv_and_transposed_columns or transposed_walk"
 
 
 def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):
@@ -611,14 +606,14 @@ def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
 _SLOW = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="half a minute each: CBX_EMU_SLOW=1")
 
 
-@pytest.mark.parametrize("meanflow,T,fused_qkv,fused_mlp", [(False, 20, True, False), pytest.param(True, 34, True, False, marks=_SLOW), pytest.param(False, 18, True, False, marks=_SLOW),
-                                                            pytest.param(False, 20, True, True, marks=_SLOW), pytest.param(True, 36, True, False, marks=_SLOW)])
-def test_cfm_solve_c_entry_point_on_the_emulator(emu, meanflow, T, fused_qkv, fused_mlp):
+@pytest.mark.parametrize("meanflow,T,fused_qkv", [(False, 20, True), pytest.param(True, 34, True, marks=_SLOW), pytest.param(False, 18, True, marks=_SLOW),
+                                                  pytest.param(True, 36, True, marks=_SLOW)])
+def test_cfm_solve_c_entry_point_on_the_emulator(emu, meanflow, T, fused_qkv):
     """tests/test_zzz_stage_seams_gpu.py on the emulator: cbx_cfm_solve (ABI v12) against FlowEngine.cfm's own launch sequence, bit for bit -- one utterance,
     one mid stage, two Euler steps, CFG with the fused q | k | V^T projection; opt-in (CBX_EMU_SLOW=1, all pass): meanflow, the separate projection
-    (T % 4 != 0), the fused feed-forward."""
+    (T % 4 != 0)."""
     import test_zzz_stage_seams_gpu as S
-    S.test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(CPU, meanflow, T, fused_qkv, fused_mlp, n_mid=1, B=1, n_steps=2)
+    S.test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(CPU, meanflow, T, fused_qkv, n_mid=1, B=1, n_steps=2)
 
 
 @pytest.mark.parametrize("ragged,fade,precision", [(True, True, 16), pytest.param(False, False, 1, marks=_SLOW)])

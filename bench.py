@@ -675,6 +675,8 @@ def main():
             eng.t3.decode_events = []
             elapsed, (audio, lats) = timed(lambda: pipelined_run(args.steps, 0))
         except Exception as e:  # the headline must never be lost to the throughput schedule: fall back to the serial one and say so
+            if world > 1:  # (a rank-local fallback would desynchronise the C2 collectives of the other ranks: fail loudly instead)
+                raise
             fallback = f"{type(e).__name__}: {e}"[:300]
             log(f"pipelined schedule failed ({fallback}): falling back to the serial schedule")
             torch.cuda.synchronize()

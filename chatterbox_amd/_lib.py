@@ -47,6 +47,7 @@ class GemmPlParams(ctypes.Structure):
         ("ldc", c_long), ("c_s1", c_long), ("ldr", c_long), ("r_s1", c_long), ("ldp", c_long), ("p_lo", c_long), ("p_s1", c_long), ("reserved0", c_int),
         ("PT", c_f), ("pt_n0", c_int), ("pt_T", c_int), ("pt_ld", c_long), ("pt_lo", c_long), ("pt_zs", c_long),  # ABI v8
         ("tile", c_int),  # ABI v13: this call's tile form (0 automatic, -1 = PL_TILE_CORESIDENT)
+        ("ln_w", c_f), ("ln_b", c_f), ("LNP", c_f), ("ld_lnp", c_long), ("lnp_lo", c_long), ("lnp_s1", c_long), ("ln_eps", c_float),  # ABI v13: LayerNorm epilogue
     ]
 
 
@@ -121,7 +122,7 @@ class CfmStage(ctypes.Structure):  # cbx_cfm_stage_t
 
 
 class CfmSolve(ctypes.Structure):  # cbx_cfm_t
-    _fields_ = ([(k, c_int) for k in ("n_stages", "rows", "B", "n_steps", "cfg", "fused_qkv", "reserved1")]
+    _fields_ = ([(k, c_int) for k in ("n_stages", "rows", "B", "n_steps", "cfg", "fused_qkv", "fused_ln")]
                 + [("T", c_long), ("cfg_rate", c_float), ("dt", ctypes.POINTER(c_float)), ("stages", ctypes.POINTER(CfmStage)),
                    ("fin_c", PlanesRef), ("fin_proj", PlanesRef)]
                 + [(k, c_f) for k in ("fin_c_b", "fin_n_w", "fin_n_b", "fin_proj_b", "tbias", "lens", "xin")]

@@ -119,6 +119,21 @@ __device__ __forceinline__ void pl_loader_wave(const cbx_gemm_pl_t& p, const lds
         }
 }
 
+// ---- LayerNorm of the finished row in the epilogue (round 5, cbx_gemm_pl_t.ln_w): the ROW-SPANNING tile 64 x 256 (N == 256: attention out-projection, ff2, 1x1
+// residual conv of the CFM estimator) finishes whole rows, so it can produce nn.LayerNorm(row) -- the input of the NEXT Linear -- itself: mean and variance of the
+// 256 finished values of a row (the 2 x 16 values a lane holds are reduced over its 16-lane DPP row, then over the 8 row pieces of the 4 N-waves through LDS), the two-pass
+// form of norm.hip (mean first, then the variance of the centred values), (v - mean) * rstd * w[n] + b[n], written in plane format by the same lane-pair exchange as the
+// plain plane output.  Replaces a cbx_layernorm_planes_f32 launch (16 MB read + 16 MB written per 16000 x 256) per Linear.
+constexpr int PL_ACT_LNF = 100;  // internal value of the ACT template parameter: "no activation, LayerNorm of the row to LNP"
+
+__device__ __forceinline__ float pl_row16_sum(float x) {  // all-reduce over the 16 lanes of a DPP row: quad xor 1, xor 2, then rotations by 4 and 8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true));  // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));  // row_ror:8
+    return x;
+}
+
 // LD > 0 = loader-wave form: the workgroup has LD EXTRA waves that do nothing but issue the DMAs of every K tile and wait for them; the
 // NWV consumer waves only read LDS, multiply and run the epilogue.  A vector-memory instruction costs its issuing wave 100-200 cycles while
 // the CU's address path is busy, and a wave issues in order: in the symmetric form every wave's MFMAs queue behind its own DMA issue
@@ -343,6 +358,87 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4, ldp2 = (int)p.ldp * 2;
     const bool odd = lr & 1;
     float amax = 0.f;
+    if constexpr (ACT == PL_ACT_LNF) {
+        static_assert(ACT != PL_ACT_LNF || (TM == 1 && BN == 256 && LD == 0 && WARPS_N * 2 == 8), "LayerNorm epilogue: 64 x 256 tile, 2 x 4 waves of 32 x 64");
+        float* const red = reinterpret_cast<float*>(smem + NS * STAGE_BYTES);  // [WARPS_M][8 row pieces][32 rows]
+        float* const stat = red + WARPS_M * 8 * 32;                              // [BM]: mean, then rstd
+        const __amdgpu_buffer_rsrc_t n_rs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<_Float16*>(p.LNP) + (long)z * p.lnp_s1, 0, (int)((((long)Mrem - 1) * p.ld_lnp + p.lnp_lo + p.N) * 2), 0x00020000);
+        const int mb = m0 + wm * WM + 4 * lh;  // row of register 0
+        // 1. the finished values (bias, residual), kept in the accumulator registers; fp32 output
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * WN + j * 32 + lr;  // (n0 == 0, N == 256: every column exists)
+            const float bia = p.bias ? p.bias[n] : 0.f;
+            const int ro = mb * ldr4 + n * 4, co = mb * ldc4 + n * 4;
+            float res[16];
+            if (hasR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, ro, ((r & 3) + 8 * (r >> 2)) * ldr4, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = __builtin_fmaf(accc[0][j][r], 1.0f / CBX_F16_LO_SCALE, acc[0][j][r]) + bia;
+                if (hasR) v += res[r];
+                acc[0][j][r] = v;
+                if (hasC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, co, ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+            }
+        }
+        // 2. mean, 3. variance of the centred values: lane -> 16-lane row -> the row's 8 pieces (4 N-waves x 2 DPP rows) through LDS
+        const int piece = (wm * 8 + wn * 2 + (lr >> 4)) * 32;
+        float st[16];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (pass) acc[0][j][r] -= st[r];  // centre on the mean of pass 0
+                    t += pass ? acc[0][j][r] * acc[0][j][r] : acc[0][j][r];
+                }
+                t = pl_row16_sum(t);
+                if ((lr & 15) == 0) red[piece + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
+            }
+            __syncthreads();
+            if (tid < BM) {
+                const float* rp = red + ((tid >> 5) * 8) * 32 + (tid & 31);
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += rp[q * 32];
+                stat[tid] = pass ? rsqrtf(t * (1.0f / 256.0f) + p.ln_eps) : t * (1.0f / 256.0f);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(stat + wm * WM + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[4 * g + e] = t4[e];
+            }
+        }
+        // 4. (v - mean) * rstd * w[n] + b[n] -> planes (the lane-pair exchange of the plain plane output)
+        const int ldn2 = (int)p.ld_lnp * 2, nlo2 = (int)p.lnp_lo * 2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * WN + j * 32 + lr, ne = n & ~1;
+            const float gw = p.ln_w[n], gb = p.ln_b ? p.ln_b[n] : 0.f;
+            const int po = mb * ldn2 + ne * 2 + (odd ? ldn2 : 0);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float y0 = __builtin_fmaf(acc[0][j][r] * st[r], gw, gb), y1 = __builtin_fmaf(acc[0][j][r + 1] * st[r + 1], gw, gb);
+                const float give = odd ? y0 : y1;
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                const float c0 = odd ? got : y0, c1 = odd ? y1 : got;  // columns ne, ne + 1 of this lane's row
+                unsigned h2, l2;
+                cbx_split2(c0, c1, h2, l2);
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(c0), "v"(c1));
+                const int so = ((r & 3) + 8 * (r >> 2)) * ldn2;
+                __builtin_amdgcn_raw_buffer_store_b32(h2, n_rs, po, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(l2, n_rs, po + nlo2, so, 0);
+            }
+        }
+        if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+    } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + lr;
@@ -426,6 +522,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         }
     }
         if ((hasP || vt_tile) && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+    }  // (plain epilogue)
     }  // tile loop
 }
 
@@ -453,7 +550,7 @@ int g_pl_persist = getenv("CBX_PL_PERSIST") ? atoi(getenv("CBX_PL_PERSIST")) : 1
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
 int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16;
+    constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16 + (ACT == PL_ACT_LNF ? (size_t)(WARPS_M * 8 * 32 + BM) * 4 : 0);  // + the LayerNorm epilogue's row pieces
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD>;
     constexpr int THREADS = (WARPS_M * WARPS_N + LD) * 64;
@@ -536,6 +633,14 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     CBX_REQUIRE((!p.C || p.ldc >= Np) && (!p.R || p.ldr >= Np) && (!p.P || (p.p_lo > 0 && p.ldp >= p.p_lo + Np)),
                 "gemm_planes: rows must not overlap (ldc, ldr >= N; plane output rows hold [h | l]: ldp >= p_lo + N)");
     hipStream_t st = (hipStream_t)stream;
+    if (p.ln_w) {  // LayerNorm of the finished row in the epilogue: the row-spanning 64 x 256 tile (one form; cbx_gemm_pl_t.tile does not apply)
+        CBX_REQUIRE(p.N == 256 && p.LNP && !p.P && !p.PT && p.act == CBX_ACT_NONE, "gemm_planes: the LayerNorm epilogue needs N == 256, LNP, no P / PT / activation (N=%d)", p.N);
+        CBX_REQUIRE((p.ld_lnp | p.lnp_lo | p.lnp_s1) % 2 == 0 && ((uintptr_t)p.LNP & 3) == 0 && p.lnp_lo > 0 && p.ld_lnp >= p.lnp_lo + 256 &&
+                        ((long)p.M * p.ld_lnp + p.lnp_lo + 256) * 2 < 0x7fffffffL && ((uintptr_t)p.ln_w & 3) == 0,
+                    "gemm_planes: LayerNorm planes need even strides, ld_lnp >= lnp_lo + 256, less than 2 GiB per batch");
+        return launch_pl_act<64, 256, 2, 4, 32, 3, PL_ACT_LNF, 0>(p, st);
+    }
+    CBX_REQUIRE(!p.LNP, "gemm_planes: LNP without ln_w");
     const bool k64 = p.Cin % 64 == 0;
     int force = p.tile ? p.tile : g_pl_tile;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     if (force == CBX_PL_TILE_CORESIDENT) {    // one 8-wave workgroup per CU (96 KiB of LDS, <= 120 VGPRs); small grids / narrow outputs keep their forms (they never fill a CU)

@@ -35,7 +35,7 @@ struct CfmCtx {
     }
     // F.linear over all M rows as one batch (ops.linear_planes)
     int linear(const cbx_planes_t& x, const cbx_planes_t& w, int N, int K, float* out, const cbx_planes_t* outp, const float* bias, const float* R,
-               int act) const {
+               int act, const float* ln_w = nullptr, const float* ln_b = nullptr, const cbx_planes_t* lnp = nullptr) const {
         cbx_gemm_pl_t g{};
         g.A = x.p, g.W = w.p, g.C = out, g.P = outp ? outp->p : nullptr, g.bias = bias, g.R = R;
         g.M = (int)M, g.N = N, g.K = K, g.Cin = K, g.taps = 1, g.dil = 1, g.stride = 1, g.nz1 = 1;
@@ -45,6 +45,7 @@ struct CfmCtx {
         if (R) g.ldr = N;
         if (outp) g.ldp = outp->ld, g.p_lo = outp->lo;
         g.tile = d->gemm_tile;
+        if (ln_w) g.ln_w = ln_w, g.ln_b = ln_b, g.LNP = lnp->p, g.ld_lnp = lnp->ld, g.lnp_lo = lnp->lo, g.ln_eps = 1e-5f;  // LayerNorm of the finished row (ops.linear_planes(ln=...))
         return cbx_gemm_planes(&g, stream);
     }
     int ln_planes(const float* x, const cbx_planes_t& out, const float* w, const float* b, const float* post_add, int act) const {
@@ -63,10 +64,11 @@ struct CfmCtx {
 
     // BasicTransformerBlock (matcha/transformer.py:243-316, diffusers Attention / GELU): d->x updated in place, or -- the LAST block of a stage -- written
     // in plane format only (outP)
-    int tblock(const cbx_cfm_tblock_t& t, const cbx_planes_t* outP) const {
+    // fused_ln: norm3 from the out-projection's epilogue, the NEXT block's norm1 (`next`) from ff2's; `pre_normed`: d->hP already holds norm1(x)
+    int tblock(const cbx_cfm_tblock_t& t, const cbx_planes_t* outP, bool pre_normed, const cbx_cfm_tblock_t* next) const {
         int rc;
         float* x = d->x;
-        if ((rc = ln_planes(x, d->hP, t.n1_w, t.n1_b, nullptr, CBX_ACT_NONE))) return rc;
+        if (!pre_normed && (rc = ln_planes(x, d->hP, t.n1_w, t.n1_b, nullptr, CBX_ACT_NONE))) return rc;
         if (d->fused_qkv && T % 4 == 0) {  // to_q | to_k | to_v as ONE Linear; the v columns are stored transposed per row group
             cbx_gemm_pl_t g{};
             g.A = d->hP.p, g.W = t.wqkv.p, g.P = d->qkP.p;
@@ -90,16 +92,24 @@ struct CfmCtx {
         if ((rc = cbx_flash_attn_planes_v(q.p, k.p, d->vtP.p, d->attP.p, d->lens, rows, 8, (int)T, (int)T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo,
                                           512 * d->vtP.ld, d->vtP.ld, d->vtP.lo, T * d->attP.ld, d->attP.ld, d->attP.lo, 0.125f, 0, d->attn_version, stream)))
             return rc;
-        if ((rc = linear(d->attP, t.wo, 256, 512, x, nullptr, t.bo, x, CBX_ACT_NONE))) return rc;
-        if ((rc = ln_planes(x, d->hP, t.n3_w, t.n3_b, nullptr, CBX_ACT_NONE))) return rc;
+        if (d->fused_ln) {
+            if ((rc = linear(d->attP, t.wo, 256, 512, x, nullptr, t.bo, x, CBX_ACT_NONE, t.n3_w, t.n3_b, &d->hP))) return rc;
+        } else {
+            if ((rc = linear(d->attP, t.wo, 256, 512, x, nullptr, t.bo, x, CBX_ACT_NONE))) return rc;
+            if ((rc = ln_planes(x, d->hP, t.n3_w, t.n3_b, nullptr, CBX_ACT_NONE))) return rc;
+        }
         if ((rc = linear(d->hP, t.w1, 1024, 256, nullptr, &d->ffP, t.b1, nullptr, CBX_ACT_GELU_ERF))) return rc;
+        if (next) return linear(d->ffP, t.w2, 256, 1024, x, nullptr, t.b2, x, CBX_ACT_NONE, next->n1_w, next->n1_b, &d->hP);
         return linear(d->ffP, t.w2, 256, 1024, outP ? nullptr : x, outP, t.b2, x, CBX_ACT_NONE);
     }
 
     int block(int k, const cbx_planes_t& inP, const cbx_planes_t& outP, const float* tbias) const {
         const cbx_cfm_stage_t& s = d->stages[k];
         int rc = resnet(s, inP, tbias + (long)k * 256);
-        for (int j = 0; !rc && j < s.n_tb; ++j) rc = tblock(s.tb[j], j == s.n_tb - 1 ? &outP : nullptr);
+        for (int j = 0; !rc && j < s.n_tb; ++j) {
+            const bool last = j == s.n_tb - 1;
+            rc = tblock(s.tb[j], last ? &outP : nullptr, d->fused_ln >= 2 && j > 0, (d->fused_ln >= 2 && !last) ? &s.tb[j + 1] : nullptr);
+        }
         return rc;
     }
 

@@ -299,9 +299,11 @@ class planes_geometry:
 
 
 def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, act_slope=0.0, alpha=1.0, lens=None, Cin=0, taps=1, dil=1,
-                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0, PT=None, pt_n0=0, pt_T=0, pt_zs=0, tile=None):
+                stride=1, pad_left=0, Tin=0, nz1=1, a_s1=0, w_s1=0, ldc=0, c_s1=0, ldr=0, r_s1=0, p_s1=0, PT=None, pt_n0=0, pt_T=0, pt_zs=0, tile=None,
+                ln=None, lnp=None, lnp_s1=0, ln_eps=1e-5):
     """Raw access to cbx_gemm_planes (include/cbx.h): A, W, P are Planes operands, C / R fp32 tensors (their data_ptr() is the base).
-    PT (Planes over (groups * (N - pt_n0), >= pt_T) rows): output columns n >= pt_n0 are written TRANSPOSED per group of pt_T rows."""
+    PT (Planes over (groups * (N - pt_n0), >= pt_T) rows): output columns n >= pt_n0 are written TRANSPOSED per group of pt_T rows.
+    ln = (w, b) + lnp (Planes, N == 256): the epilogue also writes LayerNorm(C row) * w + b to lnp (ABI v13: replaces a layernorm_planes launch)."""
     p = GemmPlParams()
     p.A, p.W, p.C, p.P = A.ptr, W.ptr, _p(C), None if P is None else P.ptr
     p.bias, p.R, p.lens = _p(bias), _p(R), _p(lens)
@@ -317,18 +319,22 @@ def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, a
         p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
     p.reserved0 = GEMM_DIAG
     p.tile = _PLANES_GEOM[0] if tile is None else int(tile)
+    if ln is not None:
+        assert lnp is not None and N == 256
+        p.ln_w, p.ln_b, p.LNP, p.ld_lnp, p.lnp_lo, p.lnp_s1, p.ln_eps = _p(_f32(ln[0], "ln_w")), _p(ln[1]), lnp.ptr, lnp.ld, lnp.lo, lnp_s1, ln_eps
     if PT is not None:
         p.PT, p.pt_n0, p.pt_T, p.pt_ld, p.pt_lo, p.pt_zs = PT.ptr, pt_n0, pt_T, PT.ld, PT.lo, pt_zs
     _timed("gemm_planes", 2.0 * M * N * K * nz1, 4.0 * nz1 * (M * K / max(1, taps) + N * K + M * N),
            lambda: check(lib.cbx_gemm_planes(ctypes.byref(p), _stream()), "cbx_gemm_planes"))
 
 
-def linear_planes(x, w, *, out=None, outp=None, bias=None, act=NONE, residual=None, act_slope=0.0):
-    """epilogue(x @ w^T) for Planes x (M, K), w (N, K): fp32 `out` (M, N) and / or Planes `outp`; residual fp32 (may alias out)."""
+def linear_planes(x, w, *, out=None, outp=None, bias=None, act=NONE, residual=None, act_slope=0.0, ln=None, lnp=None):
+    """epilogue(x @ w^T) for Planes x (M, K), w (N, K): fp32 `out` (M, N) and / or Planes `outp`; residual fp32 (may alias out).
+    ln = (w, b), lnp (Planes (M, 256)): LayerNorm of the finished row to lnp as well (N == 256)."""
     M, K, N = x.rows, x.C, w.rows
     assert w.C == K and (out is not None or outp is not None)
     gemm_planes(x, w, M=M, N=N, K=K, C=out, P=outp, bias=bias, R=residual, act=act, act_slope=act_slope,
-                ldc=0 if out is None else out.stride(0), ldr=0 if residual is None else residual.stride(0))
+                ldc=0 if out is None else out.stride(0), ldr=0 if residual is None else residual.stride(0), ln=ln, lnp=lnp)
 
 
 def conv1d_planes(x, w, *, B, T, taps, cin, out=None, outp=None, bias=None, pad_left=0, lens=None, act=NONE, residual=None):

@@ -114,6 +114,10 @@ class FlowEngine:
         # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
         self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
+        # LayerNorm produced by the epilogue of the N = 256 Linear in front of it (cbx_gemm_pl_t.ln_w, ABI v13).  1 (default): norm3 from the attention
+        # out-projection (K = 512: 33.4 -> 28.8 us for Linear + LayerNorm, same box); 2: also the NEXT block's norm1 from ff2 (K = 1024: the row-spanning 64 x 256
+        # tile is 14 us behind the 4-loader 128 x 128 form there, so 38.1 -> 44.0 us: not the default); 0: LayerNorm launches of their own (rounds 3-4)
+        self.fused_ln = int(os.environ.get("CBX_FUSED_LN", "1"))
         self._pw = None
         # the token encoder (flash rel-pos form) and the Euler loop (plane-format path) through the stage-level C entry points cbx_s3gen_encode /
         # cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python sequencing below -- bit-identical results on the MI355X:
@@ -377,12 +381,15 @@ class FlowEngine:
         cv(inP, pw["res"], cin, taps=1, out=x, bias=sw["res"][1], residual=b)
         return x
 
-    def _tblock_pl(self, tw, pw, x, rows, T, lens, ws, outP=None):
+    def _tblock_pl(self, tw, pw, x, rows, T, lens, ws, outP=None, pre_normed=False, next_ln=None):
         """BasicTransformerBlock on plane operands.  x (rows,T,256) fp32 residual stream, updated in place -- except by the LAST block of a
-        stage (outP given): its result only feeds convolutions, so it is written in plane format alone."""
+        stage (outP given): its result only feeds convolutions, so it is written in plane format alone.
+        fused_ln (round 5, cbx_gemm_pl_t.ln_w): norm3 is produced by the out-projection's epilogue and the NEXT block's norm1 (`next_ln`) by ff2's -- the
+        row-spanning 64 x 256 tile finishes whole rows -- so a block launches no LayerNorm of its own (`pre_normed`: hP already holds norm1(x))."""
         M = rows * T
         x2, hP, qkP, vtP, attP, ffP = x.view(M, 256), ws["hP"], ws["qkP"], ws["vtP"], ws["attP"], ws["ffP"]
-        ops.layernorm_planes(x2, tw["n1"][0], tw["n1"][1], hP, 1e-5)
+        if not pre_normed:
+            ops.layernorm_planes(x2, tw["n1"][0], tw["n1"][1], hP, 1e-5)
         if self.fused_qkv and T % 4 == 0:
             # to_q | to_k | to_v as ONE Linear: the q | k columns go to qkP, the v columns are stored transposed (V^T[z] = 512 x T per row group of T)
             ops.gemm_planes(hP, pw["wqkv"], M=M, N=1536, K=256, P=qkP, PT=vtP, pt_n0=1024, pt_T=T, pt_zs=512 * vtP.ld)
@@ -391,10 +398,13 @@ class FlowEngine:
             # V^T[z] (512 x T) = W_v h[z]^T: the same products with the operands swapped, so the store is the transposed tile
             ops.gemm_planes(pw["wv"], hP, M=512, N=T, K=256, nz1=rows, w_s1=T * hP.ld, P=vtP, p_s1=512 * vtP.ld)
         ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=rows, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125, key_lens=lens)
-        ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
-        ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)
+        if self.fused_ln:
+            ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2, ln=tw["n3"], lnp=hP)
+        else:
+            ops.linear_planes(attP, pw["wo"], out=x2, bias=tw["bo"], residual=x2)
+            ops.layernorm_planes(x2, tw["n3"][0], tw["n3"][1], hP, 1e-5)
         ops.linear_planes(hP, pw["w1"], outp=ffP, bias=tw["b1"], act=ops.GELU_ERF)
-        ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2)
+        ops.linear_planes(ffP, pw["w2"], out=x2 if outP is None else None, outp=outP, bias=tw["b2"], residual=x2, ln=next_ln, lnp=hP if next_ln is not None else None)
 
     def _estimator_pl(self, xinP, rows, T, lens, tbias, ws):
         """ConditionalDecoder.forward (decoder.py:243-333) on plane operands: xinP Planes (rows*T, 320) -> ws['v'] (rows,T,80) fp32."""
@@ -404,8 +414,11 @@ class FlowEngine:
 
         def block(k, inP, cin, outP):
             x = self._resnet_pl(st[k], pws[k], inP, cin, rows, T, tbias[k], ws)
-            for j, (tw, pw) in enumerate(zip(st[k]["tb"], pws[k]["tb"])):
-                self._tblock_pl(tw, pw, x, rows, T, lens, ws, outP if j == len(st[k]["tb"]) - 1 else None)
+            tbs = st[k]["tb"]
+            for j, (tw, pw) in enumerate(zip(tbs, pws[k]["tb"])):
+                last = j == len(tbs) - 1
+                self._tblock_pl(tw, pw, x, rows, T, lens, ws, outP if last else None, pre_normed=self.fused_ln >= 2 and j > 0,
+                                next_ln=tbs[j + 1]["n1"] if (self.fused_ln >= 2 and not last) else None)
 
         skip, xh = catP.cols(256, 256), catP.cols(0, 256)  # [x | skip] of the up block: both halves are written in place by their producers
         block(0, xinP, 320, skip)
@@ -464,7 +477,7 @@ class FlowEngine:
         ref = lambda P: PlanesRef(P.ptr, P.ld, P.lo)
         dt = (ctypes.c_float * n_steps)(*[float(t_span[k + 1] - t_span[k]) for k in range(n_steps)])
         assert tb.is_contiguous() and tb.shape == (n_steps, len(self.stages), 256) and lens_r.dtype == torch.int32 and lens_r.numel() == rows
-        d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), T
+        d.rows, d.B, d.n_steps, d.cfg, d.fused_qkv, d.fused_ln, d.T = rows, B, n_steps, int(cfg), int(self.fused_qkv), int(self.fused_ln), T
         d.cfg_rate, d.dt = cfg_rate, dt
         d.gemm_tile, d.attn_version = int(self.gemm_tile), int(self.attn_version)
         d.tbias, d.lens, d.xin, d.xinP = ops._p(tb), ops._p(lens_r), ops._p(xin), ref(xinP)

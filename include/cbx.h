@@ -141,6 +141,12 @@ typedef struct cbx_gemm_pl_t {
      * VGPRs per CU with 96 KiB of LDS (form 17), so that the workgroups of a latency-bound kernel chain on ANOTHER stream (the T3 decode step of the next
      * batch) stay co-resident instead of waiting for these to retire (profiles/r05_overlap_*).  Same arithmetic in every form. */
     int tile;
+    /* ABI v13 -- LayerNorm of the FINISHED row, produced by the epilogue (N == 256 only: the attention out-projection, ff2 and the 1 x 1 residual conv of the CFM
+     * estimator, whose consumer is nn.LayerNorm -> Linear, matcha/transformer.py:243-316 norm3 / the next block's norm1).  ln_w != NULL: besides C (the fp32
+     * row incl. bias and residual) the launch writes LNP[m][n] = (C[m][n] - mean_m) * rstd_m * ln_w[n] + ln_b[n] in plane format (row stride ld_lnp, plane
+     * offset lnp_lo, batch stride lnp_s1, halves), mean / variance over the 256 columns in fp32 (two passes, as cbx_layernorm_f32), eps ln_eps.  It replaces the
+     * cbx_layernorm_planes_f32 launch between the two Linears.  Needs N == 256, K % 32 == 0, no activation, no P / PT; runs on the row-spanning 64 x 256 tile. */
+    const float* ln_w; const float* ln_b; void* LNP; long ld_lnp, lnp_lo, lnp_s1; float ln_eps;
 } cbx_gemm_pl_t;
 #define CBX_PL_TILE_CORESIDENT (-1)
 /* ABI v13: a stream ATTRIBUTE (like its priority): launches on a co-resident stream that would otherwise put several workgroups of one kernel on a CU
@@ -499,7 +505,9 @@ typedef struct cbx_cfm_stage_t {
  * Needs T even, rows * T > 32, (rows * T + 512) * 4096 < 2^31.  Sequences kernel-level entry points only (results bit-identical to issuing them one by one):
  * no allocation, no synchronisation, hipGraph-capturable. */
 typedef struct cbx_cfm_t {
-    int n_stages, rows, B, n_steps, cfg, fused_qkv, reserved1;   /* reserved1: 0 (was fused_mlp, ABI v12) */
+    int n_stages, rows, B, n_steps, cfg, fused_qkv, fused_ln;    /* fused_ln (ABI v13; the slot of v12's fused_mlp): 1 = norm3 from the attention
+                                                                  * out-projection's epilogue (cbx_gemm_pl_t.ln_w), 2 = also the next block's norm1
+                                                                  * from ff2's; 0 = LayerNorm launches of their own */
     long T;
     float cfg_rate;
     const float* dt;                      /* HOST [n_steps] */

@@ -128,6 +128,22 @@ for ver in (1, 2, 3, 4):
 ops.lib.cbx_set_attn_planes_version(4)
 print(line, flush=True)
 
+
+# LayerNorm from the GEMM epilogue (cbx_gemm_pl_t.ln_w, round 5) against the two launches it replaces
+for name, K in (("attn_out + norm3", 512), ("ff2 + next norm1", 1024)):
+    aP, wP2 = ops.split_planes(torch.randn(M, K, device=dev)), ops.split_planes(torch.randn(256, K, device=dev) * 0.05)
+    bb, xr, lw_, lb_ = torch.randn(256, device=dev), torch.randn(M, 256, device=dev), torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    hP_ = ops.Planes(M, 256, dev)
+
+    def two():
+        ops.linear_planes(aP, wP2, out=xr, bias=bb, residual=xr)
+        ops.layernorm_planes(xr, lw_, lb_, hP_, 1e-5)
+
+    def one():
+        ops.linear_planes(aP, wP2, out=xr, bias=bb, residual=xr, ln=(lw_, lb_), lnp=hP_)
+
+    print(f"{name:18s} K={K:5d} | Linear + layernorm_planes (2 launches) {timeit(two):6.1f} us | LayerNorm in the epilogue (1 launch) {timeit(one):6.1f} us", flush=True)
+
 # LayerNorm
 x = torch.randn(M, 256, device=dev)
 w1, b1, y, st = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.empty(M, 256, device=dev), torch.empty(M, 2, device=dev)

@@ -18,6 +18,10 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_be
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_serial_steps5_kernel_stats.csv
 head -12 $O/bench_serial_steps5_kernel_stats.csv | cut -c1-200 | sed 's/(anonymous namespace):://g'
 cd $R
+for f in 1 0; do  # LayerNorm of norm3 from the out-projection's epilogue (the default) against LayerNorm launches, serial schedule, same box
+  CBX_FUSED_LN=$f timeout 200 python bench.py --schedule serial --steps 6 --warmup 2 --no-cpu-baseline --no-alt-precisions --no-streaming --no-autotune > $O/bench_serial_fused_ln_$f.json 2> $O/bench_ln_$f.err
+  python -c "import json; d=json.load(open('$O/bench_serial_fused_ln_$f.json')); print('serial, fused_ln $f:', d['value'], d['ms_per_step'], d['stage_ms'])"
+done
 for w in turbo nano; do
   timeout 150 python bench.py --workload $w --batch 1 --steps 8 --warmup 2 --no-cpu-baseline --no-alt-precisions --no-streaming > $O/bench_${w}_b1.json 2> $O/bench_${w}.err
   python -c "import json; d=json.load(open('$O/bench_${w}_b1.json')); print('$w b1', d['value'], d['config'].get('stage_ms_per_step'), d.get('decode_step', {}).get('ms_per_step'), d.get('decode_step', {}).get('frac'))"

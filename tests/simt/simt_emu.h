@@ -236,6 +236,10 @@ static inline int __any(int pred) { return simt_ballot(pred != 0) != 0; }
 // v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100), row_shr / row_shl / row_ror, row_mirror, row_half_mirror, row_bcast are not all
 // needed -- the sources use quad_perm only; anything else fails loudly
 static inline int simt_mov_dpp(int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    if (ctrl >= 0x121 && ctrl <= 0x12F) {  // row_ror:n -- lane l of a 16-lane row receives from lane (l - n) mod 16 (gemm_planes.hip: the LayerNorm epilogue's row sums)
+        const int n = ctrl & 0xF;
+        return simt_shfl_by(v, [=](int l) { return (l & ~15) | (((l & 15) - n) & 15); });
+    }
     if (ctrl < 0 || ctrl > 0xFF) {
         fprintf(stderr, "simt: unsupported DPP control 0x%x\n", ctrl);
         abort();

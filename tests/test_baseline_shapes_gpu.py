@@ -165,6 +165,14 @@ def test_flow_t1000_b2_vs_reference(dev, s3_sd, prec):
         eng.co_resident(True)
         mel2 = eng.inference(toks, torch.tensor([N] * B), synth.s3gen_ref(n_prompt_tokens=P), z=z, n_steps=int(g["n_steps"])).cpu()
         assert torch.equal(mel2, mel), f"co-resident kernel forms changed the mel: max |d| {(mel2 - mel).abs().max():.3e}"
+        # LayerNorm as launches of its own (fused_ln = 0: the form of rounds 3-4; or = 2 if the engine runs another mode) must meet the same tolerance, and the forms each other
+        eng.co_resident(False)
+        eng.fused_ln = 0 if eng.fused_ln else 2
+        mel3 = eng.inference(toks, torch.tensor([N] * B), synth.s3gen_ref(n_prompt_tokens=P), z=z, n_steps=int(g["n_steps"])).cpu()
+        for b in range(B):
+            err = (mel3[b] - torch.from_numpy(g["mel"][b]).t()).abs()
+            assert err.mean() <= TOL_MEL[prec][0] and err.max() <= TOL_MEL[prec][1], f"fused_ln {eng.fused_ln}: utt {b}: mel L1 {err.mean():.3e} max {err.max():.3e}"
+        assert (mel3 - mel).abs().max() <= 3e-5, f"LayerNorm in the epilogue vs as a launch: max |d| {(mel3 - mel).abs().max():.3e}"
 
 
 def _window_rmse(wav, g, b):

@@ -255,3 +255,30 @@ def test_estimator_planes_path_matches_fp32_operand_path(dev, monkeypatch):
     for b, n in enumerate(lens.tolist()):
         d = (mel_p[b, : 2 * n] - mel_f[b, : 2 * n]).abs()
         assert d.mean() <= 2e-6 and d.max() <= 3e-5, f"row {b}: mean {d.mean():.2e} max {d.max():.2e}"
+
+
+@pytest.mark.parametrize("M,K,res", [(16000 + 37, 512, True), (333, 1024, True), (64, 256, False), (1000, 512, True)])
+def test_gemm_planes_layernorm_epilogue(dev, M, K, res):
+    """cbx_gemm_pl_t.ln_w (ABI v13): the row-spanning 64 x 256 tile writes the fp32 row (bias + residual) AND nn.LayerNorm of that row in plane format -- against
+    fp64 on the values the planes hold, against the two launches it replaces (plain Linear: bit-identical fp32 row; cbx_layernorm_planes_f32 of that row: the
+    LayerNorm tolerance), ragged M, with and without a residual."""
+    from chatterbox_amd import ops
+    N = 256
+    x, w, b = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3)
+    r = _r((M, N), 4) * 3.0 + 0.5  # a residual stream with a non-zero row mean
+    lw, lb = 1 + 0.1 * _r((N,), 5), 0.1 * _r((N,), 6)
+    xP, wP = ops.split_planes(x.to(dev)), ops.split_planes(w.to(dev))
+    ref = F.linear(_planes_exact(x), _planes_exact(w), b.double()) + (r.double() if res else 0)
+    out = r.clone().to(dev) if res else torch.empty(M, N, device=dev)
+    lnP = ops.Planes(M, N, dev, zero=True)
+    ops.linear_planes(xP, wP, out=out, bias=b.to(dev), residual=out if res else None, ln=(lw.to(dev), lb.to(dev)), lnp=lnP)
+    _close(out, ref, 3e-5 * max(1.0, math.sqrt(K / 256)), f"fp32 row {M}x{K}")
+    ln_ref = F.layer_norm(out.double().cpu(), (N,), lw.double(), lb.double(), 1e-5)
+    _close(lnP.float(), ln_ref, 3e-6, f"LayerNorm epilogue {M}x{K}")
+    # the two launches it replaces
+    out2 = r.clone().to(dev) if res else torch.empty(M, N, device=dev)
+    ops.linear_planes(xP, wP, out=out2, bias=b.to(dev), residual=out2 if res else None)
+    assert torch.equal(out2, out), "the fp32 row must not depend on the tile form"
+    ln2 = ops.Planes(M, N, dev, zero=True)
+    ops.layernorm_planes(out2, lw.to(dev), lb.to(dev), ln2, 1e-5)
+    assert (ln2.float() - lnP.float()).abs().max() <= 4e-6, f"vs layernorm_planes: {(ln2.float() - lnP.float()).abs().max():.3e}"

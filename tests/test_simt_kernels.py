@@ -130,6 +130,13 @@ def test_gemm_planes_tiles_small(emu, tile, persist):
         emu.cbx_set_planes_persist(1)
 
 
+@pytest.mark.parametrize("M,K,res", [(333, 512, True), (64, 256, False)])
+def test_gemm_planes_layernorm_epilogue_small(emu, M, K, res):
+    """tests/test_planes_gpu.py::test_gemm_planes_layernorm_epilogue at emulator-sized shapes."""
+    import test_planes_gpu
+    test_planes_gpu.test_gemm_planes_layernorm_epilogue(CPU, M, K, res)
+
+
 def test_gemm_planes_conv_and_transposed_columns_small(emu):
     """Causal 3-tap Conv1d on planes with ragged lengths, and q | k | V^T from one launch (ABI v8), at emulator-sized shapes."""
     from chatterbox_amd import ops
@@ -442,7 +449,7 @@ def _rerun(env, select):
     return r.returncode, (r.stdout + r.stderr)[-1500:]
 
 
-_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or conv_and_transposed_columns or transposed_walk"
+_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or conv_and_transposed_columns or transposed_walk or layernorm_epilogue"
 
 
 def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):
@@ -606,14 +613,14 @@ def test_autotuner_child_entry_point_on_the_emulator(emu, monkeypatch, capsys):
 _SLOW = pytest.mark.skipif(os.environ.get("CBX_EMU_SLOW") != "1", reason="half a minute each: CBX_EMU_SLOW=1")
 
 
-@pytest.mark.parametrize("meanflow,T,fused_qkv", [(False, 20, True), pytest.param(True, 34, True, marks=_SLOW), pytest.param(False, 18, True, marks=_SLOW),
-                                                  pytest.param(True, 36, True, marks=_SLOW)])
-def test_cfm_solve_c_entry_point_on_the_emulator(emu, meanflow, T, fused_qkv):
+@pytest.mark.parametrize("meanflow,T,fused_qkv,fused_ln", [(False, 20, True, 2), pytest.param(True, 34, True, 1, marks=_SLOW), pytest.param(False, 18, True, 1, marks=_SLOW),
+                                                           pytest.param(True, 36, True, 0, marks=_SLOW), pytest.param(False, 20, True, 0, marks=_SLOW)])
+def test_cfm_solve_c_entry_point_on_the_emulator(emu, meanflow, T, fused_qkv, fused_ln):
     """tests/test_zzz_stage_seams_gpu.py on the emulator: cbx_cfm_solve (ABI v12) against FlowEngine.cfm's own launch sequence, bit for bit -- one utterance,
     one mid stage, two Euler steps, CFG with the fused q | k | V^T projection; opt-in (CBX_EMU_SLOW=1, all pass): meanflow, the separate projection
     (T % 4 != 0)."""
     import test_zzz_stage_seams_gpu as S
-    S.test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(CPU, meanflow, T, fused_qkv, n_mid=1, B=1, n_steps=2)
+    S.test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(CPU, meanflow, T, fused_qkv, fused_ln, n_mid=1, B=1, n_steps=2)
 
 
 @pytest.mark.parametrize("ragged,fade,precision", [(True, True, 16), pytest.param(False, False, 1, marks=_SLOW)])

@@ -12,15 +12,16 @@ pytestmark = pytest.mark.gpu
 # profiles/r05_a_seams_first_hardware_run.log -- green), so every S3Gen / HiFT golden of tests/test_models_gpu.py passes through them as well.
 
 
-@pytest.mark.parametrize("meanflow,T,fused_qkv", [(False, 152, True), (False, 150, True), (True, 152, True), (False, 152, False)])
-def test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(dev, meanflow, T, fused_qkv, n_mid=2, B=3, n_steps=3):
+@pytest.mark.parametrize("meanflow,T,fused_qkv,fused_ln", [(False, 152, True, 1), (False, 150, True, 2), (True, 152, True, 1), (False, 152, False, 2),
+                                                           (False, 152, True, 0)])
+def test_cfm_solve_through_the_c_entry_point_equals_the_python_sequence(dev, meanflow, T, fused_qkv, fused_ln, n_mid=2, B=3, n_steps=3):
     """solve_euler (CFG or meanflow) on the plane-format estimator: cbx_cfm_solve against FlowEngine.cfm's own launch sequence, for a ragged batch, the fused
-    and the separate q | k | V^T projection (T % 4 != 0 forces the separate one)."""
+    and the separate q | k | V^T projection (T % 4 != 0 forces the separate one), LayerNorm from the GEMM epilogues and as launches of its own."""
     from chatterbox_amd import ops, synth
     from chatterbox_amd.s3gen import FlowEngine
     sd = synth.s3gen_state_dict(0, meanflow=meanflow, n_mid=n_mid, n_enc=1, n_up_enc=1)
     eng = FlowEngine(sd, dev, meanflow=meanflow)
-    eng.fused_qkv = fused_qkv
+    eng.fused_qkv, eng.fused_ln = fused_qkv, fused_ln
     mu, cond, z = (synth.randn((B, T, 80), seed=s).to(dev) for s in (1, 2, 3))
     cond[:, T // 3:] = 0
     spk = synth.randn((B, 80), seed=4).to(dev)

@@ -114,10 +114,12 @@ class FlowEngine:
         # split into their two fp16 planes ONCE (here, lazily) and activations written in plane format by their producers
         self.use_planes = os.environ.get("CBX_PLANES", "1") != "0"
         self.fused_qkv = os.environ.get("CBX_FUSED_QKV", "1") != "0"  # q | k | V^T of a transformer block from one GEMM launch (ABI v8)
-        # LayerNorm produced by the epilogue of the N = 256 Linear in front of it (cbx_gemm_pl_t.ln_w, ABI v13).  1 (default): norm3 from the attention
-        # out-projection (K = 512: 33.4 -> 28.8 us for Linear + LayerNorm, same box); 2: also the NEXT block's norm1 from ff2 (K = 1024: the row-spanning 64 x 256
-        # tile is 14 us behind the 4-loader 128 x 128 form there, so 38.1 -> 44.0 us: not the default); 0: LayerNorm launches of their own (rounds 3-4)
-        self.fused_ln = int(os.environ.get("CBX_FUSED_LN", "1"))
+        # LayerNorm produced by the epilogue of the N = 256 Linear in front of it (cbx_gemm_pl_t.ln_w, ABI v13): 1 = norm3 from the attention out-projection,
+        # 2 = also the NEXT block's norm1 from ff2, 0 (default) = LayerNorm launches of their own.  Parity-green in all three modes, but NOT faster in the
+        # flow: in a warm micro-benchmark out-projection + norm3 goes 33.4 -> 28.8 us (ff2 + norm1 38.1 -> 44.0), inside the estimator the row-spanning
+        # 64 x 256 launch averages 44.4 us (rocprofv3) where out-projection + LayerNorm cost ~30: serial flow 204.5 (0) / 220.4 (1) ms on one box,
+        # 195.4 (0) / 199.8 (2) on another (profiles/r05_bench_layernorm_epilogue_ab.log).  Kept as an opt-in (CBX_FUSED_LN) until the tile has loader waves.
+        self.fused_ln = int(os.environ.get("CBX_FUSED_LN", "0"))
         self._pw = None
         # the token encoder (flash rel-pos form) and the Euler loop (plane-format path) through the stage-level C entry points cbx_s3gen_encode /
         # cbx_cfm_solve (ABI v12; the same launches with the same arguments as the Python sequencing below -- bit-identical results on the MI355X:

@@ -77,9 +77,10 @@ class ChatterboxEngine:
 
     @ops.on_device
     @torch.inference_mode()
-    def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True):
+    def vocode(self, speech_tokens, gen_ref, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=False, sync=True, hift_stream=None):
         """S3Gen.inference for a list of 1-D token tensors (already valid ids).  Returns (list of 1-D wav tensors on
-        device, mel (B, 2Nmax, 80) channel-last)."""
+        device, mel (B, 2Nmax, 80) channel-last).  hift_stream (synthesize_pipelined): the vocoder runs on THAT stream behind an event, so the flow
+        stream is free for the next batch's encoder + CFM; the returned waveforms belong to it."""
         B = len(speech_tokens)
         ns = [int(t.numel()) for t in speech_tokens]
         Nmax = max(ns)
@@ -100,7 +101,17 @@ class ChatterboxEngine:
             t1 = time.perf_counter()
             # short_b > 0 only when the prompt mel has an odd frame more than 2 * prompt tokens (flow.py:170-195); per voice when the batch mixes voices
             mel_lens = None if same and len(set(shorts)) == 1 else (2 * lens - torch.tensor(shorts, dtype=torch.int32)).to(self.dev)
-            wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
+            if hift_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(hift_stream):
+                    hift_stream.wait_event(ev)
+                    mel.record_stream(hift_stream)
+                    if mel_lens is not None:
+                        mel_lens.record_stream(hift_stream)
+                    wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
+            else:
+                wav, _ = self.hift.inference(mel, phase=phase, noise=noise, lens=mel_lens, fade=True)
             if sync:
                 torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -243,6 +254,42 @@ class ChatterboxEngine:
             except BaseException as e:  # re-raised by the consumer thread
                 q.put(e)
 
+        # ---- (A/B hook, OFF by default: CBX_PIPE_HIFT_STREAM=1) the vocoder of batch k on its OWN stream (behind an event), its audio fetched one batch later, so
+        #      that the flow stream runs encoder + CFM(k + 1) right behind CFM(k).  Measured WORSE -- 208.9x against 226.3x, same box (profiles/
+        #      r05_throughput_schedule_sweep.log): a fourth stream of chip-filling work thrashes like a third decode chain does.  Either way consecutive batches
+        #      report fp16-range trips into alternating flag words (ops.select_range_flag: a launch carries the word that was registered when it was ENQUEUED).
+        import collections
+        if not hasattr(self, "_s_hift"):
+            self._s_hift = torch.cuda.Stream(device=self.dev)
+        split_hift = os.environ.get("CBX_PIPE_HIFT_STREAM", "0") != "0"
+        inflight = collections.deque()
+        voc_kw = dict(n_cfm_timesteps=kw.get("n_cfm_timesteps", 10), drop_last_token=kw.get("drop_last_token", True))
+
+        def start_voc(job, st, which):
+            ops.select_range_flag(self.dev, which)
+            with torch.cuda.stream(self._s_voc):
+                wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"), sync=False,
+                                      hift_stream=self._s_hift if split_hift else None, **voc_kw)
+            with torch.cuda.stream(self._s_hift if split_hift else self._s_voc):
+                host = [torch.empty(w.shape, dtype=w.dtype, pin_memory=True).copy_(w, non_blocking=True) for w in wavs]
+                ev = torch.cuda.Event()
+                ev.record()
+            return host, ev
+
+        def finish(job, st, t0, host, ev, which):
+            ev.synchronize()
+            if 16 in (self.flow.precision, self.hift.precision) and ops.range_flag_tripped(self.dev, which):
+                warnings.warn("an S3Gen operand exceeded the fp16 range: repeating flow matching + vocoder of this batch at bf16x6")
+                saved = self.flow.precision, self.hift.precision
+                self.flow.precision, self.hift.precision = (6 if p == 16 else p for p in saved)
+                try:
+                    with torch.cuda.stream(self._s_voc):
+                        wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"), sync=False, **voc_kw)
+                        host = [w.cpu() for w in wavs]
+                finally:
+                    self.flow.precision, self.hift.precision = saved
+            return host, st, time.perf_counter() - t0
+
         th = threading.Thread(target=worker, name="cbx-t3-enqueue", daemon=True)
         th.start()
         try:
@@ -256,13 +303,18 @@ class ChatterboxEngine:
                     toks = self.t3.collect(h)  # blocks this thread until T3(k) is done; T3(k + 1) is already enqueued behind it
                 slot_free[k % n_slots].release()
                 st = tokens_of(toks)
-                host = voc_of(job, st)
-                yield host, st, time.perf_counter() - t0
+                host, evv = start_voc(job, st, k % 2)
+                inflight.append((job, st, t0, host, evv, k % 2))
+                if len(inflight) > (1 if split_hift else 0):
+                    yield finish(*inflight.popleft())
+            while inflight:
+                yield finish(*inflight.popleft())
         finally:
             stop.set()
             for sem in slot_free:
                 sem.release()
             th.join()
+            ops.select_range_flag(self.dev, 0)
 
 
 def _stream_plan(n_tokens, done, exhausted, lookahead):

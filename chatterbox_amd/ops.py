@@ -124,22 +124,39 @@ def _dev_index(device=None):
 
 
 def enable_range_flag(device=None):
-    """Allocate (once per GPU) the device word the f16x3 kernels (precision 16) raise when an operand exceeds the fp16 range.  The library
+    """Allocate (once per GPU) the device words the f16x3 kernels (precision 16) raise when an operand exceeds the fp16 range.  The library
     keeps one pointer per device ordinal (cbx_set_range_flag registers it for the CURRENT device; a launch looks its own device's word up),
-    so engines on different GPUs of one process never OR into a foreign-device pointer."""
+    so engines on different GPUs of one process never OR into a foreign-device pointer.  Two words per GPU: select_range_flag() switches the
+    registered one between batches whose launches are in flight at once (the launch carries the pointer that was registered when it was ENQUEUED)."""
     idx = _dev_index(device)
     if idx not in _RANGE_FLAGS:
         with torch.cuda.device(idx):
-            _RANGE_FLAGS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
-            check(lib.cbx_set_range_flag(_p(_RANGE_FLAGS[idx])), "cbx_set_range_flag")
-    return _RANGE_FLAGS[idx]
+            _RANGE_FLAGS[idx] = [torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", idx)), 0]
+            check(lib.cbx_set_range_flag(_p(_RANGE_FLAGS[idx][0])), "cbx_set_range_flag")
+    words, which = _RANGE_FLAGS[idx]
+    return words[which: which + 1]
 
 
-def range_flag_tripped(device=None):
-    """True when a precision-16 launch on this GPU since the last call saw an operand outside the fp16 range (synchronises; clears the flag)."""
-    flag = _RANGE_FLAGS.get(_dev_index(device))
-    if flag is None:
+def select_range_flag(device, which):
+    """Every precision-16 launch ENQUEUED from now on reports into word `which` (0 / 1) of this GPU: engine.synthesize_pipelined gives consecutive batches
+    alternating words, so a trip is attributed to the batch that raised it although the vocoder of one batch runs beside the flow of the next."""
+    enable_range_flag(device)
+    idx = _dev_index(device)
+    words = _RANGE_FLAGS[idx][0]
+    _RANGE_FLAGS[idx][1] = int(which)
+    with torch.cuda.device(idx):
+        check(lib.cbx_set_range_flag(words.data_ptr() + 4 * int(which)), "cbx_set_range_flag")
+
+
+def range_flag_tripped(device=None, which=None):
+    """True when a precision-16 launch on this GPU since the last call saw an operand outside the fp16 range (synchronises; clears the flag).
+    `which`: the word to look at (default: the one currently registered)."""
+    ent = _RANGE_FLAGS.get(_dev_index(device))
+    if ent is None:
         return False
+    words, cur = ent
+    w = cur if which is None else int(which)
+    flag = words[w: w + 1]
     hit = bool(flag.item())
     if hit:
         flag.zero_()

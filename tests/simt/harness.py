@@ -54,10 +54,10 @@ def emulated():
         self.C = self.Call - c0 if width is None else width
 
     def enable_range_flag(device=None):
-        if 0 not in ops._RANGE_FLAGS:
-            ops._RANGE_FLAGS[0] = torch.zeros(1, dtype=torch.int32)
-            _lib.check(emu.cbx_set_range_flag(ops._RANGE_FLAGS[0].data_ptr()), "cbx_set_range_flag")
-        return ops._RANGE_FLAGS[0]
+        if 0 not in ops._RANGE_FLAGS:  # [two words, index of the registered one]: the layout of ops.enable_range_flag (round 5)
+            ops._RANGE_FLAGS[0] = [torch.zeros(2, dtype=torch.int32), 0]
+            _lib.check(emu.cbx_set_range_flag(ops._RANGE_FLAGS[0][0].data_ptr()), "cbx_set_range_flag")
+        return ops._RANGE_FLAGS[0][0][:1]
 
     da_ws = (torch.empty(128 * 8 * 66), torch.zeros(128, dtype=torch.int32))
 

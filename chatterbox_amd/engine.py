@@ -170,9 +170,10 @@ class ChatterboxEngine:
         import threading
         torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
         if not hasattr(self, "_s_t3"):
-            self._s_t3 = torch.cuda.Stream(device=self.dev, priority=-1)
-            self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=-1) for _ in range(2)]  # one per T3 state in flight
-            self._s_voc = torch.cuda.Stream(device=self.dev)
+            pt3, pvoc = (int(x) for x in os.environ.get("CBX_PIPE_PRIO", "-1,0").split(","))  # (A/B hook: stream priorities of the T3 / flow streams)
+            self._s_t3 = torch.cuda.Stream(device=self.dev, priority=pt3)
+            self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=pt3) for _ in range(2)]  # one per T3 state in flight
+            self._s_voc = torch.cuda.Stream(device=self.dev, priority=pvoc)
         t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
                                     "ban_from") if k in kw}
         if os.environ.get("CBX_PIPE_CORES") is not None:  # A/B hook

@@ -558,20 +558,31 @@ def test_encoder_flash_relpos_modes_match_the_materialised_encoder(dev):
     z = synth.randn((3, 80, 2 * (P + max(Ns))), seed=5).transpose(1, 2).contiguous()
     eng.ENC_FLASH = "0"
     mel = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
-    calls, real = [0], ops.flash_relpos
+    calls, real, seam_calls, real_seam = [0], ops.flash_relpos, [0], eng._encode_c
 
     def counted(*a, **k):
         calls[0] += 1
         return real(*a, **k)
 
-    ops.flash_relpos = counted
+    def counted_seam(*a, **k):
+        seam_calls[0] += 1
+        return real_seam(*a, **k)
+
+    ops.flash_relpos, eng._encode_c = counted, counted_seam
     try:
-        for mode, cap, want in (("auto", 32 << 30, 0), ("auto", 1, 3), ("1", 32 << 30, 3)):  # 2 + 1 conformer layers in this small model
-            calls[0] = 0
-            eng.ENC_FLASH, eng.ENC_SCORE_BYTES = mode, cap
-            mel2 = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
-            assert calls[0] == want, f"CBX_ENC_FLASH={mode}, cap {cap}: {calls[0]} flash launches"
-            assert (mel - mel2).abs().max() <= 2e-5, f"flash rel-pos encoder ({mode}, cap {cap}): {(mel - mel2).abs().max():.3e}"
+        # the Python launch sequencing (c_seam off) counts kernel-level flash launches; the stage-level C entry point cbx_s3gen_encode (the engines' default
+        # since round 5) serves exactly the calls that take the flash form: one call instead of the 3 launches
+        for seam in (False, True):
+            eng.c_seam = seam
+            for mode, cap, want in (("auto", 32 << 30, 0), ("auto", 1, 3), ("1", 32 << 30, 3)):  # 2 + 1 conformer layers in this small model
+                calls[0] = seam_calls[0] = 0
+                eng.ENC_FLASH, eng.ENC_SCORE_BYTES = mode, cap
+                mel2 = eng.inference(toks, lens, ref, z=z, n_steps=3).cpu()
+                if seam:
+                    assert (calls[0], seam_calls[0]) == (0, 1 if want else 0), f"c_seam, CBX_ENC_FLASH={mode}, cap {cap}: {calls[0]} launches, {seam_calls[0]} seam calls"
+                else:
+                    assert (calls[0], seam_calls[0]) == (want, 0), f"CBX_ENC_FLASH={mode}, cap {cap}: {calls[0]} flash launches, {seam_calls[0]} seam calls"
+                assert (mel - mel2).abs().max() <= 2e-5, f"flash rel-pos encoder ({mode}, cap {cap}, c_seam {seam}): {(mel - mel2).abs().max():.3e}"
     finally:
         ops.flash_relpos = real
     for b, n in enumerate(Ns):

@@ -519,6 +519,12 @@ def vc60_main(args, dev, rank, world):
         "roofline": roof, "roofline_secondary": list(roofs.values())}), flush=True)
 
 
+def _co_resident_on_green(t3):
+    """Is the decode geometry of the throughput schedule (T3Engine.co_resident) on the committed allow-list of hardware-verified geometries?"""
+    from chatterbox_amd import autotune as at
+    return at.canon(dict(t3.tune, half_tiles=0, d_ks2=4, d_nw2=8), t3.knobs) in at.green_variants()
+
+
 def log(msg):
     if os.environ.get("CBX_BENCH_VERBOSE"):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -883,6 +889,10 @@ def main():
             # the T3 decode geometry the timed region ran (built-in + what the autotuner adopted from the hardware-green allow-list)
             "t3_geometry": ({"adopted": (tune_rep or {}).get("adopted") or {}, "tune": {k: v for k, v in eng.t3.tune.items() if v != type(eng.t3)._TUNE.get(k)},
                              "knobs": dict(eng.t3.knobs), "on_green_list": _on_green(eng.t3)} if not turbo else {"tune": dict(eng.t3.tune), "knobs": dict(eng.t3.knobs)}),
+            # ... and the geometry its decode chains ran in the throughput schedule (T3Engine.co_resident: every launch <= 8 waves x <= 128 VGPRs; the tune part is a
+            # member of the allow-list, the shallow SwiGLU batches are an op-level identity: tests/test_ops_gpu.py::test_gemv_packed_rms_fused)
+            "t3_geometry_throughput_schedule": ({"tune": {"half_tiles": 0, "d_ks2": 4, "d_nw2": 8}, "knobs": {"shallow": 1}, "t3_batches_in_flight": 2,
+                                                  "on_green_list": _co_resident_on_green(eng.t3)} if (pipelined and not turbo) else None),
             "multi_gpu_note": ("single-GPU run: no N > 1 scaling curve exists in this repo (the driver owns multi-GPU leases)" if world == 1 else None),
             "roofline": roof,
             "decode_step": dstep,

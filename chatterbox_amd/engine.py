@@ -149,7 +149,7 @@ class ChatterboxEngine:
     def co_resident(self, on):
         """Both stages on (or off) the kernel forms whose workgroups can share a CU with the other stage's (T3Engine.co_resident, FlowEngine.co_resident)."""
         if self.t3 is not None and hasattr(self.t3, "co_resident"):
-            self.t3.co_resident(on)
+            self.t3.co_resident(on and os.environ.get("CBX_PIPE_T3_CORES", "1") != "0")  # (A/B hook)
         self.flow.co_resident(on)
 
     @torch.inference_mode()

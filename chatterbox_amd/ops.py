@@ -144,7 +144,10 @@ def select_range_flag(device, which):
     idx = _dev_index(device)
     words = _RANGE_FLAGS[idx][0]
     _RANGE_FLAGS[idx][1] = int(which)
-    with torch.cuda.device(idx):
+    if words.is_cuda:
+        with torch.cuda.device(idx):  # (the registration is for the CURRENT device)
+            check(lib.cbx_set_range_flag(words.data_ptr() + 4 * int(which)), "cbx_set_range_flag")
+    else:  # the SIMT emulator's host words (tests/simt/harness.py)
         check(lib.cbx_set_range_flag(words.data_ptr() + 4 * int(which)), "cbx_set_range_flag")
 
 

@@ -282,3 +282,24 @@ def test_gemm_planes_layernorm_epilogue(dev, M, K, res):
     ln2 = ops.Planes(M, N, dev, zero=True)
     ops.layernorm_planes(out2, lw.to(dev), lb.to(dev), ln2, 1e-5)
     assert (ln2.float() - lnP.float()).abs().max() <= 4e-6, f"vs layernorm_planes: {(ln2.float() - lnP.float()).abs().max():.3e}"
+
+
+def test_range_flag_words_attribute_a_trip_to_the_batch_that_raised_it(dev):
+    """ops.select_range_flag (round 5): launches report an operand outside the fp16 range into the flag word that was registered when they were ENQUEUED -- the
+    throughput schedule gives consecutive batches alternating words, so a trip is attributed to the right batch although their launches overlap on the GPU."""
+    from chatterbox_amd import ops
+    ops.enable_range_flag(dev)
+    try:
+        ok, big = _r((64, 256), 1).to(dev), _r((64, 256), 2).to(dev)
+        big[3, 5] = 7e4
+        ops.select_range_flag(dev, 0)
+        ops.split_planes(ok)
+        ops.select_range_flag(dev, 1)
+        ops.split_planes(big)
+        ops.select_range_flag(dev, 0)
+        ops.split_planes(ok)
+        assert not ops.range_flag_tripped(dev, 0), "word 0 saw only in-range operands"
+        assert ops.range_flag_tripped(dev, 1) and not ops.range_flag_tripped(dev, 1), "word 1 tripped once; reading clears it"
+        assert not ops.range_flag_tripped(dev), "the registered word (0) is clean"
+    finally:
+        ops.select_range_flag(dev, 0)

@@ -97,7 +97,8 @@ def test_gemv_epilogue_prefetch_on_the_emulator(emu, name, args, monkeypatch):
     test_zz_abi_v9_gpu.test_gemv_epilogue_prefetch_equals_plain(CPU, name, args, monkeypatch)
 
 
-_PLANES = [("test_split_planes_roundtrip_and_range_flag", ()), ("test_layernorm_planes", ()), ("test_gemm_planes_transposed_rejects_bad_arguments", ())]
+_PLANES = [("test_split_planes_roundtrip_and_range_flag", ()), ("test_layernorm_planes", ()), ("test_gemm_planes_transposed_rejects_bad_arguments", ()),
+           ("test_range_flag_words_attribute_a_trip_to_the_batch_that_raised_it", ())]
 
 
 @pytest.mark.parametrize("name,args", _PLANES, ids=[n for n, _ in _PLANES])

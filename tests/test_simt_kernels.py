@@ -471,7 +471,7 @@ def test_results_do_not_depend_on_the_lane_schedule(emu):
     The workgroups of a launch run in a shuffled order too (the split-context decode attention must merge in split order whoever arrives last).
     Self-check: with the first barrier of every thread dropped (CBX_EMU_DROP_BARRIER=0) the same selection must fail."""
     sel = ("test_sampler or test_layernorm_rmsnorm or test_flash_attn or decode_attn_rope_fused or split_context or test_hift or (gemm_planes_tiles_small and 21-1) "
-           "or (gemm_planes_tiles_small and 3-8) or (test_gemv_packed_rms_fused and False) or flash_attn_planes_small")
+           "or (gemm_planes_tiles_small and 3-8) or (gemm_planes_tiles_small and 32-1) or (test_gemv_packed_rms_fused and False) or flash_attn_planes_small or layernorm_epilogue")
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5"}, sel)
     assert rc == 0, out
     rc, out = _rerun({"CBX_EMU_SCHED": "random:5", "CBX_EMU_DROP_BARRIER": "0"}, "test_gemv_decode or test_linear")  # the K-slice reduction through LDS

@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 13  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 14  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -69,6 +69,21 @@ class DecodeAttnParams(ctypes.Structure):  # cbx_decode_attn_t (ABI v10)
                 ("cache_row_stride", c_long), ("cache_head_stride", c_long), ("scale", c_float),
                 ("unroll", c_int), ("pipeline", c_int), ("split_min", c_int), ("split_ws", c_f), ("split_cnt", c_f), ("split_pairs", c_long),
                 ("qkv_nparts", c_int), ("qkv_part_stride", c_long), ("qkv_ssq", c_f), ("rms_dim", c_int), ("rms_eps", c_float)]  # ABI v11
+
+
+class GemvRowParams(ctypes.Structure):  # cbx_gemv_row_t (ABI v14)
+    _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("res", c_f), ("out", c_f), ("ln_w", c_f), ("ln_b", c_f), ("eps", c_float),
+                ("parts", c_f), ("n_parts", c_int), ("n_heads", c_int), ("N", c_int), ("K", c_int), ("ldw", c_long), ("act", c_int),
+                ("rows_per_wave", c_int)]
+
+
+class AttnPartsParams(ctypes.Structure):  # cbx_attn_parts_t (ABI v14)
+    _fields_ = [("qkv", c_f), ("positions", c_f), ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f), ("parts", c_f),
+                ("rows", c_int), ("n_heads", c_int), ("n_splits", c_int), ("chunks", c_int), ("max_ctx", c_int),
+                ("ld_qkv", c_long), ("cache_row_stride", c_long), ("cache_head_stride", c_long), ("scale", c_float)]
+
+
+ATTN_PART_REC = 68  # CBX_ATTN_PART_REC
 
 
 class SamplerParams(ctypes.Structure):
@@ -164,6 +179,8 @@ _SIGS = {
     "cbx_last_error": ([], ctypes.c_char_p),
     "cbx_gemm_f32": ([ctypes.POINTER(GemmParams), c_f], c_int),
     "cbx_gemv_f32": ([ctypes.POINTER(GemvParams), c_f], c_int),
+    "cbx_gemv_row_f32": ([ctypes.POINTER(GemvRowParams), c_f], c_int),
+    "cbx_decode_attn_parts": ([ctypes.POINTER(AttnPartsParams), c_f], c_int),
     "cbx_set_gemv_deep_batches": ([c_int], c_int),
     "cbx_set_gemv_epilogue_prefetch": ([c_int], c_int),
     "cbx_pack_gemv_weight_f32": ([c_f, c_f, c_int, c_int, c_long, c_int, c_f], c_int),

@@ -8,7 +8,8 @@ import os
 
 import torch
 
-from ._lib import ATTN_PL_CORESIDENT, GEMV_DEEP, GEMV_PRE_EPI, GEMV_SHALLOW, PL_TILE_CORESIDENT, DecodeAttnParams, GemmParams, GemmPlParams, GemvParams, SamplerParams, check, lib
+from ._lib import (ATTN_PART_REC, ATTN_PL_CORESIDENT, GEMV_DEEP, GEMV_PRE_EPI, GEMV_SHALLOW, PL_TILE_CORESIDENT, AttnPartsParams, DecodeAttnParams, GemmParams,
+                   GemmPlParams, GemvParams, GemvRowParams, SamplerParams, check, lib)
 
 NONE, SILU, GELU_ERF, GELU_TANH, MISH, LRELU, ELU, TANH, SNAKE, ABS = range(10)
 
@@ -581,6 +582,36 @@ def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packe
     geom.fill(p)
     check(lib.cbx_decode_attn_rope(ctypes.byref(p), _stream()), "cbx_decode_attn_rope")
     return out
+
+
+def gemv_row(x, w, out, *, bias=None, res=None, ln=None, eps=1e-5, parts=None, n_heads=0, act=NONE, rows_per_wave=0):
+    """Batch-1 decode GEMV (cbx_gemv_row_f32): out (N,) = act(x' . w[n] + bias) + res with x' = x (K,), LayerNorm(x) (ln = (weight, bias)) or the
+    merge of the split-context attention records `parts` (n_heads, n_splits, ATTN_PART_REC) that decode_attn_parts left (x is then None).
+    w (N, K) row-major fp32 -- the checkpoint layout, no packed image."""
+    N, K = w.shape
+    p = GemvRowParams()
+    p.x, p.W, p.bias, p.res, p.out = _p(x), _p(_f32(w, "w")), _p(bias), _p(res), _p(_f32(out, "out"))
+    if ln is not None:
+        p.ln_w, p.ln_b, p.eps = _p(ln[0]), _p(ln[1]), eps
+    if parts is not None:
+        assert parts.dim() == 3 and parts.shape[2] == ATTN_PART_REC and parts.is_contiguous()
+        p.parts, p.n_parts, p.n_heads = _p(parts), parts.shape[1], parts.shape[0]
+    p.N, p.K, p.ldw, p.act, p.rows_per_wave = N, K, w.stride(0), act, int(rows_per_wave)
+    _timed("gemv_f32", 2.0 * N * K, 4.0 * N * K, lambda: check(lib.cbx_gemv_row_f32(ctypes.byref(p), _stream()), "cbx_gemv_row_f32"))
+    return out
+
+
+def decode_attn_parts(qkv, positions, kc, vc, parts, scale, cos_t=None, sin_t=None, chunks=0):
+    """Split-context decode attention that leaves its partial results (cbx_decode_attn_parts): qkv (rows, 3*H*64), caches (rows, H, max_ctx, 64),
+    parts (rows, H, n_splits, ATTN_PART_REC) -- merged by the consuming gemv_row(parts=parts[row])."""
+    rows, H, max_ctx = kc.shape[0], kc.shape[1], kc.shape[2]
+    assert parts.shape[:2] == (rows, H) and parts.shape[3] == ATTN_PART_REC and parts.is_contiguous()
+    p = AttnPartsParams()
+    p.qkv, p.positions, p.cos_t, p.sin_t, p.kc, p.vc, p.parts = _p(qkv), _p(positions), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(parts)
+    p.rows, p.n_heads, p.n_splits, p.chunks, p.max_ctx = rows, H, parts.shape[2], int(chunks), max_ctx
+    p.ld_qkv, p.cache_row_stride, p.cache_head_stride, p.scale = qkv.stride(0), kc.stride(0), kc.stride(1), scale
+    check(lib.cbx_decode_attn_parts(ctypes.byref(p), _stream()), "cbx_decode_attn_parts")
+    return parts
 
 
 def gemv_flags(pre_epi=0, deep=0, shallow=0):

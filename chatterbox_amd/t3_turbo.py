@@ -43,7 +43,10 @@ class T3TurboEngine:
         # qkv_tc = 12 / od_tc = 4 (ABI v9): c_attn resp. the two N = D projections on N / 12 resp. N / 4 workgroups, d_ks = 1: the MLP
         # projection adds bias + residual itself (no partial images, no fold in the next c_attn GEMV)
         # head_ct: column tiles per workgroup of the head GEMV (cbx_gemv_t.col_tiles: 6563 columns = 411 tiles -> 206 workgroups, one round of the chip)
-        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, head_ct=2)
+        # row_path (round 6, ABI v14): batch 1 runs on the single-row streaming kernels (ops.gemv_row / ops.decode_attn_parts: row-major weights, no
+        # MFMA padding, no LDS reduction, no partial images; _forward_decode_row); row_splits / row_chunks: context slices per (row, head) and
+        # 16-position chunks in flight per workgroup of its attention
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, head_ct=2, row_path=1, row_splits=8, row_chunks=4)
         for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
             k, v = kv.split("=")
             assert k.strip() in self.tune, f"CBX_TURBO_TUNE: unknown knob {k!r} (known: {sorted(self.tune)})"
@@ -131,6 +134,21 @@ class T3TurboEngine:
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=D, nw=8, norm_w=self.lnf[0], ln_cw=self.c_head[0], ln_cb=self.c_head[1],
                  col_tiles=int(tn.get("head_ct") or 0) if D % 256 == 0 else 0, **red, **pk)
 
+    def _forward_decode_row(self, st):
+        """Batch 1: 5 launches per GPT-2 layer on the single-row kernels (include/cbx.h "batch-1 decode").  LayerNorm lives in the prologue of the
+        c_attn / c_fc / head GEMVs, the attention leaves `row_splits` partial records per head that the c_proj GEMV merges in ITS prologue, both
+        projections add bias + residual in place.  Weights are the row-major matrices the prefill uses (no packed images)."""
+        ws, tn = st["dws"], self.tune
+        x, qkv, g, parts = ws["x"][0], ws["qkv"][0], ws["g"][0], ws["parts"]
+        ops.embed(st["next_ids"], self.speech_emb, ws["x"], table2=self.wpe, ids2=st["positions"])
+        for i, lw in enumerate(self.layers):
+            ops.gemv_row(x, lw["wqkv"], qkv, bias=lw["bqkv"], ln=lw["ln1"])
+            ops.decode_attn_parts(ws["qkv"], st["positions"], st["kc"][i], st["vc"][i], parts, 0.125, chunks=tn["row_chunks"])
+            ops.gemv_row(None, lw["wo"], x, bias=lw["bo"], res=x, parts=parts[0])
+            ops.gemv_row(x, lw["wfc"], g, bias=lw["bfc"], ln=lw["ln2"], act=ops.GELU_TANH)
+            ops.gemv_row(g, lw["wpr"], x, bias=lw["bpr"], res=x)
+        ops.gemv_row(x, self.head, st["logits"][0], bias=self.head_b, ln=self.lnf)
+
     def _tiles(self):
         """(c_attn tile width, attention / MLP projection tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
         tn = self.tune
@@ -157,6 +175,8 @@ class T3TurboEngine:
                       next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
 
     def _forward(self, st):
+        if self.decode_mode == "v2" and st["B"] == 1 and self.tune.get("row_path") and self.D % 256 == 0:
+            return self._forward_decode_row(st)
         if self.decode_mode == "v2" and st["B"] <= 16:
             return self._forward_decode_v2(st)
         self._forward_decode(st)
@@ -182,7 +202,9 @@ class T3TurboEngine:
                            # packed operand images of the v2 path (rows padded to a 16-row tile, pad rows stay 0)
                            x_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), x2_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev),
                            att_pk=torch.zeros((B + 15) // 16 * 16, D, device=dev), g_pk=torch.zeros((B + 15) // 16 * 16, 4 * D, device=dev),
-                           pd_pk=torch.zeros(4, (B + 15) // 16 * 16, D, device=dev)),
+                           pd_pk=torch.zeros(4, (B + 15) // 16 * 16, D, device=dev),
+                           # split-context attention records of the batch-1 row path (ops.decode_attn_parts -> ops.gemv_row(parts=...))
+                           parts=torch.zeros(B, self.H, max(1, min(16, int(self.tune.get("row_splits") or 8))), ops.ATTN_PART_REC, device=dev)),
                   graph=None, samp_dev=torch.zeros(B, 8, device=dev),
                   # geometry + caller-owned split-context workspace of this state's attention launches (cbx_decode_attn_t, ABI v10)
                   da=ops.DecodeAttnGeom(dev, unroll=0 if int(self.knobs["da_u"]) == 4 else int(self.knobs["da_u"]), pipeline=int(self.knobs["da_pipe"]),

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 13 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 14 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
@@ -29,7 +29,8 @@ extern "C" {
                               12: stage-level seams of the flow and the vocoder: cbx_planes_t, cbx_s3gen_encode, cbx_cfm_solve, cbx_hift_f0_source, cbx_hift_decode;
                               13: per-call launch geometry of the plane-format kernels (cbx_gemm_pl_t.tile, cbx_flash_attn_planes_v, cbx_cfm_t.gemm_tile /
                                   attn_version: no process-wide state on the flow path either) incl. the CO-RESIDENT forms of the throughput schedule
-                                  (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW */
+                                  (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW;
+                              14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -333,6 +334,40 @@ typedef struct cbx_decode_attn_t {
     int qkv_nparts; long qkv_part_stride; const float* qkv_ssq; int rms_dim; float rms_eps;
 } cbx_decode_attn_t;
 int cbx_decode_attn_rope(const cbx_decode_attn_t* p, void* stream);
+
+/* ---- batch-1 decode (ABI v14): one activation row, weights in the checkpoint's row-major layout ----
+ * cbx_gemv_row_f32:  out[n] = act( x' . W[n][:] + bias[n] ) + res[n],  n < N, where the operand x' is
+ *     x                                   (ln_w == NULL, parts == NULL),
+ *     LayerNorm(x) * ln_w + ln_b          (ln_w, ln_b; eps; two-pass variance: F.layer_norm), or
+ *     the attention output of the row     (parts: the n_parts split-context records per head that cbx_decode_attn_parts left, merged in
+ *                                          slice order; K == 64 n_heads; x unused).
+ * A wave owns rows_per_wave (0 = automatic: ~1024 waves) output rows over the whole of K and requests all of its weights up front: no LDS
+ * reduction, no partial images.  K in {256, 768, 1024, 3072, 4096}; W [N][ldw] fp32, 16-byte aligned; res may alias out.
+ * Replaces HF Conv1D / nn.Linear at q_len == 1 + GPT2Block ln_1 / ln_2 / ln_f inside T3.inference_turbo's loop (models/t3/t3.py:435-460). */
+#define CBX_ATTN_PART_REC 68 /* floats per (row, head, slice) record: {running max, sum, -, -, 64 numerators} */
+typedef struct cbx_gemv_row_t {
+    const float* x; const float* W; const float* bias; const float* res; float* out;
+    const float *ln_w, *ln_b; float eps;
+    const float* parts; int n_parts, n_heads;
+    int N, K; long ldw;
+    int act;            /* CBX_ACT_* after the bias */
+    int rows_per_wave;  /* 0 = automatic; 1, 2, 3, 4, 8 (K >= 3072: 1, 2) */
+} cbx_gemv_row_t;
+int cbx_gemv_row_f32(const cbx_gemv_row_t* p, void* stream);
+/* Decode attention of ONE new token per row over a small (row, head) grid, split over n_splits workgroups per (row, head) by 16-position
+ * chunks (chunk c belongs to slice c % n_splits -- independent of the context length, so the cache stream starts before positions[] has
+ * arrived).  Appends the token's k / v (RoPE'd when cos_t / sin_t are given; GPT-2: NULL) to the caches at positions[row] and leaves
+ * parts[((row * n_heads + head) * n_splits + slice) * CBX_ATTN_PART_REC] for the consumer to merge (cbx_gemv_row_t.parts): no ticket, no
+ * fence, no last-arriver.  chunks = 16-position chunks in flight per workgroup (2, 4 (= 0) or 8).  The caches hold >= max_ctx positions
+ * behind every (row, head).  Replaces the q_len == 1 attention of HF GPT2Attention / LlamaAttention (t3.py:435-460 via sdpa). */
+typedef struct cbx_attn_parts_t {
+    const float* qkv; const int* positions; const float *cos_t, *sin_t;
+    float *kc, *vc, *parts;
+    int rows, n_heads, n_splits, chunks, max_ctx;
+    long ld_qkv, cache_row_stride, cache_head_stride;
+    float scale;
+} cbx_attn_parts_t;
+int cbx_decode_attn_parts(const cbx_attn_parts_t* p, void* stream);
 /* tuning knob: tile shape of the split-bf16 GEMM (0 = automatic; 64, 12864, 128, 1282) */
 int cbx_set_split_tile(int t);
 /* TEST HOOKS of the positional cbx_decode_attn_rope_f32 (process-wide; the engines pass cbx_decode_attn_t instead): unroll / pipeline /

@@ -777,3 +777,77 @@ def test_gemv_bf16_weights_equal_rounded_fp32(dev, case):
     ops.gemv(xp, ops.pack_gemv_weight(w.to(dev), bf16=True, **pk), a, **kw)
     ops.gemv(xp, ops.pack_gemv_weight(wr.to(dev), **pk), b, **kw)
     assert torch.equal(a, b), f"{case}: bf16-weight kernel != fp32 kernel on rounded weights (max {float((a - b).abs().max()):.3e})"
+
+
+@pytest.mark.parametrize("N,K,pro,R", [(40, 256, "plain", 0), (1030, 256, "ln", 3), (3072, 1024, "ln", 0), (6563, 1024, "ln", 8), (2304, 768, "ln", 0), (1024, 4096, "plain", 0), (768, 3072, "plain", 2),
+                                       (1024, 1024, "attn", 1), (768, 768, "attn", 2)])
+def test_gemv_row(dev, N, K, pro, R):
+    """cbx_gemv_row_f32 (batch-1 decode GEMV, ABI v14): every prologue (plain / LayerNorm / attention-record merge), bias + gelu_new + in-place
+    residual, ragged N (rows past N inside the last wave and the last workgroup) against fp64."""
+    from chatterbox_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias, res = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    kw, x = {}, None
+    if pro == "attn":
+        H, S = K // 64, 5
+        parts = torch.zeros(H, S, ops.ATTN_PART_REC)
+        parts[:, :, 0] = torch.randn(H, S, generator=g) * 3
+        parts[:, :, 1] = torch.rand(H, S, generator=g) + 0.5
+        parts[:, :, 4:] = torch.randn(H, S, 64, generator=g)
+        parts[1, 2, 0], parts[1, 2, 1], parts[1, 2, 4:] = float("-inf"), 0.0, 0.0  # a slice that saw no position
+        m = parts[:, :, 0].double()
+        f = torch.exp(m - m.max(1, keepdim=True).values)
+        want_x = ((f[:, :, None] * parts[:, :, 4:].double()).sum(1) / (f * parts[:, :, 1].double()).sum(1, keepdim=True)).reshape(-1)
+        kw = dict(parts=parts.to(dev))
+    else:
+        xc = torch.randn(K, generator=g) * 2 + 0.3
+        x, want_x = xc.to(dev), xc.double()
+        if pro == "ln":
+            lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+            want_x = F.layer_norm(xc.double(), (K,), lw.double(), lb.double(), 1e-5)
+            kw = dict(ln=(lw.to(dev), lb.to(dev)))
+    out = res.clone().to(dev)  # in place: res aliases out
+    ops.gemv_row(x, w.to(dev), out, bias=bias.to(dev), res=out, act=ops.GELU_TANH, rows_per_wave=R, **kw)
+    want = F.gelu(w.double() @ want_x + bias.double(), approximate="tanh") + res.double()
+    err = (out.cpu().double() - want).abs().max()
+    assert err < 3e-5 * max(1.0, math.sqrt(K / 256)), float(err)
+
+
+@pytest.mark.parametrize("S,chunks,rope", [(8, 4, False), (3, 2, True), (16, 8, False)])
+def test_decode_attn_parts(dev, S, chunks, rope):
+    """cbx_decode_attn_parts + the merge prologue of cbx_gemv_row_f32 == softmax attention of the new token over the cache (fp64), for ragged
+    contexts incl. a first token (context 1), slices that stay empty, and contexts that need a second batch of chunks; the new k / v land in the cache."""
+    from chatterbox_amd import ops
+    rows, H, max_ctx = 3, 2, 320
+    g = torch.Generator().manual_seed(S)
+    k0, v0 = torch.randn(rows, H, max_ctx, 64, generator=g), torch.randn(rows, H, max_ctx, 64, generator=g)
+    qkv = torch.randn(rows, 3 * H * 64, generator=g)
+    pos = torch.tensor([0, 37, min(16 * S * chunks + 5, max_ctx - 1)], dtype=torch.int32)
+    cos = sin = None
+    if rope:
+        ang = torch.rand(max_ctx, 32, generator=g) * 6.28
+        cos, sin = torch.cat([ang.cos(), ang.cos()], 1).contiguous(), torch.cat([ang.sin(), ang.sin()], 1).contiguous()
+    parts = torch.full((rows, H, S, ops.ATTN_PART_REC), float("nan")).to(dev)
+    kc, vc = k0.clone().to(dev), v0.clone().to(dev)
+    ops.decode_attn_parts(qkv.to(dev), pos.to(dev), kc, vc, parts, 0.125, cos_t=None if cos is None else cos.to(dev), sin_t=None if sin is None else sin.to(dev),
+                          chunks=chunks)
+    pc = parts.cpu()
+    kc, vc = kc.cpu(), vc.cpu()
+    for r in range(rows):
+        p = int(pos[r])
+        m = pc[r, :, :, 0].double()
+        f = torch.where(torch.isinf(m), torch.zeros_like(m), torch.exp(m - m.max(1, keepdim=True).values))
+        got = ((f[:, :, None] * pc[r, :, :, 4:].double()).sum(1) / (f * pc[r, :, :, 1].double()).sum(1, keepdim=True)).reshape(-1)
+        q, k, v = (qkv[r].view(3, H, 64)[i].double() for i in range(3))
+        if rope:
+            rot = lambda t: torch.cat([-t[:, 32:], t[:, :32]], 1)
+            q, k = q * cos[p].double() + rot(q) * sin[p].double(), k * cos[p].double() + rot(k) * sin[p].double()
+        K_ = torch.cat([k0[r, :, :p].double(), k[:, None]], 1)
+        V_ = torch.cat([v0[r, :, :p].double(), v[:, None]], 1)
+        a = torch.softmax((K_ @ q[:, :, None]).squeeze(-1) * 0.125, -1)
+        want = (a[:, :, None] * V_).sum(1).reshape(-1)
+        assert (got - want).abs().max() < 1e-5, (r, float((got - want).abs().max()))
+        assert torch.allclose(kc[r, :, p].double(), k, atol=1e-6) and torch.equal(vc[r, :, p], qkv[r].view(3, H, 64)[2])
+        assert torch.equal(kc[r, :, :p], k0[r, :, :p]) and torch.equal(kc[r, :, p + 1:], k0[r, :, p + 1:])
+        assert torch.equal(vc[r, :, :p], v0[r, :, :p]) and torch.equal(vc[r, :, p + 1:], v0[r, :, p + 1:])

@@ -78,6 +78,9 @@ _OPS = [
     ("test_decode_attn_folds_qkv_partial_sums", (5, 16, 2, 1)), ("test_decode_attn_folds_qkv_partial_sums", (2, 12, 4, 0)),
     ("test_flash_relpos_equals_materialised_scores", (2, 150, 2, (150, 70))), ("test_flash_relpos_equals_materialised_scores", (3, 33, 1, (33, 1, 0))),
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
+    ("test_gemv_row", (40, 256, "plain", 0)), ("test_gemv_row", (1030, 256, "ln", 3)), ("test_gemv_row", (70, 1024, "ln", 8)), ("test_gemv_row", (33, 768, "plain", 2)),
+    ("test_gemv_row", (9, 4096, "plain", 0)), ("test_gemv_row", (256, 256, "attn", 1)), ("test_gemv_row", (50, 768, "attn", 2)),
+    ("test_decode_attn_parts", (8, 4, False)), ("test_decode_attn_parts", (3, 2, True)), ("test_decode_attn_parts", (16, 8, False)),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
         ("test_gemv_packed_residual_epilogue", (7, 1024, 1024, 8)), ("test_gemv_layernorm_fused", (5, 2304, 768, 4, False)),
@@ -667,3 +670,23 @@ def test_vocode_with_every_stage_seam_on_the_emulator(emu):
     assert torch.equal(out[False][1], out[True][1]), "mel differs"
     for a, b in zip(out[False][0], out[True][0]):
         assert a.numel() > 0 and torch.equal(a, b), f"max |diff| {(a - b).abs().max().item():.3e}"
+
+
+def test_t3_turbo_batch1_row_path_samples_the_oracles_tokens_on_the_emulator(emu):
+    """Batch 1 of T3-Turbo runs on the single-row kernels (T3TurboEngine._forward_decode_row): sampled ids == the CPU oracle's."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3_turbo import T3TurboEngine
+    from oracle import ref_torch as O
+    samp = dict(temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2)
+    L, d, steps = 1, 256, 5
+    sd = synth.t3_turbo_state_dict(L, d, 0)
+    text, cond = synth.turbo_text_tokens(9, seed=4), synth.t3_cond(seed=5, prompt_len=24)
+    u = synth.rand((1, steps + 1), seed=12)
+    eng = T3TurboEngine(sd, CPU)
+    assert eng.tune["row_path"]
+    calls = []
+    orig = eng._forward_decode_row
+    eng._forward_decode_row = lambda st: (calls.append(1), orig(st))[1]
+    toks = eng.generate(cond, [text], max_gen_len=steps, uniforms=u, ban_eos=True, use_graph=False, **samp)
+    ref = O.t3_inference_turbo(sd, L, d // 64, cond, text, steps, u[0], ban_eos=True, **samp)
+    assert len(calls) == steps and toks[0].tolist() == ref.tolist(), (len(calls), toks[0].tolist(), ref.tolist())

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
                 st[t][r] = sv;
                 mt = fmaxf(mt, sv);
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = fmaxf(mt, cbx_xor_lane<32>(mt));
         const float m_new = fmaxf(m_run, mt);
         float alpha = 1.f;
         if (m_new > -INFINITY) alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
     }
 
     // ---- finalise: both half-waves hold partial sums of the same query
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + cbx_xor_lane<32>(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.Tq) {
         float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void flash_relpos_f32_kernel(const FlashRelArg
                 st[t][r] = sv;
                 mt = fmaxf(mt, sv);
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = fmaxf(mt, cbx_xor_lane<32>(mt));
         const float m_new = fmaxf(m_run, mt);
         float alpha = 1.f;
         if (m_new > -INFINITY) alpha = __expf(m_run - m_new);  // m_run = -inf -> 0
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void flash_relpos_f32_kernel(const FlashRelArg
     }
 
     // ---- finalise: both half-waves hold partial sums of the same query
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + cbx_xor_lane<32>(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.T) {
         float* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
@@ -418,10 +418,10 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
             f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)pos * 64 + l16 * 4);
             d = kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
         }
-        d += __shfl_xor(d, 8);
-        d += __shfl_xor(d, 4);
-        d += __shfl_xor(d, 2);
-        d += __shfl_xor(d, 1);
+        d += cbx_xor_lane<8>(d);
+        d += cbx_xor_lane<4>(d);
+        d += cbx_xor_lane<2>(d);
+        d += cbx_xor_lane<1>(d);
         if (pos < ctx) {
             if (l16 == 0) sc[pos] = d;
             mx = fmaxf(mx, d);
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256) void decode_attn_f32_kernel(const float* __res
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        acc[e] += __shfl_xor(acc[e], 16);
-        acc[e] += __shfl_xor(acc[e], 32);
+        acc[e] += cbx_xor_lane<16>(acc[e]);
+        acc[e] += cbx_xor_lane<32>(acc[e]);
     }
     if (sub == 0) *reinterpret_cast<f32x4*>(&oacc[wid][l16 * 4]) = acc;
     __syncthreads();
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         }
         const float c = cos_t ? cos_t[(long)pos * 64 + lane] : 1.f, s = cos_t ? sin_t[(long)pos * 64 + lane] : 0.f;  // GPT-2: no RoPE
         const float sgn = lane < 32 ? -1.f : 1.f;
-        const float qn = qv * c + sgn * __shfl_xor(qv, 32) * s;
-        const float kn = kn0 * c + sgn * __shfl_xor(kn0, 32) * s;
+        const float qn = qv * c + sgn * cbx_xor_lane<32>(qv) * s;
+        const float kn = kn0 * c + sgn * cbx_xor_lane<32>(kn0) * s;
         q_s[lane] = qn * scale;
         k_new[lane] = kn;
         v_new[lane] = vn0;
@@ -612,10 +612,10 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
                 vd[u] = *reinterpret_cast<const f32x4*>(&v_new[l16 * 4]);
             }
             float t = kd[u][0] * qv4[0] + kd[u][1] * qv4[1] + kd[u][2] * qv4[2] + kd[u][3] * qv4[3];
-            t += __shfl_xor(t, 8);
-            t += __shfl_xor(t, 4);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 1);
+            t += cbx_xor_lane<8>(t);
+            t += cbx_xor_lane<4>(t);
+            t += cbx_xor_lane<2>(t);
+            t += cbx_xor_lane<1>(t);
             d[u] = p < p_hi ? t : -INFINITY;
             mt = fmaxf(mt, d[u]);
         }
@@ -781,12 +781,7 @@ extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v
     CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn: 16-byte alignment");
     FlashArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal};
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
-    static const int prefetch = getenv("CBX_FLASH_PREFETCH") ? atoi(getenv("CBX_FLASH_PREFETCH")) : 1;
-    if (prefetch) {
-        hipLaunchKernelGGL(flash_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    } else {
-        hipLaunchKernelGGL(flash_attn_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    }
+    hipLaunchKernelGGL(flash_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);  // (<false>: without the K / V register prefetch; measured slower in round 2)
     return cbx_check_launch("flash_attn");
 }
 
@@ -822,7 +817,7 @@ extern "C" int cbx_decode_attn_f32(const float* q, const float* kc, const float*
 // ---- process-wide TEST HOOKS of the positional entry point cbx_decode_attn_rope_f32 (tests / A-B scripts).  The engines do not use them: their
 // geometry and their split-context workspace travel per call in cbx_decode_attn_t (ABI v10), so two engines in one process -- or a hipGraph
 // captured earlier -- never see each other's settings.
-static int g_da_u = 0;  // 0: from the environment (CBX_DA_U) on first use, default 4
+static int g_da_u = 0;  // 0: the default, 4
 extern "C" int cbx_set_decode_attn_unroll(int u) {
     CBX_REQUIRE(u == 4 || u == 8 || u == 16, "decode_attn unroll must be 4, 8 or 16");
     g_da_u = u;
@@ -839,13 +834,13 @@ extern "C" int cbx_set_decode_attn_workspace(float* ws, int* zeroed_counters, lo
     g_da_pairs[d] = ws && zeroed_counters ? max_pairs : 0;
     return 0;
 }
-static int g_da_pipe = getenv("CBX_DA_PIPE") ? atoi(getenv("CBX_DA_PIPE")) : 0;
+static int g_da_pipe = 0;
 extern "C" int cbx_set_decode_attn_pipeline(int on) {  // bit 0: pipelined K / V stream; bit 1: non-temporal K / V loads; bit 2: speculative first step
     g_da_pipe = on & 7;
     return 0;
 }
 constexpr int DA_MAX_SPLIT = 8;
-static int g_da_split_min = getenv("CBX_DA_SPLIT_MIN") ? atoi(getenv("CBX_DA_SPLIT_MIN")) : 512;
+static int g_da_split_min = 512;
 extern "C" int cbx_set_decode_attn_split_min(int min_ctx) {
     CBX_REQUIRE(min_ctx >= 1, "decode_attn split threshold must be >= 1");
     g_da_split_min = min_ctx;
@@ -920,15 +915,13 @@ extern "C" int cbx_decode_attn_rope(const cbx_decode_attn_t* pd, void* stream) {
 extern "C" int cbx_decode_attn_rope_f32(const float* qkv, const int* positions, const float* cos_t, const float* sin_t, float* kc,
                                         float* vc, float* o, int rows, int n_heads, long ld_qkv, long o_ld, int o_packed,
                                         long cache_row_stride, long cache_head_stride, float scale, void* stream) {
-    if (g_da_u == 0) g_da_u = getenv("CBX_DA_U") ? atoi(getenv("CBX_DA_U")) : -1;  // key rows in flight per 16-lane group (-1: the default, 4)
-    static const int no_split = getenv("CBX_DA_NO_SPLIT") ? atoi(getenv("CBX_DA_NO_SPLIT")) : 0;
     cbx_decode_attn_t a{};
     a.qkv = qkv, a.positions = positions, a.cos_t = cos_t, a.sin_t = sin_t, a.kc = kc, a.vc = vc, a.o = o;
     a.rows = rows, a.n_heads = n_heads, a.ld_qkv = ld_qkv, a.o_ld = o_ld, a.o_packed = o_packed;
     a.cache_row_stride = cache_row_stride, a.cache_head_stride = cache_head_stride, a.scale = scale;
     a.unroll = g_da_u > 0 ? g_da_u : 0, a.pipeline = g_da_pipe, a.split_min = g_da_split_min;
     int d = 0;
-    if (!no_split && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) a.split_ws = g_da_ws[d], a.split_cnt = g_da_cnt[d], a.split_pairs = g_da_pairs[d];
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) a.split_ws = g_da_ws[d], a.split_cnt = g_da_cnt[d], a.split_pairs = g_da_pairs[d];
     return cbx_decode_attn_rope(&a, stream);
 }
 

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
                     mt = fmaxf(mt, sv);
                 }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = fmaxf(mt, cbx_xor_lane<32>(mt));
         const float m_new = fmaxf(m_run, mt);
         const float mc_new = m_new > -INFINITY ? m_new * sc : 0.f;  // a row that has seen no key yet: exp2(-inf - 0) = 0
         const float alpha = __builtin_amdgcn_exp2f(mc_run - mc_new);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pl_kernel(const FlashPlArgs
 #pragma unroll
     for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
     // ---- finalise: both half-waves hold partial sums of the same query.  O^T register r of d-tile dt is d = 32 dt + (r&3) + 8(r>>2) + 4 lh
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + cbx_xor_lane<32>(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.Tq) {
         _Float16* op = a.o + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NQW * 64, 2) void flash_attn_pl2_kernel(const Flash
 }  // namespace
 
 // default 4 since round 4: same-box A/B at the bench shape (profiles/r04_attn_planes_ab.log) 111.1-111.2 us against 114.4-115.5 for version 2, twice in a row
-static int g_attn_pl_version = getenv("CBX_ATTN_PL_VERSION") ? atoi(getenv("CBX_ATTN_PL_VERSION")) : 4;
+static int g_attn_pl_version = 4;  // TEST HOOK (cbx_set_attn_planes_version); callers pass their own version per call
 extern "C" int cbx_set_attn_planes_version(int v) {
     g_attn_pl_version = v;
     return 0;
@@ -555,7 +555,7 @@ extern "C" int cbx_flash_attn_planes_v(const void* q, const void* k, const void*
     a.diag = getenv("CBX_ATTN_DIAG") ? atoi(getenv("CBX_ATTN_DIAG")) : 0;
 #endif
     // versions 2 / 4 (256 queries per workgroup; 4 = the free-running loop, the default) serve the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
-    // (or CBX_ATTN_PL_VERSION) keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
+    // keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
     const int ver = version ? version : g_attn_pl_version;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;
     if (ver >= 2 && v2ok) {

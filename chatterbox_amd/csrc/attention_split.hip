@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
                     mt = fmaxf(mt, sv);
                 }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = fmaxf(mt, cbx_xor_lane<32>(mt));
         const float m_new = fmaxf(m_run, mt);
         const float m_sub = m_new > -INFINITY ? m_new : 0.f;  // a row that has seen no key yet: exp2(-inf - 0) = 0
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const FlashSpl
         for (int d = 0; d < 2; ++d) ot[d] += otc[d] * (1.0f / CBX_F16_LO_SCALE);
     }
     // ---- finalise: both half-waves hold partial sums of the same query
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + cbx_xor_lane<32>(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.Tq && a.o_planes) {  // attention output feeds the to_out projection only: written as the two fp16 planes that GEMM consumes
         _Float16* op = reinterpret_cast<_Float16*>(a.o) + (long)z * a.o_sb + (long)qi * a.o_st + head * 64;

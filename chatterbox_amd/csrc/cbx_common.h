@@ -153,14 +153,50 @@ __device__ __forceinline__ float cbx_act(float v, int act, float slope, float pa
     }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// x of lane (l ^ MASK), MASK a power of two < 64, WITHOUT the LDS crossbar: hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS round trip, ~100
+// cycles each; a 6-step butterfly is a dependent chain of six) -- here 1 / 2 are quad_perm DPP moves, 4 is a row_shl:4 / row_shr:4 pair under
+// bank masks, 8 is row_ror:8 (a rotation by half a 16-lane row IS the xor), 16 / 32 are v_permlane16_swap / v_permlane32_swap (gfx950).  Same
+// partner lane as __shfl_xor, so every reduction built on it keeps its results bit for bit (round 6).  The two operands of a swap must be
+// DIFFERENT registers (hipcc folds swap(x, x) into "both results equal"): the copy is made opaque.
+template <int MASK>
+__device__ __forceinline__ float cbx_xor_lane(float x) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "xor partner: a power of two below 64");
+    const int v = __builtin_bit_cast(int, x);
+    if constexpr (MASK == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4) {
+        int r = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);  // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11 of a row) take lane l + 4
+        r = __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);      // row_shr:4 -> banks 1, 3 take lane l - 4
+        return __builtin_bit_cast(float, r);
+    } else if constexpr (MASK == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true));  // row_ror:8
+    else {
+        unsigned a = (unsigned)v, b = a;
+        asm volatile("" : "+v"(b));
+        if constexpr (MASK == 16) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(a, b, false, false);  // odd rows of a <-> even rows of b
+            return __builtin_bit_cast(float, (threadIdx.x & 16) ? sw[0] : sw[1]);
+        } else {
+            const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // lanes 32-63 of a <-> lanes 0-31 of b
+            return __builtin_bit_cast(float, (threadIdx.x & 32) ? sw[0] : sw[1]);
+        }
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {  // the xor butterfly 32, 16, .. 1 (order and partners of rounds 1-5: same bits)
+    v += cbx_xor_lane<32>(v);
+    v += cbx_xor_lane<16>(v);
+    v += cbx_xor_lane<8>(v);
+    v += cbx_xor_lane<4>(v);
+    v += cbx_xor_lane<2>(v);
+    v += cbx_xor_lane<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    v = fmaxf(v, cbx_xor_lane<32>(v));
+    v = fmaxf(v, cbx_xor_lane<16>(v));
+    v = fmaxf(v, cbx_xor_lane<8>(v));
+    v = fmaxf(v, cbx_xor_lane<4>(v));
+    v = fmaxf(v, cbx_xor_lane<2>(v));
+    v = fmaxf(v, cbx_xor_lane<1>(v));
     return v;
 }
 

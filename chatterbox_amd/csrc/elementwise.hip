@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* qkv, const int* __r
     float* kp = qp + (long)n_heads * 64;
     const float* vp = kp + (long)n_heads * 64;
     const float qv = qp[d], kv = kp[d];
-    const float qo = __shfl_xor(qv, 32), ko = __shfl_xor(kv, 32);
+    const float qo = cbx_xor_lane<32>(qv), ko = cbx_xor_lane<32>(kv);
     const float sgn = d < 32 ? -1.f : 1.f;
     const float qn = qv * c + sgn * qo * s;
     const float kn = kv * c + sgn * ko * s;

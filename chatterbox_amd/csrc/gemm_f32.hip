@@ -328,8 +328,7 @@ int launch(const cbx_gemm_t& p, hipStream_t st) {
 
 // can the buffer-load loader serve this call?  (K tiles that never straddle the end of K or a conv tap, 31-bit byte offsets)
 bool fast_loader_ok(const cbx_gemm_t& p, int bk) {
-    static const int off = getenv("CBX_GEMM_GENERIC_LOADER") ? atoi(getenv("CBX_GEMM_GENERIC_LOADER")) : 0;
-    return !off && !p.w_kn && p.up == 1 && p.K % bk == 0 && p.Cin % bk == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
+    return !p.w_kn && p.up == 1 && p.K % bk == 0 && p.Cin % bk == 0 && (long)(p.Tin + 1) * p.lda * 4 < 0x7fffffffL &&
            (long)(p.N + 256) * p.ldw * 4 < 0x7fffffffL && (long)p.pad_left * p.lda * 4 < 0x3fffffffL;
 }
 
@@ -370,10 +369,9 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     }
     if (p.M <= 32) return launch<32, 128, 1, 4, false>(p, st);
     {
-        // precision 0 = library default (CBX_GEMM_PRECISION, else exact); 1 = exact fp32 MFMA; 3 / 6 = fp32 rebuilt from
+        // precision 0 = exact; 1 = exact fp32 MFMA; 3 / 6 = fp32 rebuilt from
         // 3 / 6 bf16 plane products on the 16x faster bf16 matrix cores, 16 = from 3 fp16 plane products (gemm_split.hip)
-        static const int env_prec = getenv("CBX_GEMM_PRECISION") ? atoi(getenv("CBX_GEMM_PRECISION")) : 1;
-        const int prec = p.precision ? p.precision : env_prec;
+        const int prec = p.precision ? p.precision : 1;
         CBX_REQUIRE(prec == 1 || prec == 3 || prec == 6 || prec == 16, "gemm: precision must be 0, 1, 3, 6 or 16 (got %d)", prec);
         if (prec != 1) {
             int rc = cbx_gemm_split_dispatch(p, prec == 16 ? 16 : prec == 3 ? 2 : 3, st);
@@ -382,23 +380,9 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
         }
     }
     if (p.N <= 64) return launch<128, 64, 2, 2, false>(p, st);
-    {
-        // 256 CUs: a grid below ~2 workgroups per CU leaves each SIMD with a single in-order wave (no latency hiding)
-        static const int force = getenv("CBX_GEMM_TILE") ? atoi(getenv("CBX_GEMM_TILE")) : 0;
-        const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1 * p.nz2;
-        // measured on the CFM / HiFT shapes (bench.py, MI355X): 64x64 tiles 492 ms per flow pass, 128x64 543, 64x128 536,
-        // 128x128 803 -- the single-stage pipeline needs many co-resident waves to hide its load->LDS->barrier latency
-        (void)g128;
-        if (force == 128) return launch<128, 128, 2, 2, false>(p, st);
-        if (force == 1288) return launch<128, 128, 2, 4, false>(p, st);   // 8 waves: 64x32 per wave
-        if (force == 12864) return launch<128, 64, 4, 2, false>(p, st);   // 8 waves: 32x32 per wave
-        if (force == 64128) return launch<64, 128, 2, 2, false>(p, st);
-        if (force == 64) return launch<128, 64, 2, 2, false>(p, st);
-        if (force == 6464) return launch<64, 64, 2, 2, false>(p, st);
-        // BK = 32 halves the barriers and loader work per MFMA; a K tile must stay inside one conv tap
-        if (force == 32 && (p.taps == 1 || p.Cin % 32 == 0)) return launch<128, 64, 4, 2, false, 32>(p, st);
-        if (!force && fast_loader_ok(p, 16)) return launch<128, 64, 4, 2, false, 16, 1>(p, st);
-        return launch<128, 64, 4, 2, false>(p, st);  // 8 waves x (32x32): 81 TF/s on the bench mix vs 77 for 64x64 (4 waves)
-    }
-    return launch<128, 128, 2, 2, false>(p, st);
+    // measured on the CFM / HiFT shapes (bench.py, MI355X): 64x64 tiles 492 ms per flow pass, 128x64 543, 64x128 536, 128x128 803 -- the
+    // single-stage pipeline needs many co-resident waves to hide its load->LDS->barrier latency; 8 waves x (32x32): 81 TF/s on the bench mix
+    // vs 77 for 64x64 (4 waves).  (Rounds 1-2 A/B'd six more tile forms through an environment knob; the losers are gone with it.)
+    if (fast_loader_ok(p, 16)) return launch<128, 64, 4, 2, false, 16, 1>(p, st);
+    return launch<128, 64, 4, 2, false>(p, st);
 }

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
 }
 
-int g_pl_persist = getenv("CBX_PL_PERSIST") ? atoi(getenv("CBX_PL_PERSIST")) : 1;
+int g_pl_persist = 1;  // TEST HOOK: cbx_set_planes_persist
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
 int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
@@ -582,7 +582,7 @@ int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
 
 }  // namespace
 
-static int g_pl_tile = getenv("CBX_PL_TILE") ? atoi(getenv("CBX_PL_TILE")) : 0;
+static int g_pl_tile = 0;  // TEST HOOK: cbx_set_planes_tile (callers pass cbx_gemm_pl_t.tile per call)
 extern "C" int cbx_set_planes_tile(int t) {
     g_pl_tile = t;
     return 0;
@@ -645,7 +645,7 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     int force = p.tile ? p.tile : g_pl_tile;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     if (force == CBX_PL_TILE_CORESIDENT) {    // one 8-wave workgroup per CU (96 KiB of LDS, <= 120 VGPRs); small grids / narrow outputs keep their forms (they never fill a CU)
         const long g128c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
-        static const int co_k64 = getenv("CBX_PL_CORES_K64") ? atoi(getenv("CBX_PL_CORES_K64")) : 8;  // 8 = the 128 x 128 x 64 two-stage form (128 KiB, 8 waves x 117 VGPRs): 214.5x against 211.3x for form 17 in the throughput schedule, same box (A/B hook)
+        constexpr int co_k64 = 8;  // 8 = the 128 x 128 x 64 two-stage form (128 KiB, 8 waves x 117 VGPRs): 214.5x against 211.3x for form 17 in the throughput schedule, same box (A/B hook)
         force = (g128c < 64 || p.N <= 96) ? 0 : (k64 ? co_k64 : 17);
     }
     // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log

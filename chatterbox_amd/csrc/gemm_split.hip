@@ -406,7 +406,7 @@ int launch_split(const cbx_gemm_t& p, hipStream_t st) {
 
 }  // namespace
 
-static int g_split_tile = getenv("CBX_SPLIT_TILE") ? atoi(getenv("CBX_SPLIT_TILE")) : 0;
+static int g_split_tile = 0;
 // tuning knob: 0 = automatic, 64 / 12864 / 128 force a tile shape, 1286401 / 12801 = the single-LDS-stage forms
 extern "C" int cbx_set_split_tile(int t) {
     g_split_tile = t;
@@ -433,8 +433,7 @@ extern "C" int cbx_set_range_flag(int* dev_flag) {
 // dispatcher below that do not depend on the caller's other operands: no forced tile, the buffer-load loader usable (31-bit offsets,
 // no CBX_SPLIT_GENERIC_LOADER), K % 32 == 0.  The caller additionally needs precision 16, taps == 1, one batch, no lens.
 static int split_generic_loader_forced() {
-    static const int no_fast = getenv("CBX_SPLIT_GENERIC_LOADER") ? atoi(getenv("CBX_SPLIT_GENERIC_LOADER")) : 0;
-    return no_fast;
+    return 0;  // (the generic loader of round 1 is kept for shapes the buffer-load loader does not serve)
 }
 extern "C" int cbx_gemm_ln_fusable(long M, int K, long lda) {
     if (g_split_tile || split_generic_loader_forced()) return 0;

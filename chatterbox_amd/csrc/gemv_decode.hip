@@ -269,11 +269,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             float v = ss[t];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v += cbx_xor_lane<16>(v);
+            v += cbx_xor_lane<32>(v);
             float u = sx[t];
-            u += __shfl_xor(u, 16);
-            u += __shfl_xor(u, 32);
+            u += cbx_xor_lane<16>(u);
+            u += cbx_xor_lane<32>(u);
             if (q == 0) {
                 ssq[(w * MT + t) * 16 + c] = v;
                 ssx[(w * MT + t) * 16 + c] = u;
@@ -447,10 +447,10 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
         for (int r = 0; r < 4; ++r) red[(w * CT + c) * 256 + (q * 4 + r) * 16 + c16] = acc[c][r];
     {
         float v = ss, u = sx;
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        u += __shfl_xor(u, 16);
-        u += __shfl_xor(u, 32);
+        v += cbx_xor_lane<16>(v);
+        v += cbx_xor_lane<32>(v);
+        u += cbx_xor_lane<16>(u);
+        u += cbx_xor_lane<32>(u);
         if (q == 0) ssq[w * 16 + c16] = v, ssx[w * 16 + c16] = u;
     }
     __syncthreads();
@@ -504,8 +504,8 @@ int launch_ct(const cbx_gemv_t& p, hipStream_t st) {
 }
 
 // process-wide TEST HOOKS: ORed into cbx_gemv_t.flags of every cbx_gemv_f32 launch (the engines set the flags per launch instead)
-int g_gemv_deep = getenv("CBX_GEMV_DEEP") ? atoi(getenv("CBX_GEMV_DEEP")) : 0;  // cbx_set_gemv_deep_batches
-int g_gemv_pre_epi = getenv("CBX_GEMV_PRE_EPI") ? atoi(getenv("CBX_GEMV_PRE_EPI")) : 0;  // cbx_set_gemv_epilogue_prefetch
+int g_gemv_deep = 0;     // cbx_set_gemv_deep_batches
+int g_gemv_pre_epi = 0;  // cbx_set_gemv_epilogue_prefetch
 
 template <int MT, bool SWIGLU, bool PK, bool XPK, bool RMS, int NP = 0, bool WB = false>
 int launch_nw(const cbx_gemv_t& p, hipStream_t st) {

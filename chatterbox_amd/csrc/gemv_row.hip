@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void decode_attn_parts_kernel(const cbx_attn_p
         f32x4 qo, ko;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            qo[e] = __shfl_xor(q4[e], 8);
-            ko[e] = __shfl_xor(kn[e], 8);
+            qo[e] = cbx_xor_lane<8>(q4[e]);
+            ko[e] = cbx_xor_lane<8>(kn[e]);
         }
         q4 = q4 * c + qo * s * sgn;
         kn = kn * c + ko * s * sgn;
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void decode_attn_parts_kernel(const cbx_attn_p
                 *reinterpret_cast<f32x4*>(a.vc + (vb - a.vc) + (long)pos * 64 + l16 * 4) = vn;
             }
             float t = kv[u][0] * q4[0] + kv[u][1] * q4[1] + kv[u][2] * q4[2] + kv[u][3] * q4[3];
-            t += __shfl_xor(t, 8);
-            t += __shfl_xor(t, 4);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 1);
+            t += cbx_xor_lane<8>(t);
+            t += cbx_xor_lane<4>(t);
+            t += cbx_xor_lane<2>(t);
+            t += cbx_xor_lane<1>(t);
             d[u] = pp <= pos ? t : -INFINITY;
             mt = fmaxf(mt, d[u]);
         }

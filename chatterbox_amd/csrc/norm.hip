@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
         pv[i] = post_add ? *reinterpret_cast<const f32x4*>(post_add + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     auto group_sum = [](float t) {
-        t += __shfl_xor(t, 8);
-        t += __shfl_xor(t, 4);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 1);
+        t += cbx_xor_lane<8>(t);
+        t += cbx_xor_lane<4>(t);
+        t += cbx_xor_lane<2>(t);
+        t += cbx_xor_lane<1>(t);
         return t;
     };
 #pragma unroll
@@ -185,7 +185,7 @@ extern "C" int cbx_layernorm_f32(const float* x, float* y, const float* w, const
     CBX_REQUIRE(x && y && w, "layernorm: null operand");
     CBX_REQUIRE(C % 4 == 0 && C <= 4096 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: C=%d ldx=%ld ldy=%ld", C, ldx, ldy);
     if (rows <= 0) return 0;
-    static const int narrow = getenv("CBX_LN_NARROW") ? atoi(getenv("CBX_LN_NARROW")) : 1;
+    constexpr int narrow = 1;  // (2: the two-rows-per-wave form, 0: the generic kernel -- measured slower at C = 256: profiles/r02_layernorm_variants.log)
     if (narrow && C == 256 && rows >= 64) {
         if (narrow == 2)
             hipLaunchKernelGGL((layernorm_narrow_kernel<4, 2>), dim3((unsigned)((rows + 31) / 32)), dim3(256), cbx_coresident_lds((hipStream_t)stream, 0, 2), (hipStream_t)stream, x, y, w,

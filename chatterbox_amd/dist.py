@@ -91,3 +91,50 @@ def gather_waveforms(wavs, dst=0, force=False):
         for i in range(int(shapes[r][0])):
             out.append(blocks[r][i, : int(all_lens[r][i])].cpu())
     return out
+
+
+class AsyncGatherer:
+    """C2 off the critical path of a stream of batches (engine.synthesize_pipelined): `post(wavs)` hands a finished batch to ONE background
+    thread that runs `gather_waveforms` for the batches in the order they were posted (every rank posts the same number of batches in the same
+    order, so the collectives line up); the posting thread goes on enqueueing the next batch.  `close()` waits for the gathers still in flight
+    and returns, on `dst`, one list of waveforms per posted batch (None elsewhere) -- call it before any other collective of the process group
+    (the barrier that ends a timed region).  Without an initialised process group (one GPU) a post is a host copy and no thread is started."""
+
+    def __init__(self, dst=0, force=False):
+        import queue
+        import threading
+        self.dst, self.force, self.results, self.error = dst, force, [], None
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        self._q = queue.Queue() if self.active else None
+        self._thread = None
+        if self.active:
+            dev = torch.cuda.current_device() if dist.get_backend() == "nccl" else None
+
+            def run():
+                try:
+                    if dev is not None:
+                        torch.cuda.set_device(dev)
+                    while True:
+                        item = self._q.get()
+                        if item is None:
+                            return
+                        self.results.append(gather_waveforms(item, dst=self.dst, force=self.force))
+                except BaseException as e:  # re-raised by close()
+                    self.error = e
+            self._thread = threading.Thread(target=run, name="cbx-c2-gather", daemon=True)
+            self._thread.start()
+
+    def post(self, wavs):
+        if self.active:
+            self._q.put(list(wavs))
+        else:
+            self.results.append([w.detach().cpu() for w in wavs])
+
+    def close(self):
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join()
+            self._thread = None
+            if self.error is not None:
+                raise self.error
+        return self.results

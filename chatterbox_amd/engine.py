@@ -149,11 +149,11 @@ class ChatterboxEngine:
     def co_resident(self, on):
         """Both stages on (or off) the kernel forms whose workgroups can share a CU with the other stage's (T3Engine.co_resident, FlowEngine.co_resident)."""
         if self.t3 is not None and hasattr(self.t3, "co_resident"):
-            self.t3.co_resident(on and os.environ.get("CBX_PIPE_T3_CORES", "1") != "0")  # (A/B hook)
+            self.t3.co_resident(on)
         self.flow.co_resident(on)
 
     @torch.inference_mode()
-    def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, t3_in_flight=2, **kw):
+    def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, t3_in_flight=2, stream_priorities=(-1, 0), **kw):
         """Throughput mode for a stream of batches: T3 of batch k+1 runs on a high-priority HIP stream WHILE the flow
         matching + vocoder of batch k run on a second stream.  jobs: list of dicts(text_tokens=[...], t3_conds=..., gen_ref=...); yields
         (wavs, tokens, latency_s) per job in order.  Results are identical to synthesize() called per job.
@@ -170,21 +170,19 @@ class ChatterboxEngine:
         import threading
         torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
         if not hasattr(self, "_s_t3"):
-            pt3, pvoc = (int(x) for x in os.environ.get("CBX_PIPE_PRIO", "-1,0").split(","))  # (A/B hook: stream priorities of the T3 / flow streams)
+            pt3, pvoc = stream_priorities  # HIP priorities of the T3 / flow streams (measured: no effect either way, profiles/r05_throughput_schedule_sweep.log)
             self._s_t3 = torch.cuda.Stream(device=self.dev, priority=pt3)
             self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=pt3) for _ in range(2)]  # one per T3 state in flight
             self._s_voc = torch.cuda.Stream(device=self.dev, priority=pvoc)
         t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
                                     "ban_from") if k in kw}
-        if os.environ.get("CBX_PIPE_CORES") is not None:  # A/B hook
-            co_resident = os.environ["CBX_PIPE_CORES"] != "0"
         self.co_resident(bool(co_resident))
         # ... and the flow + vocoder stream carries the co-resident ATTRIBUTE: its LayerNorm / split-GEMM launches (encoder, vocoder) keep to one or two
         # workgroups per CU as well (cbx_set_stream_coresident; no effect on results)
         from ._lib import check, lib
         # (with TWO T3 batches in flight the flow stream is the critical one and T3 has slack: capping its short LayerNorm launches costs more than the
-        # decode chains gain -- 217.2x with the attribute, 220.8x without, same box; it stays on for t3_in_flight = 1.  CBX_PIPE_STREAM_ATTR: A/B hook)
-        attr = bool(co_resident) and os.environ.get("CBX_PIPE_STREAM_ATTR", "1" if t3_in_flight < 2 else "0") != "0"
+        # decode chains gain -- 217.2x with the attribute, 220.8x without, same box; it stays on for t3_in_flight = 1)
+        attr = bool(co_resident) and t3_in_flight < 2
         check(lib.cbx_set_stream_coresident(self._s_voc.cuda_stream, int(attr)), "cbx_set_stream_coresident")
         torch.cuda.synchronize()
 
@@ -234,7 +232,7 @@ class ChatterboxEngine:
         #      round trip are off its critical path); this thread waits for T3(k)'s END EVENT on the vocoder stream, fetches its tokens there (a copy on the
         #      T3 stream would queue behind T3(k + 1)) and enqueues flow + vocoder(k) beside T3(k + 1).
         import queue
-        n_t3 = max(1, min(3, int(os.environ.get("CBX_PIPE_T3_STREAMS", t3_in_flight))))
+        n_t3 = max(1, min(3, int(t3_in_flight)))
         q, stop = queue.Queue(), threading.Event()
         n_slots = max(2, n_t3)
         slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
@@ -255,23 +253,17 @@ class ChatterboxEngine:
             except BaseException as e:  # re-raised by the consumer thread
                 q.put(e)
 
-        # ---- (A/B hook, OFF by default: CBX_PIPE_HIFT_STREAM=1) the vocoder of batch k on its OWN stream (behind an event), its audio fetched one batch later, so
-        #      that the flow stream runs encoder + CFM(k + 1) right behind CFM(k).  Measured WORSE -- 208.9x against 226.3x, same box (profiles/
-        #      r05_throughput_schedule_sweep.log): a fourth stream of chip-filling work thrashes like a third decode chain does.  Either way consecutive batches
-        #      report fp16-range trips into alternating flag words (ops.select_range_flag: a launch carries the word that was registered when it was ENQUEUED).
+        # (the vocoder of batch k on a stream of its own was measured WORSE -- 208.9x against 226.3x, same box, profiles/r05_throughput_schedule_sweep.log: a
+        # fourth stream of chip-filling work thrashes like a third decode chain does -- and is gone.)  Consecutive batches report fp16-range trips into
+        # alternating flag words (ops.select_range_flag: a launch carries the word that was registered when it was ENQUEUED).
         import collections
-        if not hasattr(self, "_s_hift"):
-            self._s_hift = torch.cuda.Stream(device=self.dev)
-        split_hift = os.environ.get("CBX_PIPE_HIFT_STREAM", "0") != "0"
         inflight = collections.deque()
         voc_kw = dict(n_cfm_timesteps=kw.get("n_cfm_timesteps", 10), drop_last_token=kw.get("drop_last_token", True))
 
         def start_voc(job, st, which):
             ops.select_range_flag(self.dev, which)
             with torch.cuda.stream(self._s_voc):
-                wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"), sync=False,
-                                      hift_stream=self._s_hift if split_hift else None, **voc_kw)
-            with torch.cuda.stream(self._s_hift if split_hift else self._s_voc):
+                wavs, _ = self.vocode(st, job["gen_ref"], z=job.get("z"), phase=job.get("phase"), noise=job.get("noise"), sync=False, **voc_kw)
                 host = [torch.empty(w.shape, dtype=w.dtype, pin_memory=True).copy_(w, non_blocking=True) for w in wavs]
                 ev = torch.cuda.Event()
                 ev.record()
@@ -306,8 +298,7 @@ class ChatterboxEngine:
                 st = tokens_of(toks)
                 host, evv = start_voc(job, st, k % 2)
                 inflight.append((job, st, t0, host, evv, k % 2))
-                if len(inflight) > (1 if split_hift else 0):
-                    yield finish(*inflight.popleft())
+                yield finish(*inflight.popleft())
             while inflight:
                 yield finish(*inflight.popleft())
         finally:
@@ -316,6 +307,8 @@ class ChatterboxEngine:
                 sem.release()
             th.join()
             ops.select_range_flag(self.dev, 0)
+            torch.cuda.synchronize()
+            self.co_resident(False)  # callers of vocode() / flow.inference() / synthesize_stream() get the fastest-alone forms back
 
 
 def _stream_plan(n_tokens, done, exhausted, lookahead):

@@ -304,7 +304,11 @@ def layernorm_planes(x, w, b, out, eps=1e-5, act=NONE, post_add=None, scale=1.0)
 
 # launch geometry of the plane-format kernels issued inside `with planes_geometry(tile, attn_version)` (cbx_gemm_pl_t.tile / the version argument of
 # cbx_flash_attn_planes_v: per-call descriptor fields since ABI v13, nothing process-wide); (0, 0) = the library's measured defaults
-_PLANES_GEOM = [0, 0]  # (only the flow's own host thread enters planes_geometry)
+def _planes_geom():
+    """(tile form, attention version) of the calling HOST THREAD's planes_geometry scope -- thread-local like the GEMM precision (a plane
+    GEMM issued by another thread while the flow thread sits inside a scope must not pick the scope's forms up)."""
+    return getattr(_TLS, "planes_geom", (0, 0))
+
 
 
 class planes_geometry:
@@ -312,11 +316,11 @@ class planes_geometry:
         self.new = [int(tile), int(attn_version)]
 
     def __enter__(self):
-        self.old = list(_PLANES_GEOM)
-        _PLANES_GEOM[:] = self.new
+        self.old = _planes_geom()
+        _TLS.planes_geom = tuple(self.new)
 
     def __exit__(self, *a):
-        _PLANES_GEOM[:] = self.old
+        _TLS.planes_geom = self.old
 
 
 def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, act_slope=0.0, alpha=1.0, lens=None, Cin=0, taps=1, dil=1,
@@ -339,7 +343,7 @@ def gemm_planes(A, W, *, M, N, K, C=None, P=None, bias=None, R=None, act=NONE, a
     if P is not None:
         p.ldp, p.p_lo, p.p_s1 = P.ld, P.lo, p_s1
     p.reserved0 = GEMM_DIAG
-    p.tile = _PLANES_GEOM[0] if tile is None else int(tile)
+    p.tile = _planes_geom()[0] if tile is None else int(tile)
     if ln is not None:
         assert lnp is not None and N == 256
         p.ln_w, p.ln_b, p.LNP, p.ld_lnp, p.lnp_lo, p.lnp_s1, p.ln_eps = _p(_f32(ln[0], "ln_w")), _p(ln[1]), lnp.ptr, lnp.ld, lnp.lo, lnp_s1, ln_eps
@@ -375,7 +379,7 @@ def flash_attn_planes(q, k, vt, out, *, Z, H, T, vt_sb, scale, key_lens=None, ca
     args = (q.ptr, k.ptr, vt.ptr, out.ptr, _p(key_lens), Z, H, T, T, T * q.ld, q.ld, q.lo, T * k.ld, k.ld, k.lo, vt_sb, vt.ld, vt.lo,
             T * out.ld, out.ld, out.lo, scale, int(causal))
     _timed("flash_attn_planes", 4.0 * Z * H * T * T * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * 4 * T,
-           lambda: check(lib.cbx_flash_attn_planes_v(*args, _PLANES_GEOM[1] if version is None else int(version), _stream()), "cbx_flash_attn_planes_v"))
+           lambda: check(lib.cbx_flash_attn_planes_v(*args, _planes_geom()[1] if version is None else int(version), _stream()), "cbx_flash_attn_planes_v"))
     return out
 
 
@@ -547,8 +551,8 @@ class DecodeAttnGeom:
 
     def __init__(self, device, unroll=0, pipeline=0, split_min=None, max_pairs=128, split=True):
         dev = torch.device(device)
-        if split_min is None:  # 0 = the library's 512; CBX_DA_SPLIT_MIN: A/B scripts
-            split_min = int(os.environ.get("CBX_DA_SPLIT_MIN", "0") or 0)
+        if split_min is None:  # 0 = the library's 512
+            split_min = 0
         self.unroll, self.pipeline, self.split_min, self.max_pairs = int(unroll), int(pipeline), int(split_min), int(max_pairs)
         self.ws = torch.empty(max_pairs * 8 * 66, dtype=torch.float32, device=dev) if split else None
         self.cnt = torch.zeros(max_pairs, dtype=torch.int32, device=dev) if split else None

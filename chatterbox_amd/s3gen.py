@@ -136,9 +136,6 @@ class FlowEngine:
         Same arithmetic, bit-identical mel."""
         from ._lib import ATTN_PL_CORESIDENT, PL_TILE_CORESIDENT
         self.gemm_tile, self.attn_version = (PL_TILE_CORESIDENT, ATTN_PL_CORESIDENT) if on else (0, 0)
-        if on:  # A/B hooks (scripts/profile_r05_q.sh)
-            self.gemm_tile = int(os.environ.get("CBX_PIPE_TILE", self.gemm_tile))
-            self.attn_version = int(os.environ.get("CBX_PIPE_ATTN", self.attn_version))
 
     # ------------------------------------------------------------------ conformer encoder
     def _rel_pos_table(self, T, dev=None, dm=512):

@@ -207,14 +207,25 @@ class T3Engine:
         """Switch the decode geometry of THIS engine: `tune` replaces self.tune, `knobs` (da_pipe, da_u, deep, pre_epi) the launch knobs of the
         decode attention / GEMV load batches -- per-call descriptor fields since ABI v10, so another engine in the process keeps its own.
         Captured decode graphs and C step descriptors bake the geometry in: they are dropped."""
-        from .autotune import LIB_KNOBS
+        from .autotune import LIB_KNOBS, canon
+        old_key = canon(self.tune, self.knobs) + (("shallow", int(bool(self.knobs.get("shallow")))),)
         self.tune = dict(tune)
         self.knobs = dict(LIB_KNOBS, **(knobs or {}))
         assert int(self.knobs["da_pipe"]) in range(8) and int(self.knobs["da_u"]) in (4, 8, 16)
+        new_key = canon(self.tune, self.knobs) + (("shallow", int(bool(self.knobs.get("shallow")))),)
         for st in self._state.values():
-            st["graph"] = None
-            st.pop("cstep", None)
+            # the captured graph / C step descriptor of a state are kept PER GEOMETRY (ADVICE r05: alternating synthesize() and synthesize_pipelined()
+            # re-captured the decode graph on every switch); they reference the state's own buffers and the weight images, which both outlive the switch
+            cache = st.setdefault("geom_cache", {})
+            cache[old_key] = (st.get("graph"), st.pop("cstep", None))
+            st["graph"], cstep = cache.pop(new_key, (None, None))
+            if cstep is not None:
+                st["cstep"] = cstep
             self._sync_geom(st)
+        if getattr(self, "_co_res", False) and not getattr(self, "_co_switching", False):
+            # a geometry adopted WHILE the co-resident form is on becomes the one co_resident(False) returns to (its co-resident keys aside)
+            self._co_saved = (dict(self._co_saved[0], **{k: v for k, v in self.tune.items() if k not in ("half_tiles", "d_ks2", "d_nw2")}),
+                              dict(self._co_saved[1], **{k: v for k, v in self.knobs.items() if k != "shallow"}))
 
     def co_resident(self, on):
         """The decode step on the geometry whose workgroups fit on a CU BESIDE a co-resident flow workgroup (engine.synthesize_pipelined; profiles/r05_overlap_*):
@@ -223,11 +234,15 @@ class T3Engine:
         on=False: back to the engine's default geometry.  Switching drops the captured decode graphs."""
         if getattr(self, "_co_res", False) == bool(on):
             return
-        if on:
-            self._co_saved = (dict(self.tune), dict(self.knobs))
-            self.apply_variant(dict(self.tune, half_tiles=0, d_ks2=4, d_nw2=8), dict(self.knobs, shallow=1))
-        else:
-            self.apply_variant(*self._co_saved)
+        self._co_switching = True
+        try:
+            if on:
+                self._co_saved = (dict(self.tune), dict(self.knobs))
+                self.apply_variant(dict(self.tune, half_tiles=0, d_ks2=4, d_nw2=8), dict(self.knobs, shallow=1))
+            else:
+                self.apply_variant(*self._co_saved)
+        finally:
+            self._co_switching = False
         self._co_res = bool(on)
 
     @ops.on_device
@@ -245,6 +260,7 @@ class T3Engine:
         self._prepare_tune()
         st["graph"] = None
         st.pop("cstep", None)
+        st.pop("geom_cache", None)
         gen = torch.Generator(device=self.dev).manual_seed(20240229)
         for k in ("kc", "vc"):
             st[k].normal_(0.0, 0.5, generator=gen)

@@ -71,7 +71,7 @@ typedef struct cbx_gemm_t {
     long ldc, c_s1, c_s2;
     long ldr, r_s1, r_s2;
     long ldc2, c2_s1, c2_s2;
-    int precision;            /* 0 = library default (exact unless CBX_GEMM_PRECISION is set); 1 = exact fp32 MFMA
+    int precision;            /* 0 = exact; 1 = exact fp32 MFMA
                                  (bitwise an fmaf chain); 3 = "bf16x3", 6 = "bf16x6": every fp32 operand split into 2 / 3
                                  bf16 planes and the product rebuilt from 3 / 6 bf16-MFMA plane products with fp32
                                  accumulation (rel. error ~4e-6 / ~1e-7; fp32 MFMA ~2.5e-7); 16 = "f16x3": two fp16 planes
@@ -236,7 +236,7 @@ int cbx_gemv_f32(const cbx_gemv_t* p, void* stream);
  * 162, so that its workgroups fit on a CU beside a workgroup of ANOTHER stream that leaves half of the register file free (the throughput schedule of
  * ChatterboxEngine.synthesize_pipelined: T3 of batch k + 1 beside flow + vocoder of batch k).  Same products, same order: bit-identical. */
 #define CBX_GEMV_SHALLOW 4
-/* TEST HOOKS (env CBX_GEMV_DEEP / CBX_GEMV_PRE_EPI, default 0): OR the bit into the flags of EVERY cbx_gemv_f32 launch of the process. */
+/* TEST HOOKS (default 0): OR the bit into the flags of EVERY cbx_gemv_f32 launch of the process. */
 int cbx_set_gemv_deep_batches(int on);
 int cbx_set_gemv_epilogue_prefetch(int on);
 /* x += sum_k part[k] (fixed order), h = RMSNorm(x) * w : residual add + split-K reduce + LlamaRMSNorm in one pass (the residual /
@@ -371,7 +371,7 @@ int cbx_decode_attn_parts(const cbx_attn_parts_t* p, void* stream);
 /* tuning knob: tile shape of the split-bf16 GEMM (0 = automatic; 64, 12864, 128, 1282) */
 int cbx_set_split_tile(int t);
 /* TEST HOOKS of the positional cbx_decode_attn_rope_f32 (process-wide; the engines pass cbx_decode_attn_t instead): unroll / pipeline /
- * split_min as the fields above (env CBX_DA_U, CBX_DA_PIPE, CBX_DA_SPLIT_MIN), and the workspace it splits through, registered for the calling
+ * split_min as the fields above, and the workspace it splits through, registered for the calling
  * thread's current device (single-stream use only). */
 int cbx_set_decode_attn_unroll(int u);
 int cbx_set_decode_attn_pipeline(int on);

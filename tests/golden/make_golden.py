@@ -17,6 +17,9 @@ import os
 import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import provenance  # noqa: E402
 import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -80,7 +83,7 @@ def golden_t3(name, n_layers, steps, n_text):
     print(f"[{name}] ref tokens {r['tokens'].tolist()}")
     print(f"[{name}] oracle-vs-reference raw logits max-abs {err:.3e}; tokens equal: {torch.equal(toks, r['tokens'])}")
     assert err < 2e-3 and torch.equal(toks, r["tokens"])
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, steps=steps, n_text=n_text,
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), n_layers=n_layers, steps=steps, n_text=n_text,
                         tokens=r["tokens"].numpy(), logits_sub=r["raw"][:, :, LOGIT_IDX].numpy(),
                         logit_idx=LOGIT_IDX.numpy(), uniforms=r["u"].numpy(), fp=fingerprint(r["sd"]))
 
@@ -135,7 +138,7 @@ def golden_s3gen(name, P, N, n_steps=10):
     f0 = O.f0_predict(sd, mel)
     print(f"[{name}] f0 range {f0.min():.1f}..{f0.max():.1f}, voiced frac {(f0 > 10).float().mean():.2f}")
     assert e_mel.mean() < 1e-4 and e_src < 1e-3 and e_w2 < 1e-4
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), P=P, N=N, n_steps=n_steps, mel=mel[0].numpy(),
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), P=P, N=N, n_steps=n_steps, mel=mel[0].numpy(),
                         wav=wav[0].numpy(), src=src[0, 0, ::7].numpy(), fp=fingerprint(sd))
 
 
@@ -180,7 +183,7 @@ def golden_t3_turbo(name, n_layers, d, steps, n_text, cfg_name):
     print(f"[{name}] ref tokens {toks[0].tolist()}\n[{name}] oracle-vs-reference logits max-abs {err:.3e}; tokens equal: {torch.equal(o_toks, toks[0])}")
     assert err < 2e-3 and torch.equal(o_toks, toks[0])
     idx = torch.arange(0, 6563, 13)
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
                         logits_sub=raw[:, idx].numpy(), logit_idx=idx.numpy(), uniforms=u.numpy(), fp=fingerprint({k: v for k, v in sd.items() if k != "tfmr.wte.weight"}))
 
 
@@ -205,7 +208,7 @@ def golden_meanflow(name, P, N):
     e = (o_mel - mel).abs()
     print(f"[{name}] meanflow mel std {mel.std():.3f}; oracle-vs-ref L1 {e.mean():.3e} max {e.max():.3e}")
     assert e.mean() < 1e-4
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), P=P, N=N, mel=mel[0].numpy(), fp=fingerprint(sd))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), P=P, N=N, mel=mel[0].numpy(), fp=fingerprint(sd))
 
 
 if __name__ == "__main__":

@@ -20,6 +20,9 @@ import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import provenance  # noqa: E402
 import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -92,7 +95,7 @@ def golden_t3_b8(name="t3_l30_b8", n_layers=30, steps=250, n_text=64, B=8, check
         all_log.append(raw[step_idx][:, :, logit_idx].numpy())
         all_u.append(u.numpy())
         gaps.append(np.array(gap))
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, steps=steps, n_text=n_text, B=B,
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), n_layers=n_layers, steps=steps, n_text=n_text, B=B,
                         tokens=np.stack(all_tok), logits_sub=np.stack(all_log).astype(np.float32), step_idx=step_idx.numpy(),
                         logit_idx=logit_idx.numpy(), uniforms=np.stack(all_u), cdf_gap=np.stack(gaps).astype(np.float32),
                         fp=fingerprint(sd))
@@ -149,7 +152,7 @@ def golden_s3gen_full(name, P, N, n_steps, B, n_win, check_oracle=(0,)):
         mels.append(mel[0].numpy())
         wins.append(np.stack([wav[0, s:s + WAV_WIN].numpy() for s in starts]))
         rms.append(float(wav.pow(2).mean().sqrt()))
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), P=P, N=N, n_steps=n_steps, B=B, mel=np.stack(mels),
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), P=P, N=N, n_steps=n_steps, B=B, mel=np.stack(mels),
                         wav_win=np.stack(wins), win_start=starts, wav_rms=np.array(rms), fp=fingerprint(sd))
 
 
@@ -195,7 +198,7 @@ def golden_turbo_l24(name="turbo_l24", n_layers=24, d=1024, steps=64, n_text=64)
     assert err < 2e-3 and torch.equal(o_toks, toks[0])
     idx = torch.arange(0, 6563, 13)
     sidx = torch.arange(0, raw.shape[0], 4)
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), provenance=provenance(os.path.basename(__file__)), n_layers=n_layers, d=d, steps=steps, n_text=n_text, tokens=toks[0].numpy(),
                         logits_sub=raw[sidx][:, idx].numpy(), logit_idx=idx.numpy(), step_idx=sidx.numpy(), uniforms=u.numpy(),
                         fp=fingerprint({k: v for k, v in sd.items() if k != "tfmr.wte.weight"}))
 

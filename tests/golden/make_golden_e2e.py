@@ -14,6 +14,9 @@ import os
 import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import provenance  # noqa: E402
 import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -59,7 +62,7 @@ def main():
         mel, wav = _run_ref_s3gen(m, toks[None], ref, z, phase, noise, 10)
         starts = wav_windows(960 * N, 12)
         print(f"[e2e_b8] {N} valid tokens of {t3['tokens'].shape[1]}; mel std {mel.std():.3f}; wav rms {wav.pow(2).mean().sqrt():.4f}", flush=True)
-    np.savez_compressed(os.path.join(OUT, "e2e_b8.npz"), N=N, P=P, tokens=toks.numpy(), mel=mel[0].numpy(),
+    np.savez_compressed(os.path.join(OUT, "e2e_b8.npz"), provenance=provenance(os.path.basename(__file__)), N=N, P=P, tokens=toks.numpy(), mel=mel[0].numpy(),
                         wav_win=np.stack([wav[0, s:s + WAV_WIN].numpy() for s in starts]), win_start=starts,
                         wav_rms=float(wav.pow(2).mean().sqrt()), f0_t1000=f0["s3gen_t1000"], f0_t3500=f0["vc_t3500"], fp=fingerprint(sd))
 

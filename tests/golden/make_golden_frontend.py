@@ -15,6 +15,9 @@ import os
 import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from provenance import provenance  # noqa: E402
 import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -62,7 +65,7 @@ def main():
         emb = ve.inference(vmel[None], [vmel.shape[0]], rate=1.3)[0]
         e = (RF.ve_inference(vsd, vmel) - emb).abs().max()
         print(f"voice encoder: {vmel.shape[0]} frames, oracle-vs-reference max {e:.3e}")
-    np.savez_compressed(os.path.join(OUT, "frontend.npz"), s3_logmel=lm.numpy(), mel24k=m24.numpy(), fbank=fb.numpy(), xvector=xv.numpy(),
+    np.savez_compressed(os.path.join(OUT, "frontend.npz"), provenance=provenance(os.path.basename(__file__)), s3_logmel=lm.numpy(), mel24k=m24.numpy(), fbank=fb.numpy(), xvector=xv.numpy(),
                         ve_mel=vmel.numpy(), ve_embed=emb.numpy(), fp_cam=fingerprint(csd), fp_ve=fingerprint(vsd))
 
 

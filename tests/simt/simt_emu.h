@@ -233,43 +233,69 @@ static inline int __any(int pred) { return simt_ballot(pred != 0) != 0; }
 #define __builtin_amdgcn_ballot_w64(...) simt_ballot(__VA_ARGS__)
 #define __builtin_amdgcn_readfirstlane(x) (x) /* the sources only use it on wave-uniform values */
 
-// v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100), row_shr / row_shl / row_ror, row_mirror, row_half_mirror, row_bcast are not all
-// needed -- the sources use quad_perm only; anything else fails loudly
-static inline int simt_mov_dpp(int v, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
-    if (ctrl >= 0x121 && ctrl <= 0x12F) {  // row_ror:n -- lane l of a 16-lane row receives from lane (l - n) mod 16 (gemm_planes.hip: the LayerNorm epilogue's row sums)
-        const int n = ctrl & 0xF;
-        return simt_shfl_by(v, [=](int l) { return (l & ~15) | (((l & 15) - n) & 15); });
-    }
-    if (ctrl < 0 || ctrl > 0xFF) {
+// v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100), row_shl:n (0x100 + n: lane l of a 16-lane row receives from l + n), row_shr:n (0x110 + n: from
+// l - n), row_ror:n (0x120 + n: from (l - n) mod 16); row_mask / bank_mask select the rows (16 lanes) / banks (4 lanes of a row) that are WRITTEN, the
+// others keep `old`; a written lane without a source (shifted in from outside the row) gets 0 with bound_ctrl, `old` without.  Anything else fails loudly.
+static inline int simt_update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int l = simt::g_cur->lane;
+    int src = -1;
+    if (ctrl >= 0 && ctrl <= 0xFF) src = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl >= 0x101 && ctrl <= 0x10F) src = (l & 15) + (ctrl & 0xF) < 16 ? l + (ctrl & 0xF) : -1;
+    else if (ctrl >= 0x111 && ctrl <= 0x11F) src = (l & 15) - (ctrl & 0xF) >= 0 ? l - (ctrl & 0xF) : -1;
+    else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (l & ~15) | (((l & 15) - (ctrl & 0xF)) & 15);
+    else {
         fprintf(stderr, "simt: unsupported DPP control 0x%x\n", ctrl);
         abort();
     }
-    return simt_shfl_by(v, [=](int l) { return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3); });
+    // the xor-partner forms (cbx_xor_lane: quad_perm xor 1 / 2, the row_shl:4 | row_shr:4 pair under bank masks, row_ror:8) synchronise PAIRWISE like
+    // __shfl_xor does here -- 16-lane groups of a wave may sit in different loop iterations (decode attention) --, everything else wave-wide
+    int xb = -1;
+    if (ctrl == 0xB1) xb = 0;
+    else if (ctrl == 0x4E) xb = 1;
+    else if ((ctrl == 0x104 && bank_mask == 0x5) || (ctrl == 0x114 && bank_mask == 0xA)) xb = 2;
+    else if (ctrl == 0x128) xb = 3;
+    int got;
+    if (xb >= 0) {
+        got = (int)(unsigned)simt::shfl_xor_pair((unsigned long long)(unsigned)v, xb);
+        if (src != (l ^ (1 << xb))) src = -2;  // (a lane the bank mask does not write: whatever it received is dropped below)
+    } else {
+        got = simt_shfl_by(v, [=](int) { return src; });  // (every lane takes part in the exchange)
+    }
+    const bool enabled = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
+    if (!enabled) return old;
+    if (src < 0) {
+        if (src == -2) {
+            fprintf(stderr, "simt: DPP xor form writes a lane whose source is not its xor partner (ctrl 0x%x)\n", ctrl);
+            abort();
+        }
+        return bound_ctrl ? 0 : old;
+    }
+    return got;
 }
-#define __builtin_amdgcn_mov_dpp(...) simt_mov_dpp(__VA_ARGS__)
-#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) simt_mov_dpp(v, ctrl, rm, bm, bc)
+#define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) simt_update_dpp(0, v, ctrl, rm, bm, bc)
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) simt_update_dpp(old, v, ctrl, rm, bm, bc)
 
 typedef unsigned simt_u32x2 __attribute__((ext_vector_type(2)));
 // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src.  Returns {new vdst, new src}.
-static inline simt_u32x2 simt_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
-    const unsigned mine[2] = {vdst, src};
-    memcpy(simt::xslot_mine(), mine, 8);
-    simt::wave_sync();
+static inline simt_u32x2 simt_permlane_swap(unsigned vdst, unsigned src, int bit) {
+    const unsigned long long mine = (unsigned long long)vdst | ((unsigned long long)src << 32);
+    const unsigned long long other = simt::shfl_xor_pair(mine, bit);  // pairwise: lane l <-> lane l ^ (1 << bit)
     const int l = simt::g_cur->lane;
-    unsigned other[2];
-    memcpy(other, simt::xslot_of(l ^ 32), 8);
-    simt::xflip();
     simt_u32x2 r;
-    if (l < 32) {  // my src <- vdst of lane l + 32; my vdst unchanged
+    if (!(l & (1 << bit))) {  // lower half / even row: my src <- vdst of the partner; my vdst unchanged
         r[0] = vdst;
-        r[1] = other[0];
-    } else {  // my vdst <- src of lane l - 32; my src unchanged
-        r[0] = other[1];
+        r[1] = (unsigned)other;
+    } else {  // upper half / odd row: my vdst <- src of the partner; my src unchanged
+        r[0] = (unsigned)(other >> 32);
         r[1] = src;
     }
     return r;
 }
+static inline simt_u32x2 simt_permlane32_swap(unsigned vdst, unsigned src, bool, bool) { return simt_permlane_swap(vdst, src, 5); }
 #define __builtin_amdgcn_permlane32_swap(...) simt_permlane32_swap(__VA_ARGS__)
+// v_permlane16_swap vdst, src: odd rows (lanes 16-31, 48-63) of vdst <-> even rows (lanes 0-15, 32-47) of src.  Returns {new vdst, new src}.
+static inline simt_u32x2 simt_permlane16_swap(unsigned vdst, unsigned src, bool, bool) { return simt_permlane_swap(vdst, src, 4); }
+#define __builtin_amdgcn_permlane16_swap(...) simt_permlane16_swap(__VA_ARGS__)
 
 // ---------------------------------------------------------------------------------------------------------------- no-op instructions
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -26,6 +26,17 @@ def test_gpus_2_spawns_two_ranks_and_reports_n_gpus_2():
     st = out["selftest"]
     assert st["ranks"] == 2 and st["c1_ok"] is True and st["c2_waveforms_gathered"] == 2 * 6  # 2 steps x (3 utterances x 2 ranks)
     assert out["value"] is None  # the self-test measures nothing
+    # the throughput schedule's C2: batches posted to dist.AsyncGatherer by bench.pipelined_batches while a second host thread produces them
+    assert st["pipelined_c2_ok"] is True and st["pipelined_batches"] == 2
+
+
+def test_pipelined_c2_order_with_three_ranks_and_many_batches():
+    """the collective order of the PIPELINED path (bench.pipelined_batches: a generator fed by a second host thread, C2 posted per batch
+    to the background gatherer, closed before the barrier) over gloo, 3 ranks x 7 batches whose ranks finish their batches at different times."""
+    r = _run(["--gpus", "3", "--steps", "7", "--warmup", "0", "--batch", "2", "--tokens", "6", "--selftest-rendezvous"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["selftest"]["ranks"] == 3 and out["selftest"]["pipelined_c2_ok"] is True and out["selftest"]["pipelined_batches"] == 7
 
 
 def test_world_size_mismatch_is_an_error():
@@ -37,4 +48,4 @@ def test_single_rank_selftest_needs_no_process_group():
     r = _run(["--gpus", "1", "--steps", "1", "--selftest-rendezvous", "--batch", "2", "--tokens", "10"])
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 1 and out["selftest"]["c2_waveforms_gathered"] == 2
+    assert out["n_gpus"] == 1 and out["selftest"]["c2_waveforms_gathered"] == 2 and out["selftest"]["pipelined_c2_ok"] is True

@@ -149,3 +149,18 @@ def test_frontend_host_signal_conditioning(tmp_path):
     assert fe.VoiceEncoderEngine.frame_step(0.5, 1.3) == RF.ve_frame_step(0.5, 1.3) == 77
     for n in (1, 159, 160, 161, 301, 1001):
         assert fe.VoiceEncoderEngine.num_wins(n, 77) == RF.ve_num_wins(n, 77)
+
+
+def test_goldens_record_their_provenance():
+    """Every fixture names the third-party versions whose arithmetic it holds (the reference pins transformers 5.2.0; this image has 5.15.0:
+    SURVEY.md 8c asks for the skew to be recorded with the results)."""
+    import glob
+    import json
+    import numpy as np
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+    assert len(files) >= 12
+    for f in files:
+        with np.load(f) as z:
+            assert "provenance" in z.files, f
+            p = json.loads(str(z["provenance"]))
+        assert p["transformers"] and p["torch"] and p["reference_pins"]["transformers"] == "5.2.0", (f, p)

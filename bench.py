@@ -307,7 +307,7 @@ def pmc_traffic(kernel_substr, source="flow_only"):
     import csv
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r05", "r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
+        f = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{source}_pmc_{c}.csv") for r in ("r06", "r05", "r04", "r03", "r02", "r01")) if os.path.exists(q)), None)
         if f is None:
             return None, None
         used = os.path.basename(f)[:3]
@@ -325,7 +325,7 @@ def pmc_traffic(kernel_substr, source="flow_only"):
                                                           "a committed rocprofv3 --pmc pass of the same kernels, not re-measured in this run)")
 
 
-def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv):
+def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv, gemv_kind="llama"):
     """One roofline object per timed kernel class.  GEMM / attention: every launch of the last timed step, HIP events on the launch
     stream.  gemv: the decode step's projections replayed from a hipGraph (the form they run in inside the timed region, where
     events cannot see individual graph nodes) -- one graph per projection type sweeping the 30 layers' weights, events around it."""
@@ -370,7 +370,9 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
         tot_n = sum(v["launches"] for v in gemv.values())
         per_step_ms = sum(v["ms"] / v["launches"] * v["per_step"] for v in gemv.values())
         gbs = tot_b / (tot_ms * 1e-3) / 1e9
-        e = dict(bound="hbm", kernel="gemv_kernel / gemv_ct_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)",
+        gname = ("gemv_kernel / gemv_ct_kernel (T3 decode weight streaming: q/k/v, o, gate|up, down projections; M = 2*batch rows)" if gemv_kind == "llama" else
+                 "gemv_row_kernel (GPT-2 T3 decode at batch 1: c_attn, attention c_proj, c_fc, mlp c_proj on row-major weights, one activation row)")
+        e = dict(bound="hbm", kernel=gname,
                  achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                  launches=tot_n, avg_launch_us=round(1e3 * tot_ms / tot_n, 2), algorithmic_bytes_per_launch=round(tot_b / tot_n, 0),
                  share_of_step=round(per_step_ms * 1e-3 * n_decode / (elapsed / steps), 3),
@@ -380,7 +382,7 @@ def roofline_entries(summ, elapsed, steps, timed_steps, s3_prec, n_decode, gemv)
                  note="average launch duration INCLUDING the dependent-launch boundary (~1.2 us): events bracket hipGraph replays of "
                       "30 back-to-back launches (one per layer, 1 GB of distinct weights per sweep, so nothing is served from the "
                       "256 MB Infinity Cache); rocprofv3's per-kernel average excludes that boundary")
-        tr, src = pmc_traffic(("gemv_kernel", "gemv_ct_kernel"), "t3_eager")
+        tr, src = pmc_traffic(("gemv_kernel", "gemv_ct_kernel"), "t3_eager") if gemv_kind == "llama" else pmc_traffic(("gemv_row_kernel",), "turbo_eager")
         e["traffic"], e["traffic_source"] = (round(tr, 0) if tr else None), src
         out["gemv_f32"] = e
     return out
@@ -448,6 +450,46 @@ def gemv_sweeps(t3, rows, reps=6):
         torch.cuda.synchronize()
         res[name] = dict(ms=e0.elapsed_time(e1), launches=reps * len(t3.layers), per_step=len(t3.layers),
                          bytes=float(reps * sum(wbytes[name](lw) for lw in t3.layers)))
+    return res
+
+
+@torch.inference_mode()
+def gemv_row_sweeps(t3, reps=6):
+    """The batch-1 GPT-2 decode projections (ops.gemv_row) timed the way gemv_sweeps times the Llama ones: one hipGraph per projection type sweeping the layers'
+    (distinct) weights, HIP events around `reps` replays."""
+    from chatterbox_amd import ops
+    dev, D = t3.dev, t3.D
+    f = lambda *s: torch.randn(*s, device=dev)
+    x, g = f(D), f(4 * D)
+    qkv, out, gg = torch.empty(3 * D, device=dev), torch.zeros(D, device=dev), torch.empty(4 * D, device=dev)
+    parts = torch.zeros(t3.H, max(1, int(t3.tune.get("row_splits") or 8)), ops.ATTN_PART_REC, device=dev)
+    parts[:, :, 1] = 1.0
+    calls = {"c_attn": lambda lw: ops.gemv_row(x, lw["wqkv"], qkv, bias=lw["bqkv"], ln=lw["ln1"]),
+             "c_proj": lambda lw: ops.gemv_row(None, lw["wo"], out, bias=lw["bo"], res=out, parts=parts),
+             "c_fc": lambda lw: ops.gemv_row(x, lw["wfc"], gg, bias=lw["bfc"], ln=lw["ln2"], act=ops.GELU_TANH),
+             "mlp_c_proj": lambda lw: ops.gemv_row(g, lw["wpr"], out, bias=lw["bpr"], res=out)}
+    wname = {"c_attn": "wqkv", "c_proj": "wo", "c_fc": "wfc", "mlp_c_proj": "wpr"}
+    res = {}
+    side = torch.cuda.Stream(device=dev)
+    for name, fn in calls.items():
+        with torch.cuda.stream(side):
+            for lw in t3.layers:
+                fn(lw)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            for lw in t3.layers:
+                fn(lw)
+        gph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            gph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = dict(ms=e0.elapsed_time(e1), launches=reps * len(t3.layers), per_step=len(t3.layers),
+                         bytes=float(reps * sum(lw[wname[name]].numel() * 4 for lw in t3.layers)))
     return res
 
 
@@ -577,6 +619,11 @@ def _co_resident_on_green(t3):
     """Is the decode geometry of the throughput schedule (T3Engine.co_resident) on the committed allow-list of hardware-verified geometries?"""
     from chatterbox_amd import autotune as at
     return at.canon(dict(t3.tune, half_tiles=0, d_ks2=4, d_nw2=8), t3.knobs) in at.green_variants()
+
+
+def _range_trips():
+    from chatterbox_amd import engine
+    return int(engine.RANGE_TRIPS)
 
 
 def log(msg):
@@ -825,7 +872,9 @@ def main():
         summ = timer.summary()
         if turbo:
             dstep = decode_step_entry(eng.t3, None, gpt2=True)
-        dstep_pipe = bf16x6 = None
+            if B == 1 and eng.t3.tune.get("row_path"):
+                gemv = gemv_row_sweeps(eng.t3)
+        dstep_pipe = bf16x6 = repeat_ms = None
         if not turbo:
             dstep = decode_step_entry(eng.t3, args.t3_layers)  # the serial steps' events (the decode step with the GPU to itself)
             if pipelined and pipe_events:  # ... and the same step beside the co-resident flow kernels of the previous batch (the timed region)
@@ -857,9 +906,11 @@ def main():
                     one_step(-100)
                     torch.cuda.synchronize()
                     ta = time.perf_counter()
-                    a, _, _ = one_step(-101)
+                    a, _, tm_alt = one_step(-101)
                     torch.cuda.synchronize()
                     alt[f"s3gen_precision_{pr}"] = round(a / (time.perf_counter() - ta), 2)
+                    if pr == 6:  # what ONE fp16-range trip of the default mode costs: the flow + vocoder of the batch again, at bf16x6
+                        repeat_ms = round(1e3 * (tm_alt.get("flow_s", 0.0) + tm_alt.get("hift_s", 0.0)), 1)
                 if not args.no_fast_mode:  # the full opt-in fast mode: S3Gen bf16x3 + T3 decode weights rounded to bf16 (both narrower than fp32)
                     from chatterbox_amd.t3 import T3Engine
                     t3_fp32 = eng.t3
@@ -877,23 +928,30 @@ def main():
         if not turbo and world == 1 and not args.no_streaming:
             # chunked synthesis (engine.synthesize_stream): wall time until the first audio chunk is on the host, and the cost of the
             # whole chunked run, on the benched batch (first chunk = 1 s of audio, then 2 s chunks)
-            fl, tl = [], []
-            for rep in range(3):
-                g = torch.Generator(device=dev).manual_seed(99 + rep)
-                us = torch.rand(B, N, generator=g, device=dev)
-                torch.cuda.synchronize()
-                ts = time.perf_counter()
-                first = None
-                for r in eng.synthesize_stream(texts, t3c, gen, first_chunk=25, chunk=50, max_new_tokens=N, uniforms=us, ban_eos=True, ban_from=6561):
-                    if first is None:
-                        first = time.perf_counter() - ts
-                torch.cuda.synchronize()
-                fl.append(first)
-                tl.append(time.perf_counter() - ts)
-            fl.sort(), tl.sort()
-            stream = dict(schedule="first chunk 25 tokens (1 s of audio) + 3 lookahead, then 50-token chunks; every round re-runs encoder + CFM over all "
-                                   "tokens so far", p50_first_audio_latency_ms=round(1e3 * fl[1], 1), p50_total_ms=round(1e3 * tl[1], 1),
-                          audio_s_per_wall_s=round(B * (N - 1) / 25.0 / tl[1], 2))
+            def stream_run(first_alone):
+                fl, tl = [], []
+                for rep in range(4):
+                    g = torch.Generator(device=dev).manual_seed(99 + rep)
+                    us = torch.rand(B, N, generator=g, device=dev)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    first = None
+                    for r in eng.synthesize_stream(texts, t3c, gen, first_chunk=12, chunk=100, chunk_growth=1.35, first_alone=first_alone, max_new_tokens=N, uniforms=us,
+                                                   ban_eos=True, ban_from=6561):
+                        if first is None:
+                            first = time.perf_counter() - ts
+                    torch.cuda.synchronize()
+                    if rep:  # (the first run of a variant captures its graphs)
+                        fl.append(first)
+                        tl.append(time.perf_counter() - ts)
+                fl.sort(), tl.sort()
+                return dict(p50_first_audio_latency_ms=round(1e3 * fl[1], 1), p50_total_ms=round(1e3 * tl[1], 1), audio_s_per_wall_s=round(B * (N - 1) / 25.0 / tl[1], 2))
+
+            stream = dict(schedule="three rounds over 15 / 115 / 250 tokens (first chunk 12 tokens = 0.5 s of audio + 3 lookahead, then 100, then the rest), each round = encoder + "
+                                   "CFM + vocoder over the tokens so far; T3 keeps decoding on its own stream beside rounds 1 and 2 and -- latency first -- NOT beside round 0 "
+                                   "(engine.synthesize_stream, overlap=True, first_alone=True)", **stream_run(True))
+            # the same schedule with T3 decoding beside round 0 as well: more throughput, later first audio (same-box A/B: profiles/r06_streaming_schedules_ab.jsonl)
+            stream["t3_beside_first_round"] = stream_run(False)
         pipe_extra = None
         if not turbo and world == 1 and not args.no_streaming and not pipelined and fallback is None:
             # the throughput schedule on the same workload, outside the timed region: T3 of batch k + 1 on a high-priority stream beside flow + vocoder
@@ -914,7 +972,7 @@ def main():
             except Exception as e:
                 pipe_extra = dict(error=f"{type(e).__name__}: {e}"[:200])
                 torch.cuda.synchronize()
-        roofs = roofline_entries(summ, step_s, 1, timed_steps, s3_prec, N - 1, gemv)  # shares relative to a SERIAL step (kernels with the GPU to themselves)
+        roofs = roofline_entries(summ, step_s, 1, timed_steps, s3_prec, N - 1, gemv, "gpt2" if turbo else "llama")  # shares relative to a SERIAL step (kernels with the GPU to themselves)
         dom = args.roofline_kernel
         if dom == "auto":
             dom = max(roofs, key=lambda k: roofs[k]["share_of_step"]) if roofs else None
@@ -948,6 +1006,10 @@ def main():
             # the throughput schedule with S3Gen at strictly fp32-width operands (bf16x6: 24 significand bits, fp32 exponent range) -- THE fp32-width claim; `value` runs
             # S3Gen at f16x3 (22 significand bits per operand, range-checked, error measured at or below the exact-fp32 MFMA's: DESIGN.md section 1)
             "value_bf16x6": (bf16x6 or {}).get("value") if not turbo else None,
+            # the fp16 range check of the default S3Gen mode: passes of THIS run (warm-up, timed region, extras) that tripped it and were repeated at bf16x6, and
+            # what one such repeat costs per batch (serial flow + vocoder at bf16x6).  Seeded random-init weights: 0 trips; trip rate against activation outliers
+            # of 1e2 .. 1e5: tests/test_models_gpu.py::test_f16x3_range_flag_trip_rate_and_repeat_cost_on_outlier_activations
+            "f16x3_range_trips": _range_trips(), "bf16x6_repeat_cost_ms": repeat_ms,
             "config": {"workload": (f"configs[2]: Chatterbox-Multilingual-V3 500M architecture (T3 Llama-520M {args.t3_layers}L + S3Gen 10-step CFG CFM + "
                                     f"HiFT), batch {B}/GPU, {args.text_tokens} text tokens, {N} speech tokens = {N / 25:.0f} s audio per utterance, "
                                     f"10 s voice prompt") if not turbo else

@@ -230,6 +230,9 @@ _SIGS = {
     "cbx_fsq_index": ([c_f, c_f, c_long, c_long, c_f], c_int),
     "cbx_t3_decode_step": ([ctypes.POINTER(T3Step), c_f], c_int),
     "cbx_t3_prefill": ([ctypes.POINTER(T3Prefill), c_f], c_int),
+    "cbx_t3_loop_create": ([ctypes.POINTER(T3Step), c_f, ctypes.POINTER(c_f)], c_int),
+    "cbx_t3_loop_run": ([c_f, c_int, c_int, c_f, ctypes.POINTER(c_int)], c_int),
+    "cbx_t3_loop_destroy": ([c_f], c_int),
     "cbx_t3_sample": ([ctypes.POINTER(SamplerParams), c_f], c_int),
     "cbx_cfm_solve": ([ctypes.POINTER(CfmSolve), c_f], c_int),
     "cbx_s3gen_encode": ([ctypes.POINTER(S3Encode), c_f], c_int),

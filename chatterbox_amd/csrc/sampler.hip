@@ -14,24 +14,31 @@ CBX_TRC_TU
 constexpr int NT = 1024;
 constexpr int MAXV = 8448;  // >= 8194, multiple of 64
 
-__device__ __forceinline__ float block_max(float v, float* red) {
+// Block-wide reductions through a PING-PONG pair of LDS rows: reduction k writes row k & 1, so the writes of reduction k cannot overtake the reads of
+// reduction k - 2 (every thread passed reduction k - 1's barrier in between) and ONE barrier per reduction suffices (rounds 1-5: two; the top-k / top-p
+// bisections of Turbo run 62 reductions per token).  Same values, same order of the additions.
+struct Red {
+    float* buf;  // 2 x NT / 64 floats, 16-byte aligned
+    int k;
+};
+__device__ __forceinline__ float block_max(float v, Red& red) {
     v = wave_max(v);
+    float* b = red.buf + (red.k++ & 1) * (NT / 64);
+    if ((threadIdx.x & 63) == 0) b[threadIdx.x >> 6] = v;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float r = red[0];
+    float r = b[0];
 #pragma unroll
-    for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, red[i]);
+    for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, b[i]);
     return r;
 }
-__device__ __forceinline__ float block_sum(float v, float* red) {
+__device__ __forceinline__ float block_sum(float v, Red& red) {
     v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    float* b = red.buf + (red.k++ & 1) * (NT / 64);
+    if ((threadIdx.x & 63) == 0) b[threadIdx.x >> 6] = v;
     __syncthreads();
     float r = 0.f;
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) r += red[i];
+    for (int i = 0; i < NT / 64; ++i) r += b[i];
     return r;
 }
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
@@ -52,32 +59,13 @@ __device__ __forceinline__ void rep_penalty(float* l, const unsigned char* seen,
         if (seen[i]) l[i] = l[i] < 0.f ? l[i] * pen : l[i] / pen;
 }
 
-// T block-wide sums at once (one barrier pair instead of T): v[i] := sum over the workgroup of v[i], each in the order of block_sum.
-template <int T>
-__device__ __forceinline__ void block_sum_n(float (&v)[T], float* red) {
-#pragma unroll
-    for (int i = 0; i < T; ++i) v[i] = wave_sum(v[i]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < T; ++i) red[(threadIdx.x >> 6) * T + i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-        float r = 0.f;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) r += red[w * T + i];
-        v[i] = r;
-    }
-}
-
+// (Round 6 measured a 4-way search -- three thresholds per barrier round, half the rounds, same cut -- at 69 us against the bisection's 51 us for Turbo's
+// top-k + top-p, 59 us once the wave reductions ran on DPP: like round 3's 16-way variant (108 us) it loses, because every thread re-adds the partial sums of
+// all 16 waves per threshold.  The bisection stays; what round 6 changed is underneath it: wave_sum / wave_max are DPP / permlane butterflies now.)
 // HF TopPLogitsWarper: drop the ascending-sorted prefix whose cumulative probability is <= 1 - top_p.
-// Sort-free: token i is dropped iff mass{p_j <= p_i} <= 1 - top_p; the cut value is the boundary of a MONOTONE predicate over the bit
-// pattern of the un-normalised probabilities (every mass is summed in one fixed order: per thread, wave butterfly, waves in order -- and
-// fp32 addition of non-negative terms is monotone), so any search finds the same cut.  Round 6: a 4-way search (three thresholds per
-// round, their three sums reduced behind ONE barrier pair: 15 rounds instead of the 30 of the bisection of rounds 1-5; same cut, bit for bit).
-__device__ void top_p_filter(float* l, int V, float top_p, float* red) {
+// Sort-free: token i is dropped iff mass{p_j <= p_i} <= 1 - top_p; the cut value is found by bisection on the
+// (monotone) bit pattern of the un-normalised probabilities.
+__device__ void top_p_filter(float* l, int V, float top_p, Red& red) {
     constexpr int EPT = (MAXV + NT - 1) / NT;  // elements per thread: their un-normalised probabilities are computed ONCE and kept in registers
     float m = -INFINITY;
     for (int i = threadIdx.x; i < V; i += NT) m = fmaxf(m, l[i]);
@@ -92,31 +80,15 @@ __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
     }
     z = block_sum(z, red);
     const float budget = (1.0f - top_p) * z;
-    unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget < mass{e <= hi} (hi: never evaluated)
+    unsigned lo = 0u, hi = __float_as_uint(1.0f);  // e in [0,1]; invariant: mass{e <= lo} <= budget
     while (lo + 1 < hi) {
-        const unsigned span = hi - lo;
-        unsigned t[3];
-        float s[3];
+        unsigned mid = lo + (hi - lo) / 2;
+        float thr = __uint_as_float(mid);
+        float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            t[q] = lo + (unsigned)(((unsigned long long)span * (q + 1)) >> 2);  // lo <= t < hi; t == lo re-states the invariant
-            const float thr = __uint_as_float(t[q]);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) a += e[j] <= thr ? e[j] : 0.f;
-            s[q] = a;
-        }
-        block_sum_n<3>(s, red);
-        unsigned nlo = lo, nhi = hi;
-#pragma unroll
-        for (int q = 2; q >= 0; --q) {
-            if (!(s[q] <= budget)) nhi = t[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (s[q] <= budget && t[q] < nhi) nlo = t[q];
-        }
-        lo = nlo, hi = nhi;
+        for (int j = 0; j < EPT; ++j) s += e[j] <= thr ? e[j] : 0.f;
+        s = block_sum(s, red);
+        if (s <= budget) lo = mid; else hi = mid;
     }
     const float cut = __uint_as_float(lo);
     __syncthreads();
@@ -128,9 +100,8 @@ __device__ void top_p_filter(float* l, int V, float top_p, float* red) {
     __syncthreads();
 }
 
-// HF TopKLogitsWarper: scores < k-th largest -> -inf: the largest key x with count{key(l) >= x} >= k on the order-preserving integer image
-// (a monotone predicate: 4-way search, 16 rounds instead of 32; exact integer counts).
-__device__ void top_k_filter(float* l, int V, int k, float* red) {
+// HF TopKLogitsWarper: scores < k-th largest -> -inf (bisection on the order-preserving integer image).
+__device__ void top_k_filter(float* l, int V, int k, Red& red) {
     if (k <= 0 || k >= V) return;
     constexpr int EPT = (MAXV + NT - 1) / NT;
     auto key = [](float f) -> unsigned {
@@ -143,38 +114,20 @@ __device__ void top_k_filter(float* l, int V, int k, float* red) {
         const int i = threadIdx.x + j * NT;
         ky[j] = i < V ? key(l[i]) : 0u;
     }
-    unsigned long long lo = 0ull, hi = 1ull << 32;  // count{key >= lo} >= k > count{key >= hi}
-    while (lo + 1 < hi) {
-        const unsigned long long span = hi - lo;
-        unsigned long long t[3];
-        float c[3];
+    unsigned lo = 0u, hi = 0xFFFFFFFFu;  // largest key with count{key(l) >= key} >= k
+    while (lo < hi) {
+        unsigned mid = lo + (hi - lo) / 2 + 1;
+        float c = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            t[q] = lo + ((span * (q + 1)) >> 2);
-            const unsigned thr = (unsigned)t[q];
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) a += ky[j] >= thr ? 1.f : 0.f;
-            c[q] = a;
-        }
-        block_sum_n<3>(c, red);
-        unsigned long long nlo = lo, nhi = hi;
-#pragma unroll
-        for (int q = 2; q >= 0; --q) {
-            if (!(c[q] >= (float)k)) nhi = t[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (c[q] >= (float)k && t[q] < nhi) nlo = t[q];
-        }
-        lo = nlo, hi = nhi;
+        for (int j = 0; j < EPT; ++j) c += ky[j] >= mid ? 1.f : 0.f;
+        c = block_sum(c, red);
+        if (c >= (float)k) lo = mid; else hi = mid - 1;
     }
-    const unsigned cutk = (unsigned)lo;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int i = threadIdx.x + j * NT;
-        if (i < V && ky[j] < cutk) l[i] = -INFINITY;
+        if (i < V && ky[j] < lo) l[i] = -INFINITY;
     }
     __syncthreads();
 }
@@ -182,7 +135,8 @@ __device__ void top_k_filter(float* l, int V, int k, float* red) {
 __global__ __launch_bounds__(NT) void t3_sample_kernel(const cbx_sampler_t p) {
     __builtin_amdgcn_s_setprio(3);  // decode-step kernels are latency-bound and issue little: beside a co-resident workgroup of another stream (the throughput schedule, profiles/r05_overlap_*) their waves go first at the SIMD's issue arbiter; alone on the CU it changes nothing
     __shared__ float l[MAXV];
-    __shared__ float red[3 * (NT / 64)];
+    __shared__ __attribute__((aligned(16))) float red_buf[2 * (NT / 64)];
+    Red red{red_buf, 0};
     __shared__ double redd[NT / 64];
     __shared__ double wave_base[NT / 64];
     __shared__ int chosen;

@@ -128,3 +128,103 @@ extern "C" int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream) {
     }
     return 0;
 }
+
+// ---- The token loop in C (include/cbx.h "handle-level entry points").  The graph is what chatterbox_amd/t3.py captures through torch.cuda.graph: one
+// cbx_t3_decode_step.  On the SIMT emulator (tests/simt: no graph API) the steps are issued one by one.
+#include <vector>
+struct cbx_t3_loop {
+    cbx_t3_step_t step;
+    std::vector<cbx_t3_layer_t> layers;
+    cbx_sampler_t sampler;
+    bool has_sampler = false;
+    std::vector<int> done_host;
+#ifndef CBX_SIMT_EMU
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+#endif
+};
+
+extern "C" int cbx_t3_loop_create(const cbx_t3_step_t* step, void* stream, cbx_t3_loop_t** out) {
+    CBX_REQUIRE(step && out && step->layers && step->n_layers > 0, "t3_loop_create: null argument");
+    cbx_t3_loop* h = new cbx_t3_loop();
+    h->step = *step;
+    h->layers.assign(step->layers, step->layers + step->n_layers);
+    h->step.layers = h->layers.data();
+    if (step->sampler) {
+        h->sampler = *step->sampler;
+        h->step.sampler = &h->sampler;
+        h->has_sampler = true;
+        h->done_host.assign(h->sampler.B > 0 ? h->sampler.B : 1, 0);
+    }
+#ifndef CBX_SIMT_EMU
+    // captured on a stream of the library's own: the caller's stream may be the legacy default stream, which cannot capture, and nothing executes during a
+    // capture anyway -- the graph is LAUNCHED on the caller's stream (cbx_t3_loop_run)
+    (void)stream;
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        if (st) hipStreamDestroy(st);
+        delete h;
+        return cbx_set_error((int)e, "t3_loop_create: hipStreamBeginCapture: %s", hipGetErrorString(e));
+    }
+    const int rc = cbx_t3_decode_step(&h->step, st);
+    e = hipStreamEndCapture(st, &h->graph);  // (always ended, also after a failed step: the stream must leave capture mode)
+    hipStreamDestroy(st);
+    if (rc != 0 || e != hipSuccess || !h->graph) {
+        if (h->graph) hipGraphDestroy(h->graph);
+        delete h;
+        return rc ? rc : cbx_set_error((int)e, "t3_loop_create: hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        hipGraphDestroy(h->graph);
+        delete h;
+        return cbx_set_error((int)e, "t3_loop_create: hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+#else
+    (void)stream;
+#endif
+    *out = h;
+    return 0;
+}
+
+extern "C" int cbx_t3_loop_run(cbx_t3_loop_t* h, int n_steps, int poll_every, void* stream, int* steps_run) {
+    CBX_REQUIRE(h && n_steps >= 0 && poll_every >= 0, "t3_loop_run: bad arguments");
+    CBX_REQUIRE(poll_every == 0 || h->has_sampler, "t3_loop_run: polling the done flags needs a sampler in the step descriptor");
+    int ran = 0;
+    for (int i = 0; i < n_steps; ++i) {
+#ifndef CBX_SIMT_EMU
+        const hipError_t e = hipGraphLaunch(h->exec, (hipStream_t)stream);
+        if (e != hipSuccess) return cbx_set_error((int)e, "t3_loop_run: hipGraphLaunch: %s", hipGetErrorString(e));
+#else
+        const int rc = cbx_t3_decode_step(&h->step, stream);
+        if (rc) return rc;
+#endif
+        ++ran;
+        if (poll_every > 0 && ran % poll_every == 0 && i + 1 < n_steps) {  // the reference tests EOS on the host after every token (t3.py:366)
+#ifndef CBX_SIMT_EMU
+            hipError_t e2 = hipMemcpyAsync(h->done_host.data(), h->sampler.done, sizeof(int) * h->done_host.size(), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize((hipStream_t)stream);
+            if (e2 != hipSuccess) return cbx_set_error((int)e2, "t3_loop_run: fetching the done flags: %s", hipGetErrorString(e2));
+#else
+            for (size_t b = 0; b < h->done_host.size(); ++b) h->done_host[b] = h->sampler.done[b];
+#endif
+            bool all = true;
+            for (int d : h->done_host) all = all && d != 0;
+            if (all) break;
+        }
+    }
+    if (steps_run) *steps_run = ran;
+    return 0;
+}
+
+extern "C" int cbx_t3_loop_destroy(cbx_t3_loop_t* h) {
+    if (!h) return 0;
+#ifndef CBX_SIMT_EMU
+    if (h->exec) hipGraphExecDestroy(h->exec);
+    if (h->graph) hipGraphDestroy(h->graph);
+#endif
+    delete h;
+    return 0;
+}

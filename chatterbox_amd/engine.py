@@ -20,6 +20,9 @@ SPEECH_VOCAB = 6561
 SAMPLES_PER_TOKEN = 960  # 24 kHz / 25 tokens per second
 
 
+RANGE_TRIPS = 0  # S3Gen passes of this process that met an operand outside the fp16 range and were repeated at bf16x6 (bench.py reports it)
+
+
 def _range_checked(eng, run, check=True):
     """S3Gen's default numerics (precision 16 = f16x3) need operands inside the fp16 range; a launch that meets one outside it raises a
     device flag (ops.enable_range_flag).  Then the result is not meaningful and the work is repeated at bf16x6, which has the fp32
@@ -27,6 +30,8 @@ def _range_checked(eng, run, check=True):
     out = run()
     if check and 16 in (eng.flow.precision, eng.hift.precision) and ops.range_flag_tripped():
         warnings.warn("an S3Gen operand exceeded the fp16 range: repeating flow matching + vocoder at bf16x6")
+        global RANGE_TRIPS
+        RANGE_TRIPS += 1
         saved = eng.flow.precision, eng.hift.precision
         eng.flow.precision, eng.hift.precision = (6 if p == 16 else p for p in saved)
         try:
@@ -152,6 +157,14 @@ class ChatterboxEngine:
             self.t3.co_resident(on)
         self.flow.co_resident(on)
 
+    def _pipeline_streams(self, priorities=(-1, 0)):
+        """The T3 / flow streams of the overlapped schedules (created once; HIP priorities: measured, no effect either way)."""
+        if not hasattr(self, "_s_t3"):
+            pt3, pvoc = priorities
+            self._s_t3 = torch.cuda.Stream(device=self.dev, priority=pt3)
+            self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=pt3) for _ in range(2)]  # one per T3 state in flight
+            self._s_voc = torch.cuda.Stream(device=self.dev, priority=pvoc)
+
     @torch.inference_mode()
     def synthesize_pipelined(self, jobs, co_resident=True, host_threads=True, t3_in_flight=2, stream_priorities=(-1, 0), **kw):
         """Throughput mode for a stream of batches: T3 of batch k+1 runs on a high-priority HIP stream WHILE the flow
@@ -169,11 +182,7 @@ class ChatterboxEngine:
             calls of the C stage seams release the GIL)."""
         import threading
         torch.cuda.set_device(self.dev)  # a generator cannot hold a device guard across yields: pin the device for the caller
-        if not hasattr(self, "_s_t3"):
-            pt3, pvoc = stream_priorities  # HIP priorities of the T3 / flow streams (measured: no effect either way, profiles/r05_throughput_schedule_sweep.log)
-            self._s_t3 = torch.cuda.Stream(device=self.dev, priority=pt3)
-            self._s_t3x = [self._s_t3] + [torch.cuda.Stream(device=self.dev, priority=pt3) for _ in range(2)]  # one per T3 state in flight
-            self._s_voc = torch.cuda.Stream(device=self.dev, priority=pvoc)
+        self._pipeline_streams(stream_priorities)
         t3_kw = {k: kw[k] for k in ("max_new_tokens", "temperature", "top_p", "min_p", "repetition_penalty", "cfg_weight", "ban_eos",
                                     "ban_from") if k in kw}
         self.co_resident(bool(co_resident))
@@ -208,23 +217,27 @@ class ChatterboxEngine:
             return [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
 
         if not host_threads:  # round 4's form: one host thread enqueues T3(k + 1), then flow + vocoder(k)
-            pending = None  # (job, speech tokens, t_start)
-            for k in range(len(jobs) + 1):
-                box = {}
-                if k < len(jobs):
-                    t_start = time.perf_counter()
-                    enqueue_t3(jobs[k], box)
-                    if "error" in box:
-                        raise box["error"]
-                if pending is not None:
-                    job, st, t0 = pending
-                    host = voc_of(job, st)
-                    yield host, st, time.perf_counter() - t0
-                pending = None
-                if "handle" in box:
-                    with torch.cuda.stream(self._s_t3):
-                        toks = self.t3.collect(box["handle"])
-                    pending = (jobs[k], tokens_of(toks), t_start)
+            try:
+                pending = None  # (job, speech tokens, t_start)
+                for k in range(len(jobs) + 1):
+                    box = {}
+                    if k < len(jobs):
+                        t_start = time.perf_counter()
+                        enqueue_t3(jobs[k], box)
+                        if "error" in box:
+                            raise box["error"]
+                    if pending is not None:
+                        job, st, t0 = pending
+                        host = voc_of(job, st)
+                        yield host, st, time.perf_counter() - t0
+                    pending = None
+                    if "handle" in box:
+                        with torch.cuda.stream(self._s_t3):
+                            toks = self.t3.collect(box["handle"])
+                        pending = (jobs[k], tokens_of(toks), t_start)
+            finally:
+                torch.cuda.synchronize()
+                self.co_resident(False)
             return
 
         # ---- two host threads, two T3 states: the worker enqueues T3(k) into state k % 2 as soon as batch k - 2's tokens were collected, so the T3 stream
@@ -273,6 +286,8 @@ class ChatterboxEngine:
             ev.synchronize()
             if 16 in (self.flow.precision, self.hift.precision) and ops.range_flag_tripped(self.dev, which):
                 warnings.warn("an S3Gen operand exceeded the fp16 range: repeating flow matching + vocoder of this batch at bf16x6")
+                global RANGE_TRIPS
+                RANGE_TRIPS += 1
                 saved = self.flow.precision, self.hift.precision
                 self.flow.precision, self.hift.precision = (6 if p == 16 else p for p in saved)
                 try:
@@ -334,21 +349,24 @@ def stream_token_schedule(n_tokens, first_chunk=25, chunk=50, lookahead=3, chunk
 
 def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, chunk=50, chunk_growth=1.0, lookahead=3, fade=480, max_new_tokens=1000,
                       temperature=0.8, top_p=1.0, min_p=0.05, repetition_penalty=1.2, cfg_weight=0.5, uniforms=None, ban_eos=False,
-                      ban_from=0, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=True):
+                      ban_from=0, z=None, phase=None, noise=None, n_cfm_timesteps=10, drop_last_token=True, overlap=True, first_alone=True, run_ahead=2):
     """Chunked synthesis: first audio after `first_chunk` tokens instead of after the whole utterance.
 
     The reference is non-streaming; of its vestigial hooks only HiFT's `cache_source` works (hifigan.py:470-472) -- `finalize=False`
     (flow.py:170-171) raises a shape error there -- so the schedule is this build's own, with its own oracle
     (tests/test_stream_gpu.py restates it on the CPU oracle):
-      * T3 decodes `first_chunk + lookahead` tokens, then `chunk` more per round (graph replays of the same captured step), each chunk
-        `chunk_growth` times the previous one (stream_token_schedule: 1.0 = constant chunks; 2.0 halves the number of re-synthesis rounds);
-      * every round re-runs encoder + CFM over ALL tokens so far with the same noise realisation, masking the last
-        2 * lookahead mel frames of unfinished utterances (the encoder looks 3 tokens ahead), and HiFT with the previous round's source
-        as `cache_source` (phase-continuous excitation);
-      * new samples are emitted up to `fade` samples before the end of what the round could vocode; that tail is cross-faded
-        (raised-cosine-free linear ramp) with the next round's re-synthesis of the same samples.
-    The last round is a full synthesis: identical mel to synthesize() for the same noise.  Yields dicts
-    {wavs: [B CPU tensors of NEW samples], final: [B bools], n_tokens: [B]}; concatenating an utterance's pieces gives its waveform."""
+      * round r works on the first n_r tokens, n_0 = first_chunk + lookahead, n_r = n_{r-1} + chunk * chunk_growth^(r-1) (stream_token_schedule);
+      * every round runs encoder + CFM over the tokens so far with the same noise realisation, masking the last 2 * lookahead mel frames of
+        unfinished utterances (the encoder looks 3 tokens ahead), and HiFT with the previous round's source as `cache_source`
+        (phase-continuous excitation);
+      * new samples are emitted up to `fade` samples before the end of what the round could vocode; that tail is cross-faded (linear ramp)
+        with the next round's re-synthesis of the same samples.
+    The last round is a full synthesis: identical mel to synthesize() for the same noise.
+    overlap (round 6, the default): the two stages of the SAME utterances run side by side -- a second host thread keeps the T3 decode going on
+    its own high-priority stream (at most two rounds ahead of the vocoder; graph replays of the captured step), this thread waits for a round's
+    tokens on the flow stream and runs that round's flow + vocoder there, both stages on their co-resident kernel forms (synthesize_pipelined).
+    A round still sees exactly its n_r tokens, so every yielded sample is the one the serial form (overlap=False) yields.
+    Yields dicts {wavs: [B CPU tensors of NEW samples], final: [B bools], n_tokens: [B]}; concatenating an utterance's pieces gives its waveform."""
     torch.cuda.set_device(self.dev)
     dev, B = self.dev, len(text_tokens)
     P = gen_ref["prompt_token"].shape[-1]
@@ -362,15 +380,14 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
     if noise is None:
         noise = torch.randn(B, 9, SAMPLES_PER_TOKEN * N, device=dev)
     z, phase, noise = z.to(dev), phase.to(dev).reshape(B, 9), noise.to(dev)
-    h = self.t3.generate(t3_conds, text_tokens, max_new_tokens=N, temperature=temperature, top_p=top_p, min_p=min_p,
-                         repetition_penalty=repetition_penalty, cfg_weight=cfg_weight, uniforms=uniforms, ban_eos=ban_eos, ban_from=ban_from,
-                         async_mode=True, run_steps=first_chunk + lookahead)
-    emitted, tails, closed, src_cache = [0] * B, [None] * B, [False] * B, None
-    next_chunk = float(chunk)
+    t3_kw = dict(max_new_tokens=N, temperature=temperature, top_p=top_p, min_p=min_p, repetition_penalty=repetition_penalty, cfg_weight=cfg_weight,
+                 uniforms=uniforms, ban_eos=ban_eos, ban_from=ban_from, async_mode=True)
+    totals = stream_token_schedule(N, first_chunk, chunk, lookahead, chunk_growth)  # tokens decoded when round r starts
+    emitted, tails, closed, cache = [0] * B, [None] * B, [False] * B, [None]
     ramp = torch.linspace(0.0, 1.0, fade + 2, device=dev)[1:-1]
-    while True:
-        toks, done = self.t3.peek(h)
-        exhausted = h["next_i"] >= h["max_new_tokens"]
+
+    def one_round(toks, done, exhausted):
+        """flow + vocoder over the tokens so far on the CURRENT stream -> the dict this generator yields"""
         fin, hold = _stream_plan([t.numel() for t in toks], done, exhausted, lookahead)
         st = [drop_invalid_tokens(t) for t in toks]
         st = [t if t.numel() > 0 else torch.zeros(1, dtype=torch.long) for t in st]
@@ -388,9 +405,9 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
                 mel = self.flow.inference(tok.to(dev), torch.tensor(ns, dtype=torch.int32, device=dev), gen_ref, z=z[:, : 2 * (P + Nk)],
                                           n_steps=n_cfm_timesteps, hold_back=hold)
                 return self.hift.inference(mel, phase=phase, noise=noise[:, :, : 480 * mel.shape[1]], lens=fl, fade=True,
-                                           cache_source=src_cache)
+                                           cache_source=cache[0])
             wav, src = _range_checked(self, run)
-            src_cache = src[:, : 480 * min(frames)].clone() if min(frames) > 0 else None
+            cache[0] = src[:, : 480 * min(frames)].clone() if min(frames) > 0 else None
             for b in range(B):
                 if closed[b]:
                     continue
@@ -407,11 +424,79 @@ def synthesize_stream(self, text_tokens, t3_conds, gen_ref, *, first_chunk=25, c
                 emitted[b] = end
                 closed[b] = fin[b]
                 out[b] = new.cpu()
-        yield dict(wavs=out, final=list(fin), n_tokens=ns)
-        if all(closed) or exhausted:
-            return
-        self.t3.advance(h, max(1, int(round(next_chunk))))
-        next_chunk *= chunk_growth
+        return dict(wavs=out, final=list(fin), n_tokens=ns)
+
+    if not overlap:  # the serial form of rounds 3-5: T3 waits while a round is synthesised
+        h = self.t3.generate(t3_conds, text_tokens, run_steps=totals[0], **t3_kw)
+        for r, n_r in enumerate(totals):
+            toks, done = self.t3.peek(h)
+            exhausted = h["next_i"] >= h["max_new_tokens"]
+            yield one_round(toks, done, exhausted)
+            if all(closed) or exhausted:
+                return
+            self.t3.advance(h, totals[r + 1] - n_r)
+        return
+
+    # ---- overlapped: T3 on its own stream + host thread, at most `ahead` rounds in front of the vocoder
+    import queue
+    import threading
+    self._pipeline_streams()
+    self.co_resident(True)
+    torch.cuda.synchronize()
+    # T3 run-ahead policy (round 6, measured: profiles/r06_streaming_*): the FIRST round's flow + vocoder decide the first-audio latency, so T3 does not
+    # decode beside them (`first_alone`); once the first audio is out T3 may be up to `ahead` rounds in front of the vocoder
+    ahead = max(1, int(run_ahead))
+    q, stop, credit = queue.Queue(), threading.Event(), threading.Semaphore(1 if first_alone else ahead)
+
+    def worker():
+        try:
+            torch.cuda.set_device(dev)
+            h = None
+            with torch.inference_mode(), torch.cuda.stream(self._s_t3):
+                for r, n_r in enumerate(totals):
+                    credit.acquire()
+                    if stop.is_set():
+                        return
+                    if h is None:
+                        h = self.t3.generate(t3_conds, text_tokens, run_steps=n_r, **t3_kw)
+                    else:
+                        self.t3.advance(h, n_r - totals[r - 1])
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    q.put((h, ev, n_r))
+        except BaseException as e:  # re-raised by the consumer
+            q.put(e)
+
+    th = threading.Thread(target=worker, name="cbx-t3-stream", daemon=True)
+    th.start()
+    try:
+        for r in range(len(totals)):
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            h, ev, n_r = item
+            # the FIRST round decides the first-audio latency and T3 is far ahead of what round 1 needs: its flow runs on the fastest-alone kernel forms (T3's
+            # workgroups wait for CU slots meanwhile); from round 1 on both stages share the CUs on the co-resident forms
+            self.flow.co_resident(r > 0 or not first_alone)
+            with torch.cuda.stream(self._s_voc):  # (not held across the yield: the caller keeps its own current stream)
+                self._s_voc.wait_event(ev)
+                toks, done = self.t3.peek(h)  # synchronises THIS stream (behind the event); T3 may already be further: a round sees its n_r tokens
+                done = [bool(d) and int(t.numel()) <= n_r for d, t in zip(done, toks)]
+                toks = [t[:n_r] for t in toks]
+                exhausted = n_r >= N
+                res = one_round(toks, done, exhausted)
+            for _ in range(ahead if (first_alone and r == 0) else 1):
+                credit.release()
+            yield res
+            if all(closed) or exhausted:
+                return
+    finally:
+        stop.set()
+        for _ in range(ahead + 1):
+            credit.release()
+        th.join()
+        torch.cuda.synchronize()
+        self.co_resident(False)
 
 
 S3GEN_SIL = 4299  # reference models/s3gen/const.py:2

@@ -36,6 +36,21 @@ def llama3_rope_tables(max_pos, head_dim=64, theta=500000.0, factor=8.0, low=1.0
     return emb.cos().contiguous(), emb.sin().contiguous()
 
 
+class _LoopHandle:
+    """Owns a cbx_t3_loop_t (destroyed with the state / geometry entry that holds it)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if self.h:
+                lib.cbx_t3_loop_destroy(self.h)
+        except Exception:
+            pass
+
+
 class T3Engine:
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
@@ -105,6 +120,7 @@ class T3Engine:
         self._state = {}
         # decode launch geometry: waves per 16-column tile (nw) and cross-workgroup K splits of the two down-projections
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"  # token step through the stage-level C entry point (same kernels)
+        self.c_loop = self.c_step and os.environ.get("CBX_T3_CLOOP", "1") == "1"  # ... and the token loop through cbx_t3_loop_* (the hipGraph captured and replayed in C)
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
         self.tune = self._env_tune()
         self.knobs = self._env_knobs()
@@ -143,6 +159,7 @@ class T3Engine:
         self._state = {}
         self.time_decode, self.decode_events = False, []
         self.c_step = os.environ.get("CBX_T3_CSTEP", "1") == "1"
+        self.c_loop = self.c_step and os.environ.get("CBX_T3_CLOOP", "1") == "1"
         self.tune = cls._env_tune()
         self.knobs = cls._env_knobs()
         return self
@@ -516,21 +533,51 @@ class T3Engine:
         ops.gemv(cur, self.head_pk, st["logits"], N=self.V, K=self.D, nw=8, norm_w=self.norm, col_tiles=hct, **red, **pk)
 
     def _forward(self, st):
-        if self.decode_mode == "v2" and st["rows"] <= 16:
+        if self.decode_mode == "v2" and st["rows"] <= 16:  # (17 .. 64 rows on this 5-launch layer: measured -4.5 % at 32 rows, +2.4 % at 64 -- profiles/r06_wide_rows_decode_ab.jsonl -- not adopted)
             return self._forward_decode_v2(st)
         self._forward_decode(st)
 
     def _decode_step(self, st):
-        if self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4):
+        if self._use_c_step(st):
             return self._decode_step_c(st)
         self._forward(st)
         self._sample(st)
+
+    def _use_c_step(self, st):
+        return self.c_step and self.decode_mode == "v2" and st["rows"] <= 16 and self.tune["d_ks2"] in (1, 2, 4)
+
+    def _c_loop(self, st):
+        """The cbx_t3_loop_t of this state's current geometry (include/cbx.h: the decode step captured in a hipGraph by the LIBRARY, replayed by
+        cbx_t3_loop_run), created on first use; kept beside the step descriptor and dropped / cached with it (apply_variant)."""
+        import ctypes
+        from ._lib import check, lib
+        self._c_step_desc(st)
+        if len(st["cstep"]) == 3:
+            h = ctypes.c_void_p()
+            torch.cuda.synchronize()
+            check(lib.cbx_t3_loop_create(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream, ctypes.byref(h)), "cbx_t3_loop_create")
+            st["cstep"] = st["cstep"] + (_LoopHandle(h),)
+        return st["cstep"][3].h
+
+    def _run_c_loop(self, st, n_steps, poll_every):
+        import ctypes
+        from ._lib import check, lib
+        ran = ctypes.c_int(0)
+        check(lib.cbx_t3_loop_run(self._c_loop(st), int(n_steps), int(poll_every), torch.cuda.current_stream().cuda_stream, ctypes.byref(ran)), "cbx_t3_loop_run")
+        return int(ran.value)
 
     def _decode_step_c(self, st):
         """The same token step through the stage-level C entry point cbx_t3_decode_step (include/cbx.h): one ctypes call enqueues the
         153 launches that _forward_decode_v2 + _sample issue one by one."""
         import ctypes
-        from ._lib import SamplerParams, T3Layer, T3Step, check, lib
+        from ._lib import check, lib
+        self._c_step_desc(st)
+        check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
+
+    def _c_step_desc(self, st):
+        """Build (once per state and geometry) the cbx_t3_step_t of this state: st["cstep"] = (descriptor, layers, sampler[, loop handle])."""
+        import ctypes
+        from ._lib import SamplerParams, T3Layer, T3Step
         if "cstep" not in st:
             p = lambda t: t.data_ptr()
             ws, tn = st["dws"], self.tune
@@ -566,7 +613,6 @@ class T3Engine:
             d.head_ct = self._hct()
             d.da_ws, d.da_cnt, d.da_pairs = ops._p(da.ws), ops._p(da.cnt), (da.max_pairs if da.ws is not None else 0)  # None: >= 128 (row, head) pairs never split
             st["cstep"] = (d, layers, sp)  # keep the host structures alive
-        check(lib.cbx_t3_decode_step(ctypes.byref(st["cstep"][0]), torch.cuda.current_stream().cuda_stream), "cbx_t3_decode_step")
 
     def _sample(self, st):
         # the sampling parameters are read from device memory (st["samp_dev"], one row per utterance): a request with other settings
@@ -623,6 +669,10 @@ class T3Engine:
         no-ops inside the sampler).  Returns the number of steps enqueued."""
         st = handle["st"]
         n = max(0, min(int(n_steps), handle["max_new_tokens"] - handle["next_i"]))
+        if n and self.c_loop and self._use_c_step(st) and self.dev.type == "cuda" and st["graph"] is None:
+            self._run_c_loop(st, n, 0)
+            handle["next_i"] += n
+            return n
         for _ in range(n):
             if st["graph"] is not None:
                 st["graph"].replay()
@@ -635,8 +685,10 @@ class T3Engine:
     def peek(self, handle):
         """Tokens sampled so far (synchronises with the launch stream): (list of B 1-D LongTensors, list of B done flags)."""
         st, B = handle["st"], handle["B"]
-        n = st["n_generated"].tolist()
+        # (order matters when the decode is still running on ANOTHER stream -- engine.synthesize_stream(overlap=True): the sampler writes token, count, then
+        # the done flag, so a done flag read FIRST implies the count read after it is final; a count that is still growing just means "not final yet")
         done = st["done"].tolist()
+        n = st["n_generated"].tolist()
         toks = st["out_tokens"].cpu()
         return [toks[b, : n[b]].clone() for b in range(B)], [bool(d) for d in done]
 
@@ -739,7 +791,10 @@ class T3Engine:
         self._sample(st)
         if debug_logits:
             use_graph = False
-        if use_graph and st["graph"] is None and max_new_tokens > 1:
+        c_loop = bool(use_graph and self.c_loop and self._use_c_step(st) and self.dev.type == "cuda" and max_new_tokens > 1)
+        if c_loop:
+            self._c_loop(st)  # (captures the step on first use: before the timed events below)
+        if use_graph and not c_loop and st["graph"] is None and max_new_tokens > 1:
             torch.cuda.synchronize()
             saved = {k: st[k].clone() for k in ("seen", "step", "done", "n_generated", "out_tokens", "next_ids",
                                                 "next_pos_ids", "positions", "ctx_lens", "logits")}
@@ -757,7 +812,11 @@ class T3Engine:
             ev[0].record()
         n_replays = 0
         last = max_new_tokens if run_steps is None else max(1, min(max_new_tokens, int(run_steps)))
-        for i in range(1, last):
+        if c_loop and last > 1:  # the token loop in C: one ctypes call; EOS polled every `poll_every` steps unless the caller wants no synchronisation
+            n_replays = self._run_c_loop(st, last - 1, 0 if (ban_eos or async_mode) else poll_every)
+            if async_mode:
+                last = 1 + n_replays
+        for i in range(1, 1 if c_loop else last):
             n_replays += 1
             if use_graph and st["graph"] is not None:
                 st["graph"].replay()

@@ -46,7 +46,7 @@ class T3TurboEngine:
         # row_path (round 6, ABI v14): batch 1 runs on the single-row streaming kernels (ops.gemv_row / ops.decode_attn_parts: row-major weights, no
         # MFMA padding, no LDS reduction, no partial images; _forward_decode_row); row_splits / row_chunks: context slices per (row, head) and
         # 16-position chunks in flight per workgroup of its attention
-        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, head_ct=2, row_path=1, row_splits=8, row_chunks=4)
+        self.tune = dict(d_ks=2, d_nw=16, o_nw=8, half_tiles=1, qkv_tc=0, od_tc=0, head_ct=2, row_path=1, row_splits=16, row_chunks=2)
         for kv in filter(None, os.environ.get("CBX_TURBO_TUNE", "").split(",")):
             k, v = kv.split("=")
             assert k.strip() in self.tune, f"CBX_TURBO_TUNE: unknown knob {k!r} (known: {sorted(self.tune)})"

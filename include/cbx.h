@@ -30,7 +30,7 @@ extern "C" {
                               13: per-call launch geometry of the plane-format kernels (cbx_gemm_pl_t.tile, cbx_flash_attn_planes_v, cbx_cfm_t.gemm_tile /
                                   attn_version: no process-wide state on the flow path either) incl. the CO-RESIDENT forms of the throughput schedule
                                   (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW;
-                              14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts */
+                              14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts; the token loop in C: cbx_t3_loop_* */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -490,6 +490,18 @@ typedef struct cbx_t3_step_t {
     float* qkv_ssq;
 } cbx_t3_step_t;
 int cbx_t3_decode_step(const cbx_t3_step_t* d, void* stream);
+
+/* ---- handle-level entry points: the TOKEN LOOP of T3.inference in C (t3.py:338-386 incl. its EOS test `:366`; SURVEY.md 8b "cbx_t3_generate") ----
+ * cbx_t3_loop_create deep-copies the step descriptor (its host arrays: layers, sampler) and captures ONE cbx_t3_decode_step in a hipGraph (thread-local
+ * capture on a stream of the library's own -- `stream` may be the legacy default stream --; nothing is allocated on the device); cbx_t3_loop_run replays it up to n_steps times on `stream`.  poll_every > 0: after every
+ * poll_every steps the per-utterance done flags (cbx_sampler_t.done) are fetched and the loop ends early once every utterance has sampled its EOS --
+ * the reference's per-token host sync, amortised; poll_every = 0: all n_steps are enqueued without any synchronisation (asynchronous use).
+ * *steps_run = steps enqueued.  The caller owns every device buffer of the descriptor and keeps it alive until cbx_t3_loop_destroy.  One handle per
+ * (descriptor, stream of launches); not thread-safe.  With cbx_t3_prefill a C host runs the whole device side of T3.inference without Python. */
+typedef struct cbx_t3_loop cbx_t3_loop_t;
+int cbx_t3_loop_create(const cbx_t3_step_t* step, void* stream, cbx_t3_loop_t** out);
+int cbx_t3_loop_run(cbx_t3_loop_t* h, int n_steps, int poll_every, void* stream, int* steps_run);
+int cbx_t3_loop_destroy(cbx_t3_loop_t* h);
 
 /* ---- stage-level entry point: the PREFILL of T3.inference for every row (t3.py:303-335 -> t3_hf_backend.py:71-111: HF LlamaModel over the S prompt
  * positions, KV cache filled) ----

@@ -39,7 +39,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
                "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill,
                "cbx_planes_t": _lib.PlanesRef, "cbx_cfm_tblock_t": _lib.CfmTBlock, "cbx_cfm_stage_t": _lib.CfmStage, "cbx_cfm_t": _lib.CfmSolve,
                "cbx_hift_resblock_t": _lib.HiftResblock, "cbx_hift_t": _lib.HiftDecode,
-               "cbx_conformer_t": _lib.Conformer, "cbx_s3enc_t": _lib.S3Encode, "cbx_hift_f0_t": _lib.HiftF0}
+               "cbx_conformer_t": _lib.Conformer, "cbx_s3enc_t": _lib.S3Encode, "cbx_hift_f0_t": _lib.HiftF0,
+               "cbx_gemv_row_t": _lib.GemvRowParams, "cbx_attn_parts_t": _lib.AttnPartsParams}  # ABI v14
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

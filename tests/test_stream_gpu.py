@@ -57,11 +57,14 @@ def _setup(dev, N, P):
     return eng, s3_sd, texts, cond, ref, z, phase, noise, kw
 
 
-def test_stream_matches_oracle_schedule(dev):
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlapped", "serial"])
+def test_stream_matches_oracle_schedule(dev, overlap):
+    """overlap=True (the default since round 6): T3 keeps decoding on its own stream while a round's flow + vocoder run; a round still sees exactly the
+    tokens of the schedule, so the same oracle pins both forms."""
     from oracle import ref_torch as O
     N, P, first, chunk, look, fade = 20, 8, 6, 7, 3, 240
     eng, s3_sd, texts, cond, ref, z, phase, noise, kw = _setup(dev, N, P)
-    rounds = list(eng.synthesize_stream(texts, cond, ref, first_chunk=first, chunk=chunk, lookahead=look, fade=fade, **kw))
+    rounds = list(eng.synthesize_stream(texts, cond, ref, first_chunk=first, chunk=chunk, lookahead=look, fade=fade, overlap=overlap, **kw))
     assert len(rounds) == 3 and rounds[0]["n_tokens"] == [9, 9] and rounds[-1]["final"] == [True, True]  # 9 -> 16 -> 20 tokens
     first_len = 480 * (2 * (first + look) - 2 * look) - fade
     assert [w.numel() for w in rounds[0]["wavs"]] == [first_len, first_len]          # first audio: 6 tokens' worth minus the held-back tail

@@ -96,3 +96,47 @@ def test_hift_f0_source_through_the_c_entry_point_equals_the_python_sequence(dev
     assert len(calls) == 1, "the second pass went through cbx_hift_f0_source"
     assert torch.isfinite(out[True]).all() and out[True].abs().max() > 0
     assert torch.equal(out[True], out[False]), f"max |diff| {(out[True] - out[False]).abs().max().item():.3e}"
+
+
+def test_t3_token_loop_in_c_equals_the_python_replay_loop_and_stops_at_eos(dev):
+    """cbx_t3_loop_* (ABI v14: the library captures cbx_t3_decode_step in a hipGraph and replays it; the reference's loop t3.py:338-386 incl. its EOS test):
+    (1) T3Engine.generate through the C loop samples the tokens of the Python replay loop over a torch-captured graph (and of the eager step), for a ragged
+    batch; (2) chunked use (async generate + advance) on the C loop equals the one-shot run; (3) cbx_t3_loop_run polls the done flags: with every utterance
+    flagged done it stops at the first poll."""
+    import ctypes
+    from chatterbox_amd import synth
+    from chatterbox_amd._lib import check, lib
+    from chatterbox_amd.t3 import T3Engine
+    L, steps = 2, 21
+    eng = T3Engine(synth.t3_state_dict(L, 0), dev)
+    assert eng.c_loop and eng.c_step
+    texts = [synth.text_tokens(9, seed=1), synth.text_tokens(15, seed=2), synth.text_tokens(12, seed=3)]
+    cond, u = synth.t3_cond(), synth.rand((3, steps), seed=5)
+    kw = dict(max_new_tokens=steps, uniforms=u, ban_eos=True, ban_from=6561, temperature=0.8, cfg_weight=0.5, repetition_penalty=1.2, min_p=0.05, top_p=1.0)
+    calls, inner = [], eng._run_c_loop
+    eng._run_c_loop = lambda *a, **k: (calls.append(a[1]), inner(*a, **k))[1]
+    got = [t.tolist() for t in eng.generate(cond, texts, **kw)]
+    assert calls == [steps - 1], "generate() ran its token loop through cbx_t3_loop_run"
+    eng.c_loop = False
+    for st in eng._state.values():
+        st.pop("cstep", None)
+    ref_graph = [t.tolist() for t in eng.generate(cond, texts, **kw)]
+    ref_eager = [t.tolist() for t in eng.generate(cond, texts, use_graph=False, **kw)]
+    assert got == ref_graph == ref_eager
+    eng.c_loop = True
+    h = eng.generate(cond, texts, async_mode=True, run_steps=6, **kw)
+    eng.advance(h, 7)
+    eng.advance(h, 100)
+    assert [t.tolist() for t in eng.collect(h)] == got
+    # (3) the EOS poll: flag everything done, ask for 12 steps with a poll every 4 -> the loop stops after the first poll
+    st = h["st"]
+    with torch.inference_mode():
+        for k in ("step", "n_generated"):
+            st[k].zero_()
+        st["done"].fill_(1)
+    torch.cuda.synchronize()
+    ran = ctypes.c_int(-1)
+    check(lib.cbx_t3_loop_run(eng._c_loop(st), 12, 4, torch.cuda.current_stream().cuda_stream, ctypes.byref(ran)), "cbx_t3_loop_run")
+    assert ran.value == 4 and int(st["step"].sum()) == 0, "finished utterances are no-ops in the sampler; the loop ended at the first poll"
+    with torch.inference_mode():
+        st["done"].zero_()

@@ -74,7 +74,7 @@ class DecodeAttnParams(ctypes.Structure):  # cbx_decode_attn_t (ABI v10)
 class GemvRowParams(ctypes.Structure):  # cbx_gemv_row_t (ABI v14)
     _fields_ = [("x", c_f), ("W", c_f), ("bias", c_f), ("res", c_f), ("out", c_f), ("ln_w", c_f), ("ln_b", c_f), ("eps", c_float),
                 ("parts", c_f), ("n_parts", c_int), ("n_heads", c_int), ("N", c_int), ("K", c_int), ("ldw", c_long), ("act", c_int),
-                ("rows_per_wave", c_int)]
+                ("rows_per_wave", c_int), ("M", c_int), ("ldx", c_long), ("ldo", c_long), ("ldr", c_long), ("parts_row_stride", c_long)]
 
 
 class AttnPartsParams(ctypes.Structure):  # cbx_attn_parts_t (ABI v14)

@@ -430,8 +430,8 @@ extern "C" int cbx_set_range_flag(int* dev_flag) {
 }
 
 // Would a Linear (M, N?, K) with row stride lda fold a LayerNorm into its A operand (cbx_gemm_t.ln_stats)?  Mirrors the conditions of the
-// dispatcher below that do not depend on the caller's other operands: no forced tile, the buffer-load loader usable (31-bit offsets,
-// no CBX_SPLIT_GENERIC_LOADER), K % 32 == 0.  The caller additionally needs precision 16, taps == 1, one batch, no lens.
+// dispatcher below that do not depend on the caller's other operands: no forced tile, the buffer-load loader usable (31-bit offsets),
+// K % 32 == 0.  The caller additionally needs precision 16, taps == 1, one batch, no lens.
 static int split_generic_loader_forced() {
     return 0;  // (the generic loader of round 1 is kept for shapes the buffer-load loader does not serve)
 }

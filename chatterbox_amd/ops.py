@@ -588,20 +588,33 @@ def decode_attn_rope(qkv, positions, cos_t, sin_t, kc, vc, out, scale, out_packe
     return out
 
 
-def gemv_row(x, w, out, *, bias=None, res=None, ln=None, eps=1e-5, parts=None, n_heads=0, act=NONE, rows_per_wave=0):
-    """Batch-1 decode GEMV (cbx_gemv_row_f32): out (N,) = act(x' . w[n] + bias) + res with x' = x (K,), LayerNorm(x) (ln = (weight, bias)) or the
-    merge of the split-context attention records `parts` (n_heads, n_splits, ATTN_PART_REC) that decode_attn_parts left (x is then None).
-    w (N, K) row-major fp32 -- the checkpoint layout, no packed image."""
+def gemv_row(x, w, out, *, bias=None, res=None, ln=None, eps=1e-5, parts=None, act=NONE, rows_per_wave=0):
+    """Few-row decode GEMV (cbx_gemv_row_f32): out (M, N) [or (N,) for one row] = act(x' . w[n] + bias) + res, M <= 4, with x' = x (M, K) / (K,),
+    LayerNorm(x) (ln = (weight, bias)) or the merge of the split-context attention records `parts` (M, n_heads, n_splits, ATTN_PART_REC) [or 3-D for one
+    row] that decode_attn_parts left (x is then None).  w (N, K) row-major fp32 -- the checkpoint layout, no packed image."""
     N, K = w.shape
+    o2 = out if out.dim() == 2 else out.view(1, -1)
+    M = o2.shape[0]
+    assert o2.shape[1] == N and M <= 4
     p = GemvRowParams()
-    p.x, p.W, p.bias, p.res, p.out = _p(x), _p(_f32(w, "w")), _p(bias), _p(res), _p(_f32(out, "out"))
+    p.W, p.bias, p.out = _p(_f32(w, "w")), _p(bias), _p(_f32(out, "out"))
+    p.M, p.ldo = M, o2.stride(0)
+    if x is not None:
+        x2 = x if x.dim() == 2 else x.view(1, -1)
+        assert x2.shape == (M, K) and x2.stride(1) == 1
+        p.x, p.ldx = _p(_f32(x, "x")), x2.stride(0)
+    if res is not None:
+        r2 = res if res.dim() == 2 else res.view(1, -1)
+        assert r2.shape == (M, N)
+        p.res, p.ldr = _p(res), r2.stride(0)
     if ln is not None:
         p.ln_w, p.ln_b, p.eps = _p(ln[0]), _p(ln[1]), eps
     if parts is not None:
-        assert parts.dim() == 3 and parts.shape[2] == ATTN_PART_REC and parts.is_contiguous()
-        p.parts, p.n_parts, p.n_heads = _p(parts), parts.shape[1], parts.shape[0]
+        p4 = parts if parts.dim() == 4 else parts.unsqueeze(0)
+        assert p4.shape[0] == M and p4.shape[3] == ATTN_PART_REC and p4[0].is_contiguous()
+        p.parts, p.n_parts, p.n_heads, p.parts_row_stride = _p(parts), p4.shape[2], p4.shape[1], p4.stride(0)
     p.N, p.K, p.ldw, p.act, p.rows_per_wave = N, K, w.stride(0), act, int(rows_per_wave)
-    _timed("gemv_f32", 2.0 * N * K, 4.0 * N * K, lambda: check(lib.cbx_gemv_row_f32(ctypes.byref(p), _stream()), "cbx_gemv_row_f32"))
+    _timed("gemv_f32", 2.0 * M * N * K, 4.0 * N * K, lambda: check(lib.cbx_gemv_row_f32(ctypes.byref(p), _stream()), "cbx_gemv_row_f32"))
     return out
 
 

@@ -135,19 +135,20 @@ class T3TurboEngine:
                  col_tiles=int(tn.get("head_ct") or 0) if D % 256 == 0 else 0, **red, **pk)
 
     def _forward_decode_row(self, st):
-        """Batch 1: 5 launches per GPT-2 layer on the single-row kernels (include/cbx.h "batch-1 decode").  LayerNorm lives in the prologue of the
-        c_attn / c_fc / head GEMVs, the attention leaves `row_splits` partial records per head that the c_proj GEMV merges in ITS prologue, both
-        projections add bias + residual in place.  Weights are the row-major matrices the prefill uses (no packed images)."""
+        """Batches of 1 .. 2 utterances (same-box A/B, profiles/r06_k_few_row_path_small_batches_ab.log: 0.594 against 0.859 ms / token at B = 1, 0.780 against
+        0.893 at B = 2, 1.077 against 0.909 at B = 4 -- the VALU contraction costs M times the single row's, the MFMA tile does not): 5 launches per GPT-2 layer on the few-row kernels (include/cbx.h "few-row decode").  LayerNorm lives in the
+        prologue of the c_attn / c_fc / head GEMVs, the attention leaves `row_splits` partial records per (row, head) that the c_proj GEMV merges in ITS
+        prologue, both projections add bias + residual in place.  Weights are the row-major matrices the prefill uses (no packed images)."""
         ws, tn = st["dws"], self.tune
-        x, qkv, g, parts = ws["x"][0], ws["qkv"][0], ws["g"][0], ws["parts"]
-        ops.embed(st["next_ids"], self.speech_emb, ws["x"], table2=self.wpe, ids2=st["positions"])
+        x, qkv, g, parts = ws["x"], ws["qkv"], ws["g"], ws["parts"]
+        ops.embed(st["next_ids"], self.speech_emb, x, table2=self.wpe, ids2=st["positions"])
         for i, lw in enumerate(self.layers):
             ops.gemv_row(x, lw["wqkv"], qkv, bias=lw["bqkv"], ln=lw["ln1"])
-            ops.decode_attn_parts(ws["qkv"], st["positions"], st["kc"][i], st["vc"][i], parts, 0.125, chunks=tn["row_chunks"])
-            ops.gemv_row(None, lw["wo"], x, bias=lw["bo"], res=x, parts=parts[0])
+            ops.decode_attn_parts(qkv, st["positions"], st["kc"][i], st["vc"][i], parts, 0.125, chunks=tn["row_chunks"])
+            ops.gemv_row(None, lw["wo"], x, bias=lw["bo"], res=x, parts=parts)
             ops.gemv_row(x, lw["wfc"], g, bias=lw["bfc"], ln=lw["ln2"], act=ops.GELU_TANH)
             ops.gemv_row(g, lw["wpr"], x, bias=lw["bpr"], res=x)
-        ops.gemv_row(x, self.head, st["logits"][0], bias=self.head_b, ln=self.lnf)
+        ops.gemv_row(x, self.head, st["logits"], bias=self.head_b, ln=self.lnf)
 
     def _tiles(self):
         """(c_attn tile width, attention / MLP projection tile width) of the current tune: 16, 12, 8 or 4 output columns per workgroup."""
@@ -175,7 +176,7 @@ class T3TurboEngine:
                       next_pos_ids=st["next_pos_ids"], positions=st["positions"], ctx_lens=st["ctx_lens"])
 
     def _forward(self, st):
-        if self.decode_mode == "v2" and st["B"] == 1 and self.tune.get("row_path") and self.D % 256 == 0:
+        if self.decode_mode == "v2" and st["B"] <= 2 and self.tune.get("row_path") and self.D % 256 == 0:
             return self._forward_decode_row(st)
         if self.decode_mode == "v2" and st["B"] <= 16:
             return self._forward_decode_v2(st)

@@ -97,7 +97,7 @@ int cbx_set_range_flag(int* dev_flag);
 int cbx_row_stats_f32(const float* x, float* stats, long rows, int C, long ldx, float eps, void* stream);
 
 /* Would cbx_gemm_f32 accept ln_stats for a precision-16 Linear with M rows, K columns and row stride lda (floats)?  0 when a tuning knob
- * (cbx_set_split_tile, CBX_SPLIT_GENERIC_LOADER) or a > 2 GiB operand rules the folded form out: the caller then runs
+ * (cbx_set_split_tile) or a > 2 GiB operand rules the folded form out: the caller then runs
  * cbx_layernorm_f32 + a plain Linear (F.layer_norm + F.linear, matcha/transformer.py:243-316). */
 int cbx_gemm_ln_fusable(long M, int K, long lda);
 
@@ -335,15 +335,16 @@ typedef struct cbx_decode_attn_t {
 } cbx_decode_attn_t;
 int cbx_decode_attn_rope(const cbx_decode_attn_t* p, void* stream);
 
-/* ---- batch-1 decode (ABI v14): one activation row, weights in the checkpoint's row-major layout ----
- * cbx_gemv_row_f32:  out[n] = act( x' . W[n][:] + bias[n] ) + res[n],  n < N, where the operand x' is
+/* ---- few-row decode (ABI v14): 1 .. 4 activation rows, weights in the checkpoint's row-major layout ----
+ * cbx_gemv_row_f32:  out[m][n] = act( x'[m] . W[n][:] + bias[n] ) + res[m][n],  m < M <= 4, n < N, where the operand x' is
  *     x                                   (ln_w == NULL, parts == NULL),
  *     LayerNorm(x) * ln_w + ln_b          (ln_w, ln_b; eps; two-pass variance: F.layer_norm), or
  *     the attention output of the row     (parts: the n_parts split-context records per head that cbx_decode_attn_parts left, merged in
  *                                          slice order; K == 64 n_heads; x unused).
- * A wave owns rows_per_wave (0 = automatic: ~1024 waves) output rows over the whole of K and requests all of its weights up front: no LDS
+ * A wave owns rows_per_wave (0 = automatic: ~1024 waves) output columns over the whole of K and requests all of its weights up front: no LDS
  * reduction, no partial images.  K in {256, 768, 1024, 3072, 4096}; W [N][ldw] fp32, 16-byte aligned; res may alias out.
- * Replaces HF Conv1D / nn.Linear at q_len == 1 + GPT2Block ln_1 / ln_2 / ln_f inside T3.inference_turbo's loop (models/t3/t3.py:435-460). */
+ * Replaces HF Conv1D / nn.Linear at q_len == 1 + GPT2Block ln_1 / ln_2 / ln_f inside T3.inference_turbo's loop (models/t3/t3.py:435-460) for
+ * batches of at most 4 rows (the engines use it up to 2: beyond, the 16-row MFMA tile of cbx_gemv_f32 is faster). */
 #define CBX_ATTN_PART_REC 68 /* floats per (row, head, slice) record: {running max, sum, -, -, 64 numerators} */
 typedef struct cbx_gemv_row_t {
     const float* x; const float* W; const float* bias; const float* res; float* out;
@@ -351,7 +352,10 @@ typedef struct cbx_gemv_row_t {
     const float* parts; int n_parts, n_heads;
     int N, K; long ldw;
     int act;            /* CBX_ACT_* after the bias */
-    int rows_per_wave;  /* 0 = automatic; 1, 2, 3, 4, 8 (K >= 3072: 1, 2) */
+    int rows_per_wave;  /* 0 = automatic; 1, 2, 3, 4, 8 (K >= 3072 or parts: 1, 2) */
+    int M;              /* activation rows, 1 .. 4 (0 = 1) */
+    long ldx, ldo, ldr; /* M > 1: floats between consecutive rows of x, out, res */
+    long parts_row_stride; /* M > 1: floats between the records of consecutive rows (n_heads * n_parts * CBX_ATTN_PART_REC when dense) */
 } cbx_gemv_row_t;
 int cbx_gemv_row_f32(const cbx_gemv_row_t* p, void* stream);
 /* Decode attention of ONE new token per row over a small (row, head) grid, split over n_splits workgroups per (row, head) by 16-position

@@ -41,6 +41,24 @@ TOL_WAV_E2E_8S = 6.5e-4
 TOL_F0 = {"f0_t1000": 1.2e-3, "f0_t3500": 1.4e-3}
 
 
+# the floors the waveform / F0 tolerances are multiples of (oracle vs reference on the same inputs, printed by make_golden_big.py / make_golden_e2e.py)
+FLOOR = {"s3gen_t1000": 2.0e-4, "vc_t3500": 2.7e-4, "e2e_60s": 7.4e-4, "e2e_8s": 1.31e-4, "f0_t1000": 2.3e-4, "f0_t3500": 2.7e-4}
+MEASURED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "measured_vs_floor.jsonl")
+
+
+def _measured(name, value, tol):
+    """Record how far the GPU is from the reference in units of the oracle-vs-reference floor ("nothing tests that the GPU is closer to the
+    reference than the oracle's floor x 2") -- appended to gpurun_out/measured_vs_floor.jsonl when that directory exists -- and hold it to 3 x the floor:
+    the stated tolerance (5 x) is what DESIGN.md promises, this is the regression guard on what the hardware actually delivers."""
+    import json
+    floor = FLOOR[name]
+    rec = dict(name=name, value=float(value), tolerance=float(tol), floor=floor, ratio_to_floor=round(float(value) / floor, 3))
+    if os.path.isdir(os.path.dirname(MEASURED)):
+        with open(MEASURED, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert value <= 3.0 * floor, f"{name}: {value:.3e} is more than 3 x the oracle-vs-reference floor {floor:.1e} (stated tolerance {tol:.1e})"
+
+
 def _fp(sd):
     keys = sorted(sd)[:: max(1, len(sd) // 16)]
     return np.array([float(sd[k].double().sum()) for k in keys])
@@ -194,6 +212,7 @@ def test_hift_full_length_vs_reference(dev, s3_sd, name):
         wav, _ = eng.inference(mel, phase, noise)
         rmse = _window_rmse(wav[0].cpu(), g, b)
         assert rmse <= TOL_WAV_FULL[name], f"{name} utt {b}: waveform RMSE {rmse:.3e} (signal rms {float(g['wav_rms'][b]):.3e})"
+        _measured(name, rmse, TOL_WAV_FULL[name])
 
 
 @pytest.mark.parametrize("name,key", [("s3gen_t1000", "f0_t1000"), ("vc_t3500", "f0_t3500")])
@@ -208,6 +227,7 @@ def test_f0_max_abs_at_500_and_3000_frames(dev, s3_sd, name, key):
     assert f0.shape == ref.shape
     err = (f0 - ref).abs()
     assert err.max() <= TOL_F0[key], f"{name}: F0 max-abs {err.max():.3e} Hz at {ref.numel()} frames (f0 up to {ref.max():.0f} Hz), mean {err.mean():.3e}"
+    _measured(key, float(err.max()), TOL_F0[key])
     # the voiced / unvoiced decision (f0 > 0 after the abs()) must agree wherever the reference is clearly voiced
     assert bool(((f0 > 1.0) == (ref > 1.0))[ref > 5.0].all())
 
@@ -244,6 +264,7 @@ def test_e2e_synthesize_b8_250_tokens_vs_reference(dev, s3_sd):
     assert w0.numel() == 960 * N0
     rmse = _window_rmse(w0, dict(win_start=e["win_start"], wav_win=e["wav_win"][None]), 0)
     assert rmse <= TOL_WAV_E2E_8S, f"end-to-end waveform RMSE {rmse:.3e} (signal rms {float(e['wav_rms']):.3e}) in the batch of {B}"
+    _measured("e2e_8s", rmse, TOL_WAV_E2E_8S)
     # the CFM mel of utterance 0 inside the ragged batch (vocode returns it)
     _, mel = eng.vocode(st, synth.s3gen_ref(n_prompt_tokens=P), z=z.to(dev), phase=phase, noise=noise)
     err = (mel[0, : 2 * N0].float().cpu() - torch.from_numpy(e["mel"]).t()).abs()
@@ -273,6 +294,8 @@ def test_vc_t3500_flow_and_wave_vs_reference(dev, s3_sd, prec):
     rmse = _window_rmse(wav[0].cpu(), g, 0)
     tol_w = TOL_WAV_E2E_60S if prec != 3 else TOL_WAV_BF16_MODE
     assert rmse <= tol_w, f"mode {prec}: 60 s waveform RMSE {rmse:.3e} > {tol_w:.1e}"
+    if prec != 3:
+        _measured("e2e_60s", rmse, tol_w)
 
 
 # ----------------------------------------------------------------------------- configs[1]: Turbo 24 layers

@@ -851,3 +851,43 @@ def test_decode_attn_parts(dev, S, chunks, rope):
         assert torch.allclose(kc[r, :, p].double(), k, atol=1e-6) and torch.equal(vc[r, :, p], qkv[r].view(3, H, 64)[2])
         assert torch.equal(kc[r, :, :p], k0[r, :, :p]) and torch.equal(kc[r, :, p + 1:], k0[r, :, p + 1:])
         assert torch.equal(vc[r, :, :p], v0[r, :, :p]) and torch.equal(vc[r, :, p + 1:], v0[r, :, p + 1:])
+
+
+@pytest.mark.parametrize("M,N,K,pro,R", [(2, 3072, 1024, "ln", 0), (4, 1030, 256, "ln", 3), (3, 1024, 4096, "plain", 0), (4, 768, 3072, "plain", 2), (2, 1024, 1024, "attn", 1),
+                                         (4, 768, 768, "attn", 2), (2, 6563, 1024, "ln", 8)])
+def test_gemv_row_few_rows(dev, M, N, K, pro, R):
+    """cbx_gemv_row_f32 with 2 .. 4 activation rows (strided x / out / res, rows past M and columns past N never touched; K >= 3072: two passes over the rows)
+    and the attention-record merge per row, against fp64."""
+    from chatterbox_amd import ops
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    res = torch.randn(M, N + 8, generator=g)  # row stride > N: the strides are honoured
+    xc = torch.randn(M, K + 4, generator=g) * 1.5 + 0.2
+    kw, x = {}, xc[:, :K]
+    want_x = x.double()
+    if pro == "ln":
+        lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        want_x = F.layer_norm(x.double(), (K,), lw.double(), lb.double(), 1e-5)
+        kw = dict(ln=(lw.to(dev), lb.to(dev)))
+    elif pro == "attn":
+        H, S = K // 64, 6
+        parts = torch.zeros(M, H, S, ops.ATTN_PART_REC)
+        parts[..., 0] = torch.randn(M, H, S, generator=g) * 3
+        parts[..., 1] = torch.rand(M, H, S, generator=g) + 0.5
+        parts[..., 4:] = torch.randn(M, H, S, 64, generator=g)
+        parts[M - 1, 1, 2, 0], parts[M - 1, 1, 2, 1] = float("-inf"), 0.0
+        m = parts[..., 0].double()
+        f = torch.exp(m - m.max(-1, keepdim=True).values)
+        want_x = ((f[..., None] * parts[..., 4:].double()).sum(2) / (f * parts[..., 1].double()).sum(2, keepdim=True)).reshape(M, -1)
+        kw, x = dict(parts=parts.to(dev)), None
+    bias = torch.randn(N, generator=g)
+    want = F.gelu(want_x @ w.double().t() + bias.double(), approximate="tanh") + res[:, :N].double()
+    buf = torch.full((M + 1, N + 8), 7.0)
+    buf[:M] = res
+    buf = buf.to(dev)
+    out = buf[:M, :N]  # in place: res aliases out; the row after M and the columns past N must stay untouched
+    xd = None if x is None else xc.to(dev)[:, :K]
+    ops.gemv_row(xd, w.to(dev), out, bias=bias.to(dev), res=out, act=ops.GELU_TANH, rows_per_wave=R, **kw)
+    err = (out.cpu().double() - want).abs().max()
+    assert err < 4e-5 * max(1.0, math.sqrt(K / 256)), float(err)
+    assert bool((buf[M] == 7.0).all()) and torch.equal(buf[:M, N:].cpu(), res[:, N:])

@@ -80,6 +80,8 @@ _OPS = [
     ("test_flash_relpos_equals_materialised_scores", (1, 300, 2, (257,))),
     ("test_gemv_row", (40, 256, "plain", 0)), ("test_gemv_row", (1030, 256, "ln", 3)), ("test_gemv_row", (70, 1024, "ln", 8)), ("test_gemv_row", (33, 768, "plain", 2)),
     ("test_gemv_row", (9, 4096, "plain", 0)), ("test_gemv_row", (256, 256, "attn", 1)), ("test_gemv_row", (50, 768, "attn", 2)),
+    ("test_gemv_row_few_rows", (2, 70, 1024, "ln", 4)), ("test_gemv_row_few_rows", (4, 37, 256, "ln", 3)), ("test_gemv_row_few_rows", (3, 9, 4096, "plain", 2)),
+    ("test_gemv_row_few_rows", (2, 64, 256, "attn", 2)), ("test_gemv_row_few_rows", (4, 50, 768, "attn", 1)),
     ("test_decode_attn_parts", (8, 4, False)), ("test_decode_attn_parts", (3, 2, True)), ("test_decode_attn_parts", (16, 8, False)),
 ]
 _EPI = [("test_gemv_decode", (6, 64, 256, 1, 4)), ("test_gemv_decode", (16, 1024, 1024, 4, 4)), ("test_gemv_swiglu", ()),
@@ -406,7 +408,7 @@ def test_t3_engine_decode_step_code_on_the_emulator(emu, tiny_llama, tune, c_ste
         assert (st["logits"].double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("tune", [dict(), dict(qkv_tc=12, od_tc=4, d_ks=1, d_nw=8)], ids=["default", "qkv12_od4_nopartials"])
+@pytest.mark.parametrize("tune", [dict(), dict(row_path=0), dict(row_path=0, qkv_tc=12, od_tc=4, d_ks=1, d_nw=8)], ids=["few_row_path", "mfma_path", "mfma_qkv12_od4_nopartials"])
 def test_t3_turbo_engine_samples_the_oracles_tokens_on_the_emulator(emu, tune):
     """The WHOLE T3-Turbo path of chatterbox_amd/t3_turbo.py on the emulator -- conditioning, prefill (exact fp32 GEMMs + flash attention),
     the 5-launch GPT-2 decode step with the LayerNorm-folded GEMVs, the device sampler (top-k / top-p bisection, repetition penalty) -- on a

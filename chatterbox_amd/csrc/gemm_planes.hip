@@ -82,13 +82,21 @@ __device__ __forceinline__ void pl_loader_wave(const cbx_gemm_pl_t& p, const lds
     };
     int l_tile = blockIdx.x, l_kt = 0, l_g = 0, ld_c0 = 0, c_g = 0;
     if (l_tile < total) load_desc(l_tile);
+#ifdef CBX_DIAG  // scripts/diag_planes.sh: 1 = no DMA after the first NS - 1 K tiles, 8 = the loader waves at s_setprio 3
+    const int ldg = p.reserved0;
+    if (ldg & 8) __builtin_amdgcn_s_setprio(3);
+#else
+    constexpr int ldg = 0;
+#endif
     auto issue = [&]() {
         const lds_u8_t dst = smem + (l_g % NS) * STAGE_BYTES + LB * 1024;
+        if (!(ldg & 1) || l_g < NS - 1) {
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
             const bool isA = ((LB + i) * 64) % PLANE_SLOTS < BM * CH;  // folds: LB, i are constants
             if (isA) pl_dma16(a_rs, dst + i * 1024, vbase[i] + offA);
             else pl_dma16(w_rs, dst + i * 1024, vbase[i] + offW);
+        }
         }
         ++l_g;
         if (++l_kt == nk) {
@@ -134,6 +142,102 @@ __device__ __forceinline__ float pl_row16_sum(float x) {  // all-reduce over the
     return x;
 }
 
+// ---- DEFERRED epilogue (round 6, DF = true; loader-wave forms only).  The K = 256 Linears of the CFM transformer blocks (q | k | v: N = 1536, ff1: N = 1024) run
+// four K tiles of MFMAs per output tile and then an epilogue of the same length (fp32 -> planes: ~9 VALU per element, GELU: ~35, and 4-byte stores) during which the
+// matrix pipe of the SIMD idles, because the 8 consumer waves of the workgroup reach their epilogues together.  In this form a finished tile is only FOLDED
+// (v = acc + accc / 2048 + bias: 32 registers per wave instead of 64) and the rest of its epilogue -- activation, residual, plane split, lane exchange, stores -- is cut
+// into QUADS (the four accumulator registers 4q .. 4q + 3 of one 32 x 32 sub-tile: four consecutive rows per lane) that are issued BETWEEN the MFMA groups of the next
+// tile's first four K tiles: VALU and stores of a wave issue while the matrix pipe works on its partner's (and its own) MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD":
+// the pipe is paced at 32 cycles per MFMA, VALU slots in between are free).  Same operations on the same values in the same order per element: bit-identical output.
+// DF = 1: tiles that write planes (P, and PT for the transposed column range) and nothing else -- q | k | v, ff1; DF = 2: tiles that write fp32 C (+ residual R) and nothing
+// else -- out-projection, ff2, convs.  The kind is a template parameter so that a quad is straight-line code and needs two buffer descriptors, not four.
+struct PlEpi {
+    __amdgpu_buffer_rsrc_t a_rs, b_rs;  // DF = 1: P, PT;  DF = 2: C, R
+    int m0, n0;
+    int zq, t0;                         // DF = 1, transposed tiles: m0 / pt_T and m0 % pt_T
+    bool vt, hasR;
+};
+
+template <int WM, int WN>
+__device__ __forceinline__ void pl_quad_res(const cbx_gemm_pl_t& p, const PlEpi& e, int wm, int wn, int lr, int lh, int i, int j, int q, float (&res)[4]) {
+    const int n = e.n0 + wn * WN + j * 32 + lr;
+    const int mb = e.m0 + wm * WM + i * 32 + 4 * lh;
+    const int ldr4 = (int)p.ldr * 4;
+    const int ro = n < p.N ? mb * ldr4 + n * 4 : (int)0x80000000;
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) res[ee] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e.b_rs, ro, (8 * q + ee) * ldr4, 0));
+}
+
+template <int ACT, int KIND, int BM, int WM, int WN>
+__device__ __forceinline__ void pl_quad_epi(const cbx_gemm_pl_t& p, const PlEpi& e, int wm, int wn, int lr, int lh, int i, int j, int q, const float (&vin)[4],
+                                            const float (&res)[4], float& amax) {
+    constexpr int OOB = (int)0x80000000;
+    const int n = e.n0 + wn * WN + j * 32 + lr;
+    const bool nok = n < p.N;
+    const int ml = wm * WM + i * 32 + 4 * lh;  // row of register 0 of the sub-tile inside the tile
+    const int mb = e.m0 + ml;
+    float v[4];
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) v[ee] = vin[ee];
+    if constexpr (ACT == CBX_ACT_GELU_ERF) {
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) v[ee] = cbx_gelu_erf(v[ee]);
+    } else if constexpr (ACT == CBX_ACT_SILU) {
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) v[ee] = v[ee] / (1.0f + __expf(-v[ee]));
+    }
+    if constexpr (KIND == 2) {
+        if (e.hasR) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) v[ee] += res[ee];
+        }
+        const int ldc4 = (int)p.ldc * 4;
+        const int co = nok ? mb * ldc4 + n * 4 : OOB;
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[ee]), e.a_rs, co, (8 * q + ee) * ldc4, 0);
+    } else if (e.vt) {  // four consecutive tokens of the lane's column: one 8-byte store per plane (see the plain epilogue)
+        unsigned h01, l01, h23, l23;
+        cbx_split2(v[0], v[1], h01, l01);
+        cbx_split2(v[2], v[3], h23, l23);
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
+        const int m = mb + 8 * q;
+        int zz, t;
+        if (p.pt_T >= BM) {  // a tile crosses at most one group boundary: m / pt_T from the tile's quotient (same values as the division)
+            const int tl = e.t0 + ml + 8 * q;
+            const bool over = tl >= p.pt_T;
+            zz = e.zq + (over ? 1 : 0);
+            t = tl - (over ? p.pt_T : 0);
+        } else {
+            zz = m / p.pt_T;
+            t = m - zz * p.pt_T;
+        }
+        const long eo = (long)zz * p.pt_zs + (long)(n - p.pt_n0) * p.pt_ld + t;
+        const int bo = (nok && m < p.M) ? (int)(eo * 2) : OOB;
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2v{h01, h23}, e.b_rs, bo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2v{l01, l23}, e.b_rs, bo + (int)p.pt_lo * 2, 0, 0);
+    } else {  // the lane-pair exchange of the plain epilogue
+        const int ldp2 = (int)p.ldp * 2;
+        const bool odd = lr & 1;
+        const int ne = n & ~1;
+        const int po = (ne < p.N ? mb * ldp2 + ne * 2 : OOB) + (odd ? ldp2 : 0);
+        const int plo2 = (int)p.p_lo * 2;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const float give = odd ? v[r] : v[r + 1];
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+            const float c0 = odd ? got : v[r], c1 = odd ? v[r + 1] : got;
+            unsigned h2, l2;
+            cbx_split2(c0, c1, h2, l2);
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(c0), "v"(c1));
+            const int so = (8 * q + r) * ldp2;
+            __builtin_amdgcn_raw_buffer_store_b32(h2, e.a_rs, po, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(l2, e.a_rs, po + plo2, so, 0);
+        }
+    }
+}
+
 // LD > 0 = loader-wave form: the workgroup has LD EXTRA waves that do nothing but issue the DMAs of every K tile and wait for them; the
 // NWV consumer waves only read LDS, multiply and run the epilogue.  A vector-memory instruction costs its issuing wave 100-200 cycles while
 // the CU's address path is busy, and a wave issues in order: in the symmetric form every wave's MFMAs queue behind its own DMA issue
@@ -142,10 +246,11 @@ __device__ __forceinline__ float pl_row16_sum(float x) {  // all-reduce over the
 // ~8 TB/s in every tile form" of DESIGN section 6.0 -- while the MFMAs of a 128 x 128 x 64 K tile want 64 KiB per ~1500 cycles (~100 GB/s per
 // CU): round 5 adds LD = 2 and LD = 4 (one loader per SIMD), each loader wave issuing 1 / LD of a K tile's DMAs (for LD = 4 exactly one of
 // {A.h, W.h, A.l, W.l}).
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD, int DF = 0>
 // (the parentheses keep the template commas away from the variadic __launch_bounds__ macro)
 __global__ __launch_bounds__((WARPS_M * WARPS_N + LD) * 64, (PlOcc<BM, BN, BK, NS, WARPS_M * WARPS_N, LD>::waves_per_simd))
 void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
+    static_assert(DF == 0 || (LD > 0 && ACT != PL_ACT_LNF), "the deferred epilogue belongs to the loader-wave forms (the consumers issue no DMA: no counted vmcnt waits to disturb)");
     constexpr int NWV = WARPS_M * WARPS_N;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -241,7 +346,9 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
     const int lr = lane & 31, lh = lane >> 5;
     const int swz = (lr / RPS) & (CH - 1);  // rows of a fragment are base + lr with base % 32 == 0: f(row) = f(lr)
     const int a_off = (wm * WM + lr) * CH * 16, b_off = (BM + wn * WN + lr) * CH * 16;
-    auto compute = [&](int stage) {
+    // (round 6, measured and not kept: a second operand register set with the requests of K chunk kc + 1 pinned in front of the MFMA group of chunk kc -- 138 instead of
+    // 111 VGPRs, within 1 - 3 % on every shape: the K loop's MFMA phase already runs at ~80 % of the clock-adjusted matrix rate, profiles/r06_r_plane_gemm_operand_prefetch.log)
+    auto compute_h = [&](int stage, auto&& after_kc) {  // after_kc(kc): instructions placed behind the MFMA group of K chunk kc (the deferred epilogue's quads)
         const unsigned char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int kc = 0; kc < BK / 16; ++kc) {
@@ -265,8 +372,10 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
                     accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+            after_kc(kc);
         }
     };
+    auto compute = [&](int stage) { compute_h(stage, [](int) {}); };
 
     // ---- main loop: NS LDS stages, one barrier per K tile.  Before the barrier every wave waits until ITS DMAs of the K tile about to be
     //      consumed have landed -- a COUNTED wait: vector-memory operations complete in issue order, so "at most n outstanding" with n = the
@@ -307,6 +416,25 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         for (int s = 0; s < NS - 1; ++s)
             if (l_tile < total) issue();
     }
+    // ---- deferred epilogue (DF): the folded values of the previous tile and where they go; quad qd = (sub-tile i, j; registers 4q .. 4q + 3)
+    constexpr int NQ = TM * TN * 4;          // quads per wave and tile
+    constexpr int KCN = BK / 16, PKT = 4;    // K chunks per K tile; the quads are spread over the first PKT K tiles of the next tile
+    constexpr int SLOTS = PKT * KCN;
+    [[maybe_unused]] float pend[TM][TN][16];
+    [[maybe_unused]] float pres[4] = {0.f, 0.f, 0.f, 0.f};  // residual values of the NEXT quad (requested one quad ahead)
+    [[maybe_unused]] PlEpi pe;
+    [[maybe_unused]] bool has_pend = false;
+    [[maybe_unused]] float amax_df = 0.f;
+    [[maybe_unused]] auto quad = [&](int qd) {
+        const int i = qd / (TN * 4), j = (qd / 4) % TN, q = qd & 3;
+        const float vin[4] = {pend[i][j][4 * q], pend[i][j][4 * q + 1], pend[i][j][4 * q + 2], pend[i][j][4 * q + 3]};
+        pl_quad_epi<ACT, DF, BM, WM, WN>(p, pe, wm, wn, lr, lh, i, j, q, vin, pres, amax_df);
+        if (DF == 2 && pe.hasR && qd + 1 < NQ) pl_quad_res<WM, WN>(p, pe, wm, wn, lr, lh, (qd + 1) / (TN * 4), ((qd + 1) / 4) % TN, (qd + 1) & 3, pres);
+    };
+    [[maybe_unused]] auto slot_quads = [&](int s) {  // the quads of slot s of SLOTS: an even spread, in order
+#pragma unroll
+        for (int qd = (s * NQ + SLOTS - 1) / SLOTS; qd < ((s + 1) * NQ + SLOTS - 1) / SLOTS; ++qd) quad(qd);
+    };
     for (int c_tile = blockIdx.x; c_tile < total; c_tile += gridDim.x) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -315,7 +443,25 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = accc[i][j][r] = 0.f;
         const bool after_epi = c_tile != (int)blockIdx.x;
-        for (int kt = 0; kt < nk; ++kt) {
+        int kt = 0;
+        if constexpr (DF) {
+            if (has_pend) {  // (wave-uniform) the previous tile's quads ride on this tile's first PKT K tiles
+#pragma unroll
+                for (int u = 0; u < PKT; ++u) {
+                    if (kt < nk) {
+                        __builtin_amdgcn_s_barrier();
+                        compute_h(c_g % NS, [&](int kc) { slot_quads(u * KCN + kc); });
+                        ++c_g;
+                        ++kt;
+                    } else {
+#pragma unroll
+                        for (int kc = 0; kc < KCN; ++kc) slot_quads(u * KCN + kc);
+                    }
+                }
+                has_pend = false;
+            }
+        }
+        for (; kt < nk; ++kt) {
             if (!LD) {
                 const int younger = l_g - c_g - 1;  // K tiles issued after the one consumed now (0 .. NS - 2)
                 if (after_epi && kt == 0 && younger == NS - 2 && !DG(5)) {
@@ -335,6 +481,7 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         }
         int z, m0, n0;
         tile_of(c_tile, z, m0, n0);
+        if (DG(16)) continue;  // (diagnostic build) no epilogue at all
 
     // ---- epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     //      Lean by construction: every store / residual load is ONE buffer instruction (32-bit lane offset + a scalar row offset); rows >= M fall
@@ -438,6 +585,26 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
             }
         }
         if (amax > 65504.f && range_flag) atomicOr(range_flag, 1);
+    } else if constexpr (DF) {  // fold: the finished values (bias included) wait in `pend` for the next tile's K loop
+        pe.a_rs = DF == 1 ? p_rs : c_rs;
+        pe.b_rs = DF == 1 ? t_rs : r_rs;
+        pe.m0 = m0; pe.n0 = n0;
+        pe.vt = vt_tile; pe.hasR = hasR;
+        if (DF == 1 && vt_tile) {
+            pe.zq = m0 / p.pt_T;
+            pe.t0 = m0 - pe.zq * p.pt_T;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + lr;
+            const float bia = p.bias ? p.bias[n < p.N ? n : 0] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pend[i][j][r] = __builtin_fmaf(accc[i][j][r], 1.0f / CBX_F16_LO_SCALE, acc[i][j][r]) + bia;
+        }
+        if (DF == 2 && hasR) pl_quad_res<WM, WN>(p, pe, wm, wn, lr, lh, 0, 0, 0, pres);
+        has_pend = true;
     } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -524,6 +691,13 @@ void gemm_pl_kernel(const cbx_gemm_pl_t p, int* range_flag) {
         if ((hasP || vt_tile) && amax > 65504.f && range_flag) atomicOr(range_flag, 1);
     }  // (plain epilogue)
     }  // tile loop
+    if constexpr (DF) {
+        if (has_pend) {  // the last tile of this workgroup: nothing left to hide behind
+#pragma unroll
+            for (int qd = 0; qd < NQ; ++qd) quad(qd);
+        }
+        if (amax_df > 65504.f && range_flag) atomicOr(range_flag, 1);
+    }
 }
 
 // x (rows, C) fp32 -> planes.  One float4 per thread; two 8-byte stores.
@@ -548,11 +722,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 int g_pl_persist = 1;  // TEST HOOK: cbx_set_planes_persist
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD, int DF = 0>
 int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * 2 * (BM + BN) * (BK / 8) * 16 + (ACT == PL_ACT_LNF ? (size_t)(WARPS_M * 8 * 32 + BM) * 4 : 0);  // + the LayerNorm epilogue's row pieces
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD>;
+    auto kern = gemm_pl_kernel<BM, BN, WARPS_M, WARPS_N, BK, NS, ACT, LD, DF>;
     constexpr int THREADS = (WARPS_M * WARPS_N + LD) * 64;
     static int resident_dev[64] = {0};  // per device ordinal (hipFuncSetAttribute and the CU count are per device): workgroups the chip holds at
     int& resident = resident_dev[cbx_device()];  // once (advisory: nothing in the kernel depends on co-residency)
@@ -573,11 +747,11 @@ int launch_pl_act(const cbx_gemm_pl_t& p, hipStream_t st) {
     return cbx_check_launch("gemm_planes");
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2, int LD = 0>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS = 2, int LD = 0, int DF = 0>
 int launch_pl(const cbx_gemm_pl_t& p, hipStream_t st) {
-    if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF, LD>(p, st);
-    if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU, LD>(p, st);
-    return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_NONE, LD>(p, st);
+    if (p.act == CBX_ACT_GELU_ERF) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_GELU_ERF, LD, DF>(p, st);
+    if (p.act == CBX_ACT_SILU) return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_SILU, LD, DF>(p, st);
+    return launch_pl_act<BM, BN, WARPS_M, WARPS_N, BK, NS, CBX_ACT_NONE, LD, DF>(p, st);
 }
 
 }  // namespace
@@ -642,11 +816,15 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     }
     CBX_REQUIRE(!p.LNP, "gemm_planes: LNP without ln_w");
     const bool k64 = p.Cin % 64 == 0;
+    const int df_kind = (p.P && !p.C && !p.R) ? 1 : (p.C && !p.P && !p.PT) ? 2 : 0;  // what the deferred-epilogue forms serve (else: their plain twins)
     int force = p.tile ? p.tile : g_pl_tile;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
     if (force == CBX_PL_TILE_CORESIDENT) {    // one 8-wave workgroup per CU (96 KiB of LDS, <= 120 VGPRs); small grids / narrow outputs keep their forms (they never fill a CU)
         const long g128c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
         constexpr int co_k64 = 8;  // 8 = the 128 x 128 x 64 two-stage form (128 KiB, 8 waves x 117 VGPRs): 214.5x against 211.3x for form 17 in the throughput schedule, same box (A/B hook)
         force = (g128c < 64 || p.N <= 96) ? 0 : (k64 ? co_k64 : 17);
+        // ... except the wide Linear with an activation (ff1 + GELU): its deferred-epilogue form (12 waves, 168 VGPRs: nothing else fits beside it) is enough faster
+        // that the throughput schedule gains from it as well (same box, A / B / A / B: 209.7 / 211.7 / 209.5 / 213.0 x, profiles/r06_s_coresident_ff1_ab.log)
+        if (force && k64 && df_kind == 1 && p.act != CBX_ACT_NONE && p.N >= 512) force = 42;
     }
     // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log
     switch (force) {
@@ -687,6 +865,17 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         case 35: if (k64) return launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st); break;   // 128 KB, 64 x 32 per wave
         case 36: return launch_pl<256, 128, 4, 2, 32, 3, 4>(p, st);                   // 144 KB, 64 x 64 per wave
         case 37: return launch_pl<128, 128, 4, 2, 32, 4, 2>(p, st);                   // 128 KB
+        // round 6: the deferred epilogue (a finished tile's epilogue rides on the next tile's K loop)
+        case 41:  // form 32 + DF
+            if (k64 && df_kind == 1) return launch_pl<128, 128, 4, 2, 64, 2, 4, 1>(p, st);
+            if (k64 && df_kind == 2) return launch_pl<128, 128, 4, 2, 64, 2, 4, 2>(p, st);
+            if (k64) return launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st);
+            break;
+        case 42:  // form 35 (64 x 32 per wave) + DF
+            if (k64 && df_kind == 1) return launch_pl<128, 128, 2, 4, 64, 2, 4, 1>(p, st);
+            if (k64 && df_kind == 2) return launch_pl<128, 128, 2, 4, 64, 2, 4, 2>(p, st);
+            if (k64) return launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st);
+            break;
         default: break;
     }
     // automatic choice (rows 16 x T 1000; profiles/r03_bench_planes_tiles.log, round 5: profiles/r05_bench_planes_loader_waves.log): 8 consumer waves
@@ -696,7 +885,13 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
     if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
     if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
+    // round 6 (INTERLEAVED rounds, profiles/r06_p_plane_gemm_forms_interleaved.log): plane outputs of the wide Linears take 64 x 32 per wave; with an activation (ff1: GELU)
+    // the deferred epilogue, whose VALU rides in the next tile's MFMA shadow (41.4 against 48.4 us, at 64 rows 182 against 217); without one (q | k | v) its plain twin --
+    // there the epilogue is stores, which the deferred form only moves into the DMA-bound K loop (50.9 against 53.7 us at 16 rows, 272 against 255 at 64)
+    if (p.N >= 512 && k64 && df_kind == 1)
+        return p.act != CBX_ACT_NONE ? launch_pl<128, 128, 2, 4, 64, 2, 4, 1>(p, st) : launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st);
     if (p.N >= 512) return k64 ? launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
+    if (k64 && p.K >= 512 && df_kind == 2 && g128 > 256) return launch_pl<128, 128, 2, 4, 64, 2, 4, 2>(p, st);  // more tiles than CUs (64 rows): 61.4 against 68.7 us
     if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st);
     return launch_pl<128, 128, 4, 2, 32>(p, st);
 }

@@ -157,6 +157,50 @@ def test_gemm_planes_transposed_column_range(dev, tile, persist):
         ops.lib.cbx_set_planes_persist(1)
 
 
+DF_SHAPES = {"full": [(1000, 1536, 256), (2048, 256, 1024), (333, 320, 512)], "small": [(260, 384, 256), (200, 256, 512)]}
+
+
+@pytest.mark.parametrize("tile,plain", [(41, 32), (42, 35)])
+@pytest.mark.parametrize("persist", [2, 8, 1])
+def test_gemm_planes_deferred_epilogue_equals_plain(dev, tile, plain, persist, shapes="full"):
+    """The deferred-epilogue forms (round 6: a finished tile is folded and its epilogue rides on the next tile's K loop) against their plain twins, BIT FOR BIT:
+    plane outputs with bias and every activation (q | k | v, ff1), the transposed column range with group boundaries inside a tile (pt_T below and above the tile
+    height), fp32 outputs with an in-place residual (out-projection, ff2).  persist = 2 / 8: workgroups walk many tiles (folded tiles ride), 1: the chip-sized grid
+    (on these shapes: one tile per workgroup -- everything goes through the drain)."""
+    from chatterbox_amd import ops
+    dv = dev
+    try:
+        ops.lib.cbx_set_planes_persist(persist)
+        for (M, N, K) in DF_SHAPES[shapes]:
+            x, w, b, r = _r((M, K), 1), _r((N, K), 2, 1 / math.sqrt(K)), _r((N,), 3), _r((M, N), 4)
+            xP, wP = ops.split_planes(x.to(dv)), ops.split_planes(w.to(dv))
+            for act in (ops.NONE, ops.GELU_ERF, ops.SILU):
+                got, want = ops.Planes(M, N, dv, zero=True), ops.Planes(M, N, dv, zero=True)
+                ops.gemm_planes(xP, wP, M=M, N=N, K=K, P=got, bias=b.to(dv), act=act, tile=tile)
+                ops.gemm_planes(xP, wP, M=M, N=N, K=K, P=want, bias=b.to(dv), act=act, tile=plain)
+                assert torch.equal(got.t, want.t), f"planes, tile {tile} vs {plain}, {M}x{N}x{K} act {act}"
+                assert float(want.float().abs().max()) > 0
+            for res in (False, True):
+                got, want = r.clone().to(dv), r.clone().to(dv)
+                ops.gemm_planes(xP, wP, M=M, N=N, K=K, C=got, ldc=N, R=got if res else None, ldr=N if res else 0, bias=b.to(dv), tile=tile)
+                ops.gemm_planes(xP, wP, M=M, N=N, K=K, C=want, ldc=N, R=want if res else None, ldr=N if res else 0, bias=b.to(dv), tile=plain)
+                assert torch.equal(got, want), f"fp32 out, tile {tile} vs {plain}, {M}x{N}x{K} residual {res}"
+        for Z, T in ((5, 200), (10, 100), (3, 36)) if shapes == "full" else ((2, 132), (5, 36)):
+            M, K, N, n0 = Z * T, 256, 1536, 1024
+            Tp = (T + 7) // 8 * 8
+            h, w = _r((M, K), 5), _r((N, K), 6, 1 / math.sqrt(K))
+            hP, wP = ops.split_planes(h.to(dv)), ops.split_planes(w.to(dv))
+            outs = []
+            for t in (tile, plain):
+                qkP, vtP = ops.Planes(M, n0, dv, zero=True), ops.Planes(Z * 512, Tp, dv, zero=True)
+                ops.gemm_planes(hP, wP, M=M, N=N, K=K, P=qkP, PT=vtP, pt_n0=n0, pt_T=T, pt_zs=512 * vtP.ld, tile=t)
+                outs.append((qkP.t, vtP.t))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f"q | k | V^T, tile {tile} vs {plain}, Z {Z} T {T}"
+            assert float(outs[1][1].float().abs().max()) > 0
+    finally:
+        ops.lib.cbx_set_planes_persist(1)
+
+
 def test_gemm_planes_transposed_rejects_bad_arguments(dev):
     from chatterbox_amd import ops
     h, w = ops.split_planes(_r((200, 256), 1).to(dev)), ops.split_planes(_r((1536, 256), 2).to(dev))

@@ -136,6 +136,13 @@ def test_gemm_planes_tiles_small(emu, tile, persist):
         emu.cbx_set_planes_persist(1)
 
 
+@pytest.mark.parametrize("tile,plain,persist", [(41, 32, 2), (42, 35, 1)])
+def test_gemm_planes_deferred_epilogue_small(emu, tile, plain, persist):
+    """tests/test_planes_gpu.py::test_gemm_planes_deferred_epilogue_equals_plain at emulator-sized shapes."""
+    import test_planes_gpu
+    test_planes_gpu.test_gemm_planes_deferred_epilogue_equals_plain(CPU, tile, plain, persist, shapes="small")
+
+
 @pytest.mark.parametrize("M,K,res", [(333, 512, True), (64, 256, False)])
 def test_gemm_planes_layernorm_epilogue_small(emu, M, K, res):
     """tests/test_planes_gpu.py::test_gemm_planes_layernorm_epilogue at emulator-sized shapes."""
@@ -455,7 +462,7 @@ def _rerun(env, select):
     return r.returncode, (r.stdout + r.stderr)[-1500:]
 
 
-_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or conv_and_transposed_columns or transposed_walk or layernorm_epilogue"
+_DMA_TESTS = "gemm_planes_tiles_small or flash_attn_planes_small or conv_and_transposed_columns or transposed_walk or layernorm_epilogue or deferred_epilogue"
 
 
 def test_counted_waits_of_the_lds_dma_pipelines_are_sufficient(emu):

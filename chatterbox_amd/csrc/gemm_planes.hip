@@ -825,6 +825,11 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
         // ... except the wide Linear with an activation (ff1 + GELU): its deferred-epilogue form (12 waves, 168 VGPRs: nothing else fits beside it) is enough faster
         // that the throughput schedule gains from it as well (same box, A / B / A / B: 209.7 / 211.7 / 209.5 / 213.0 x, profiles/r06_s_coresident_ff1_ab.log)
         if (force && k64 && df_kind == 1 && p.act != CBX_ACT_NONE && p.N >= 512) force = 42;
+        // ... and q | k | v on its loader-wave form (A / B / A / B: 218.8 / 221.3 / 219.7 / 220.8 x, profiles/r06_t_coresident_qkv_ab.log)
+        else if (force && k64 && df_kind == 1 && p.N >= 512) force = 35;
+#ifdef CBX_EXP_CORESIDENT_OFF  // side-library experiment (scripts/r06/r06_v.sh): every plane GEMM of the throughput schedule on its serial-schedule form
+        force = 0;
+#endif
     }
     // tile menu (BM x BN, waves, wave tile, BK, LDS stages); the automatic choice below is the measured one: profiles/r03_gemm_planes_tiles.log
     switch (force) {
@@ -888,8 +893,10 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     // round 6 (INTERLEAVED rounds, profiles/r06_p_plane_gemm_forms_interleaved.log): plane outputs of the wide Linears take 64 x 32 per wave; with an activation (ff1: GELU)
     // the deferred epilogue, whose VALU rides in the next tile's MFMA shadow (41.4 against 48.4 us, at 64 rows 182 against 217); without one (q | k | v) its plain twin --
     // there the epilogue is stores, which the deferred form only moves into the DMA-bound K loop (50.9 against 53.7 us at 16 rows, 272 against 255 at 64)
+#ifndef CBX_EXP_NO_DF  // (side-library experiment, scripts/r06/r06_u.sh: the round-5 choice)
     if (p.N >= 512 && k64 && df_kind == 1)
         return p.act != CBX_ACT_NONE ? launch_pl<128, 128, 2, 4, 64, 2, 4, 1>(p, st) : launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st);
+#endif
     if (p.N >= 512) return k64 ? launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st) : launch_pl<128, 128, 2, 4, 32>(p, st);
     if (k64 && p.K >= 512 && df_kind == 2 && g128 > 256) return launch_pl<128, 128, 2, 4, 64, 2, 4, 2>(p, st);  // more tiles than CUs (64 rows): 61.4 against 68.7 us
     if (k64 && p.K >= 512) return launch_pl<128, 128, 4, 2, 64, 2, 4>(p, st);

@@ -139,7 +139,7 @@ typedef struct cbx_gemm_pl_t {
     void* PT; int pt_n0, pt_T; long pt_ld, pt_lo, pt_zs;   /* halves */
     /* ABI v13 -- launch geometry of THIS call: 0 = the library's measured choice (or the cbx_set_planes_tile test hook); n > 0 = form n of the tile menu
      * (gemm_planes.hip); CBX_PL_TILE_CORESIDENT (-1) = the measured choice among the forms that leave room on the CU: ONE workgroup of 8 waves and <= 120
-     * VGPRs per CU with 96 KiB of LDS (form 17), so that the workgroups of a latency-bound kernel chain on ANOTHER stream (the T3 decode step of the next
+     * VGPRs per CU (form 8 where K % 64 == 0: 128 KiB of LDS, 32 KiB left; form 17 otherwise: 96 KiB), so that the workgroups of a latency-bound kernel chain on ANOTHER stream (the T3 decode step of the next
      * batch) stay co-resident instead of waiting for these to retire (profiles/r05_overlap_*); round 6: the two wide Linears of a transformer block (ff1 + GELU, q | k | v) keep
      * their loader-wave forms even then (measured: profiles/r06_{s,t,v}_*_ab.log).  Forms 41 / 42 (round 6) = forms 32 / 35 with the DEFERRED epilogue: a finished tile is folded
      * and the rest of its epilogue is issued between the MFMA groups of the workgroup's next tile.  Same arithmetic in every form. */

@@ -881,6 +881,10 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
             if (k64 && df_kind == 2) return launch_pl<128, 128, 2, 4, 64, 2, 4, 2>(p, st);
             if (k64) return launch_pl<128, 128, 2, 4, 64, 2, 4>(p, st);
             break;
+        // round 6: deeper rings / wider K tiles for the 64 x 64 tile of small grids (batch 1: one K tile in flight is a DMA round trip per K tile)
+        case 43: return launch_pl<64, 64, 2, 2, 32, 3>(p, st);                        // 48 KB
+        case 44: if (k64) return launch_pl<64, 64, 2, 2, 64, 2>(p, st); break;        // 64 KB
+        case 45: if (k64) return launch_pl<64, 64, 2, 2, 64, 3>(p, st); break;        // 96 KB
         default: break;
     }
     // automatic choice (rows 16 x T 1000; profiles/r03_bench_planes_tiles.log, round 5: profiles/r05_bench_planes_loader_waves.log): 8 consumer waves
@@ -888,8 +892,13 @@ extern "C" int cbx_gemm_planes(const cbx_gemm_pl_t* pp, void* stream) {
     // streaming one of {A.h, W.h, A.l, W.l}) since round 5: 2-5 % under the one-loader form on every CFM shape, and now also ahead of the symmetric two-
     // workgroup form for the GELU epilogue (ff1: 43.7 against 46.1 us); N <= 96 takes half-width tiles, small grids 64 x 64.
     const long g128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz1;
-    if (g128 < 64) return launch_pl<64, 64, 2, 2, 32>(p, st);
+    // part-filled chip (batch 1 - 4: at most 128 tiles of 128 x 128): 64 x 64 tiles, with 64-wide K tiles where the shape allows (half the barriers and DMA round trips of a
+    // K walk that is latency-bound at one workgroup per CU) -- round 6, profiles/r06_ab_plane_gemm_small_grids.log: ff2 at 4 rows 18.6 -> 13.1 us, at 2 rows 13.6 -> 12.5;
+    // the crossover with the 128 x 128 forms lies between 126 and 134 such tiles for the N = 256 shapes and at 128 for the wide ones
+    auto small = [&]() { return k64 ? launch_pl<64, 64, 2, 2, 64, 2>(p, st) : launch_pl<64, 64, 2, 2, 32>(p, st); };
+    if (g128 < 64) return small();
     if (p.N <= 96) return launch_pl<128, 64, 4, 2, 32>(p, st);
+    if (g128 <= 128) return small();
     // round 6 (INTERLEAVED rounds, profiles/r06_p_plane_gemm_forms_interleaved.log): plane outputs of the wide Linears take 64 x 32 per wave; with an activation (ff1: GELU)
     // the deferred epilogue, whose VALU rides in the next tile's MFMA shadow (41.4 against 48.4 us, at 64 rows 182 against 217); without one (q | k | v) its plain twin --
     // there the epilogue is stores, which the deferred form only moves into the DMA-bound K loop (50.9 against 53.7 us at 16 rows, 272 against 255 at 64)

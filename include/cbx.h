@@ -289,14 +289,16 @@ int cbx_flash_attn_split_po(const float* q, const float* k, const float* v, void
 int cbx_flash_attn_planes(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
                           int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
                           long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, void* stream);
-/* ABI v13: the same with the kernel version chosen PER CALL (0 = the library default, else 1 .. 5 as cbx_set_attn_planes_version).  5 = the CO-RESIDENT form:
+/* ABI v13: the same with the kernel version chosen PER CALL (0 = the library's automatic choice: version 4, or its 128-query twin (the kernel of version 5) where the grid
+ * of 256-query workgroups would fill at most half of the chip -- batch 1; else 1 .. 6 as cbx_set_attn_planes_version).  5 = the CO-RESIDENT form:
  * the free-running loop of version 4 on 4-wave workgroups of 128 queries, one per CU (96 KiB of LDS, one wave of ~200 VGPRs per SIMD): 3/5 of the register
  * file stay free for another stream's workgroups; bit-identical to version 4; +8 % per launch when alone (profiles/r05_overlap_*). */
 int cbx_flash_attn_planes_v(const void* q, const void* k, const void* vt, void* o, const int* key_lens, int nz1, int n_heads, int Tq,
                             int Tk, long q_sb, long q_st, long q_lo, long k_sb, long k_st, long k_lo, long vt_sb, long vt_sd,
                             long vt_lo, long o_sb, long o_st, long o_lo, float scale, int causal, int version, void* stream);
-/* tuning knob (A/B hook, no engine calls it): kernel version of cbx_flash_attn_planes (4 = default since round 4: free-running loop, every wave
- * meets the others once per key tile; 2 = two wave groups alternating matrix / vector blocks; 1 = one group; 3 = version 2 with wave priorities) */
+/* tuning knob (A/B hook, no engine calls it): kernel version of cbx_flash_attn_planes (0 = automatic; 4 = free-running loop, every wave meets the others once per
+ * key tile; 2 = two wave groups alternating matrix / vector blocks; 1 = one group; 3 = version 2 with wave priorities; 6 = version 4 with its DMAs issued between
+ * the softmax and the PV product: measured equal, profiles/r06_y_*) */
 int cbx_set_attn_planes_version(int v);
 
 /* Single-query decode attention over a KV cache (HF DynamicCache + sdpa, q_len == 1; t3.py:378-384).

@@ -125,7 +125,7 @@ for ver in (1, 2, 3, 4):
     us_new = timeit(lambda: ops.flash_attn_planes(qkP.cols(0, 512), qkP.cols(512, 512), vtP, attP, Z=ROWS, H=8, T=T, vt_sb=512 * vtP.ld, scale=0.125,
                                                   key_lens=lens))
     line += f" planes v{ver} {us_new:6.1f} us {fl / us_new / 1e6:6.1f} TF fp32-equivalent |"
-ops.lib.cbx_set_attn_planes_version(4)
+ops.lib.cbx_set_attn_planes_version(0)
 print(line, flush=True)
 
 

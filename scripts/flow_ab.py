@@ -12,7 +12,7 @@ from chatterbox_amd.s3gen import FlowEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
 flow = FlowEngine(synth.s3gen_state_dict(0), dev)
-B, N = 8, 250
+B, N = int(os.environ.get("CBX_B", "8")), 250
 toks = torch.stack([synth.speech_tokens(N, seed=b) for b in range(B)]).to(dev)
 lens = torch.full((B,), N, dtype=torch.int32, device=dev)
 ref = synth.s3gen_ref()

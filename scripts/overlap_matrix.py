@@ -121,4 +121,4 @@ for name, fn, knobs in cases:
                           bg_ms_total=round(bg_both, 1), bg_ms_if_alone=round(n * us * 1e-3, 1), host_enqueue_ms=round(host_ms, 1),
                           note="bg_ms_total - bg_ms_if_alone = what the flow kernel lost to the co-running T3 (T3 ends first)")), flush=True)
 _lib.lib.cbx_set_planes_tile(0)
-_lib.lib.cbx_set_attn_planes_version(4)
+_lib.lib.cbx_set_attn_planes_version(0)

@@ -81,6 +81,6 @@ if os.environ.get("CBX_OV_ATTN"):
     config("F = E with the flow on the default GEMM tiles", 0, True, int(os.environ["CBX_OV_ATTN"]))
     config("G = plane attention version " + os.environ["CBX_OV_ATTN"] + " only (T3 on its default geometry, default GEMM tiles)", 0, False, int(os.environ["CBX_OV_ATTN"]))
 _lib.lib.cbx_set_planes_tile(0)
-_lib.lib.cbx_set_attn_planes_version(4)
+_lib.lib.cbx_set_attn_planes_version(0)
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)

@@ -94,5 +94,5 @@ _lib.lib.cbx_set_planes_tile(17)
 eng.t3.apply_variant(dict(eng.t3.tune, half_tiles=0, d_ks2=4, d_nw2=8), dict(eng.t3.knobs, shallow=1))
 eng.t3.generate(t3c, texts, **kw)
 report("co-residency kernels (attention v5, GEMM tile 17, T3 geometry)")
-_lib.lib.cbx_set_attn_planes_version(4)
+_lib.lib.cbx_set_attn_planes_version(0)
 _lib.lib.cbx_set_planes_tile(0)

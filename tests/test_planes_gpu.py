@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TILES = list(range(0, 20)) + [21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 37]  # 21 .. 25: the loader-wave forms, 26 .. 28: 16-wave workgroups  # 0 = the dispatcher's own choice, 1..17 = the menu of gemm_planes.hip
+TILES = list(range(0, 20)) + [21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 37, 41, 42, 43, 44, 45]  # 21 .. 25: the loader-wave forms, 26 .. 28: 16-wave workgroups  # 0 = the dispatcher's own choice, 1..17 = the menu of gemm_planes.hip
 
 
 def _r(shape, seed, scale=1.0):
@@ -228,12 +228,12 @@ def test_layernorm_planes(dev):
     assert (out.float() - plain).abs().max() <= 2.0 ** -21 * plain.abs().max(), "planes = split of the fp32 LayerNorm kernel's result"
 
 
-@pytest.fixture(params=[2, 1, 3, 4, 5])
+@pytest.fixture(params=[2, 1, 3, 4, 5, 6])
 def attn_version(request):
     from chatterbox_amd import ops
     ops.lib.cbx_set_attn_planes_version(request.param)
     yield request.param
-    ops.lib.cbx_set_attn_planes_version(4)  # the library default
+    ops.lib.cbx_set_attn_planes_version(0)  # the library's automatic choice
 
 
 @pytest.mark.parametrize("Z,T,lens", [(2, 1000, None), (3, 517, [517, 130, 64]), (1, 64, None), (2, 200, [1, 199]), (1, 300, [0])])

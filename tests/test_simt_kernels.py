@@ -205,7 +205,7 @@ def test_gemm_planes_transposed_walk_small(emu, tile):
         emu.cbx_set_planes_persist(1)
 
 
-@pytest.mark.parametrize("version", [2, 1, 4, 5])
+@pytest.mark.parametrize("version", [2, 1, 4, 5, 6])
 def test_flash_attn_planes_small(emu, version):
     """tests/test_planes_gpu.py::test_flash_attn_planes at emulator-sized shapes (ragged key lengths incl. an empty utterance)."""
     import test_planes_gpu
@@ -214,7 +214,7 @@ def test_flash_attn_planes_small(emu, version):
         test_planes_gpu.test_flash_attn_planes(CPU, version, 3, 200, [200, 130, 1])
         test_planes_gpu.test_flash_attn_planes(CPU, version, 1, 64, None)
     finally:
-        emu.cbx_set_attn_planes_version(4)  # the library default
+        emu.cbx_set_attn_planes_version(0)  # the library's automatic choice
 
 
 def test_split_gemm_small(emu):

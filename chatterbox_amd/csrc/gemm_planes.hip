@@ -242,8 +242,8 @@ __device__ __forceinline__ void pl_quad_epi(const cbx_gemm_pl_t& p, const PlEpi&
 // NWV consumer waves only read LDS, multiply and run the epilogue.  A vector-memory instruction costs its issuing wave 100-200 cycles while
 // the CU's address path is busy, and a wave issues in order: in the symmetric form every wave's MFMAs queue behind its own DMA issue
 // (measured: DMA time and MFMA time ADD, profiles/r03_planes_diag_switches.log); with dedicated loaders they overlap.  ONE loader wave issues
-// a 1 KiB DMA per ~100 cycles -- MI355X_MICROARCH.md `ldsdma-fill`: ~25 GB/s per CU, 6.4 TB/s over the chip, which is the "operand stream at
-// ~8 TB/s in every tile form" of DESIGN section 6.0 -- while the MFMAs of a 128 x 128 x 64 K tile want 64 KiB per ~1500 cycles (~100 GB/s per
+// a 1 KiB DMA per ~100 cycles -- MI355X_MICROARCH.md `ldsdma-fill`: ~25 GB/s per CU, 6.4 TB/s over the chip, which is the operand stream at
+// ~8 TB/s that every round-3 tile form ran into -- while the MFMAs of a 128 x 128 x 64 K tile want 64 KiB per ~1500 cycles (~100 GB/s per
 // CU): round 5 adds LD = 2 and LD = 4 (one loader per SIMD), each loader wave issuing 1 / LD of a K tile's DMAs (for LD = 4 exactly one of
 // {A.h, W.h, A.l, W.l}).
 template <int BM, int BN, int WARPS_M, int WARPS_N, int BK, int NS, int ACT, int LD, int DF = 0>

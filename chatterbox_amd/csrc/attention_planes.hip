@@ -565,7 +565,11 @@ extern "C" int cbx_flash_attn_planes_v(const void* q, const void* k, const void*
     // versions 2 / 4 (256 queries per workgroup; 4 = the free-running loop, the default) serve the non-causal case with 31-bit K / V^T offsets; cbx_set_attn_planes_version(1)
     // keeps the one-group kernel (A/B: scripts/bench_planes.py), 3 = version 2 with s_setprio 1 around the matrix block (measured: no gain)
     const int forced = version ? version : g_attn_pl_version;  // the call's own choice first (ABI v13); the process-wide knob is a test hook
-    const int ver = forced ? forced : 4;                        // automatic = version 4, on small grids its 128-query twin (below)
+    // automatic = version 4 (256 queries per workgroup, three stages); on small grids its 128-query twin (below); for SHORT key sequences on a filled chip the one-group
+    // kernel of version 1 (128 queries, two workgroups per CU): the 9 - 12 KV tiles of T <= 768 do not amortise version 4's prologue and its last, part-filled query
+    // tile -- 16 rows: T 530 59.3 -> 54.0 us, T 730 76.9 -> 72.4, T 1000 110.8 against 120.3 (profiles/r06_ag_plane_attention_short_sequences.log)
+    const bool short_seq = forced == 0 && Tk <= 768 && (long)((Tq + 255) / 256) * n_heads * nz1 > 128;
+    const int ver = forced ? forced : short_seq ? 1 : 4;
     const bool v2ok = !causal && k_st >= k_lo + 64 && (long)Tk * k_st * 2 < 0x7fffffffL && 64 * vt_sd * 2 < 0x7fffffffL && vt_sd >= vt_lo;
     if (ver >= 2 && v2ok) {
         constexpr int lds = 3 * PL_STAGE;

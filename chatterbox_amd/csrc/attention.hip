@@ -27,6 +27,7 @@ struct FlashArgs {
     long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
     float scale;
     int causal;  // 0 = none; else key j allowed iff j <= i + (Tk - Tq)
+    long k_sh = 64, v_sh = 64;  // head strides of K / V (ABI v15: 64 = heads side by side in a token row; the KV cache has them max_ctx * 64 apart)
 };
 
 template <bool PREFETCH>
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const FlashArgs a) 
     const int q0 = qt * 128;
     const int qi = q0 + wid * 32 + lr;  // this lane's query
     const float* qb = a.q + (long)z * a.q_sb + head * 64;
-    const float* kb = a.k + (long)z * a.k_sb + head * 64;
-    const float* vb = a.v + (long)z * a.v_sb + head * 64;
+    const float* kb = a.k + (long)z * a.k_sb + head * a.k_sh;
+    const float* vb = a.v + (long)z * a.v_sb + head * a.v_sh;
     const int klen = a.key_lens ? min(a.Tk, a.key_lens[z]) : a.Tk;
     const int coff = a.Tk - a.Tq;
 
@@ -783,6 +784,21 @@ extern "C" int cbx_flash_attn_f32(const float* q, const float* k, const float* v
     dim3 grid((Tq + 127) / 128, n_heads, nz1);
     hipLaunchKernelGGL(flash_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);  // (<false>: without the K / V register prefetch; measured slower in round 2)
     return cbx_check_launch("flash_attn");
+}
+
+// ABI v15: K / V with their own head strides -- the prefill of T3's text positions reads the keys of the (cached) conditioning prefix and its own from the KV cache
+// ([row][head][max_ctx][64]: k_st = 64, k_sh = max_ctx * 64), queries from the q | k | v workspace; causal with Tq < Tk: query i sees keys j <= i + (Tk - Tq).
+extern "C" int cbx_flash_attn_kv_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens, int nz1, int n_heads, int Tq, int Tk,
+                                     long q_sb, long q_st, long k_sb, long k_st, long k_sh, long v_sb, long v_st, long v_sh, long o_sb, long o_st, float scale,
+                                     int causal, void* stream) {
+    CBX_REQUIRE(q && k && v && o, "flash_attn_kv: null operand");
+    CBX_REQUIRE(Tq > 0 && Tk > 0 && nz1 > 0 && n_heads > 0, "flash_attn_kv: bad shape");
+    CBX_REQUIRE((q_st | k_st | v_st | o_st | q_sb | k_sb | v_sb | o_sb | k_sh | v_sh) % 4 == 0, "flash_attn_kv: strides must be multiples of 4");
+    CBX_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "flash_attn_kv: 16-byte alignment");
+    FlashArgs a{q, k, v, o, key_lens, Tq, Tk, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, scale, causal, k_sh, v_sh};
+    dim3 grid((Tq + 127) / 128, n_heads, nz1);
+    hipLaunchKernelGGL(flash_attn_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return cbx_check_launch("flash_attn_kv");
 }
 
 extern "C" int cbx_flash_relpos_f32(const float* qu, const float* qv, const float* k, const float* v, const float* pp, float* o,

@@ -488,12 +488,21 @@ def layernorm(x, w, b, out, eps=1e-5, rms=False, act=NONE, post_add=None, scale=
 
 
 def flash_attn(q, k, v, out, scale, key_lens=None, causal=False):
-    """q (Z,Tq,H,64), k/v (Z,Tk,H,64), out (Z,Tq,H,64): strided views with head stride 64, unit inner stride."""
+    """q (Z,Tq,H,64), k/v (Z,Tk,H,64), out (Z,Tq,H,64): strided views with head stride 64, unit inner stride.  k / v may carry another head stride (ABI v15:
+    views of the KV cache, exact fp32 only)."""
     Z, Tq, H, D = q.shape
     Tk = k.shape[1]
     assert D == 64
-    for t in (q, k, v, out):
+    for t in (q, out):
         assert t.stride(3) == 1 and t.stride(2) == 64
+    assert k.stride(3) == 1 and v.stride(3) == 1
+    if k.stride(2) != 64 or v.stride(2) != 64:
+        assert _prec() not in (3, 6, 16), "K / V head strides: the exact fp32 attention only"
+        kv_args = (_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), k.stride(2),
+                   v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), scale, int(causal))
+        _timed("flash_attn_f32", 4.0 * Z * H * Tq * Tk * 64 * (0.5 if causal else 1.0), 4.0 * Z * H * 64 * (2 * Tq + 2 * Tk),
+               lambda: check(lib.cbx_flash_attn_kv_f32(*kv_args, _stream()), "cbx_flash_attn_kv_f32"))
+        return out
     args = (_p(q), _p(k), _p(v), _p(out), _p(key_lens), Z, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
             v.stride(0), v.stride(1), out.stride(0), out.stride(1), scale, int(causal))
     if _prec() in (3, 6, 16):  # same numerics policy as the GEMMs issued in this scope

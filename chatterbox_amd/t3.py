@@ -124,6 +124,9 @@ class T3Engine:
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled
         self.tune = self._env_tune()
         self.knobs = self._env_knobs()
+        # K / V of a voice's 34 conditioning positions at every layer, kept after the first prefill with that voice (round 6; see _voice_prefix)
+        self.share_prefix = os.environ.get("CBX_T3_SHARE_PREFIX", "1") == "1"
+        self._prefix_cache = []
 
     # ------------------------------------------------------------------ packed device layout <-> disk (formats.save_packed / load_packed)
     _PLAIN = ("norm", "text_emb", "speech_emb", "text_pos", "speech_pos", "head", "head_pk", "spkr_w", "spkr_b", "emo_w", "pq", "cos", "sin")
@@ -162,6 +165,7 @@ class T3Engine:
         self.c_loop = self.c_step and os.environ.get("CBX_T3_CLOOP", "1") == "1"
         self.tune = cls._env_tune()
         self.knobs = cls._env_knobs()
+        self.share_prefix, self._prefix_cache = os.environ.get("CBX_T3_SHARE_PREFIX", "1") == "1", []
         return self
 
     @classmethod
@@ -443,6 +447,53 @@ class T3Engine:
         emo = float(torch.as_tensor(cond["emotion_adv"]).reshape(-1)[0])
         ops.axpby(self.emo_w.view(1, -1), out[33:34], a=emo, b=0.0)
         return out
+
+    # ------------------------------------------------------------------ the conditioning prefix of a voice (round 6)
+    # The prompt of T3.inference is [34 conditioning positions | text | BOS BOS] under a causal mask (t3.py:303-335): the conditioning positions see only
+    # themselves, so their K / V at every layer depend on the voice alone -- not on the text, the row (the CFG copy keeps cond_emb, t3.py:102-130) or the batch.
+    # After the first (full) prefill with a voice they are copied out of KV-cache row 0; later prefills with the SAME conditioning tensors run over the text
+    # positions only (a third fewer rows in every prefill GEMM at 64 text tokens) and read the prefix keys from the cache (cbx_flash_attn_kv_f32).  The entry keeps
+    # the conditioning tensors alive and is matched by identity + version counter: a hit means the very tensors the prefix was computed from, unmodified.
+    _PREFIX_KEEP = 4
+
+    def _voice_prefix(self, conds):
+        if not (self.share_prefix and isinstance(conds, dict)):
+            return None
+        for ent in self._prefix_cache:
+            ok = ent["keys"] == sorted(conds)
+            for k, v, ver in ent["items"] if ok else ():
+                c = conds[k]
+                ok = (c is v and c._version == ver) if torch.is_tensor(v) else (not torch.is_tensor(c) and c == v)
+                if not ok:
+                    break
+            if ok:
+                return ent
+        return None
+
+    def _keep_voice_prefix(self, conds, st):
+        """After a full prefill: K / V of positions 0 .. 33 of cache row 0 (L, H, 34, 64)."""
+        if not (self.share_prefix and isinstance(conds, dict)) or self._voice_prefix(conds) is not None:
+            return
+        items = [(k, v, v._version if torch.is_tensor(v) else None) for k, v in sorted(conds.items())]
+        ent = dict(keys=sorted(conds), items=items, k=st["kc"][:, 0, :, :34].clone(), v=st["vc"][:, 0, :, :34].clone(), ev=None)
+        if self.dev.type == "cuda":
+            ent["ev"] = torch.cuda.Event()
+            ent["ev"].record()
+        self._prefix_cache.insert(0, ent)
+        del self._prefix_cache[self._PREFIX_KEEP:]
+
+    def _layer_prefill_text(self, lw, x, ws, St, S, rows, kc, vc, pos, crow):
+        """_layer_prefill over the text positions alone: queries from the q | k | v workspace, keys / values [cached prefix | text] from the KV cache."""
+        ops.layernorm(x, lw["ln1"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wqkv"], ws["qkv"])
+        ops.rope_kv(ws["qkv"], pos, self.cos, self.sin, kc, vc, self.H, cache_rows=crow)
+        q4 = ws["qkv"].view(rows, St, 3, self.H, 64)
+        ops.flash_attn(q4[:, :, 0], kc[:rows, :, :S].permute(0, 2, 1, 3), vc[:rows, :, :S].permute(0, 2, 1, 3), ws["att"].view(rows, St, self.H, 64), 0.125,
+                       causal=True)
+        ops.linear(ws["att"], lw["wo"], x, residual=x)
+        ops.layernorm(x, lw["ln2"], None, ws["h"], 1e-5, rms=True)
+        ops.linear(ws["h"], lw["wgu"], ws["g"], swiglu=True)
+        ops.linear(ws["g"], lw["wd"], x, residual=x)
 
     # ------------------------------------------------------------------ one transformer layer
     def _layer_prefill(self, lw, x, ws, S, rows, kc, vc, pos, crow):
@@ -729,7 +780,11 @@ class T3Engine:
                                      ban_from=ban_from, use_graph=use_graph, poll_every=poll_every, slot=slot)
             return out
         rows = 2 * B
-        if isinstance(conds, dict):
+        prec = self.tune.get("prefill_prec") or 0
+        pre = self._voice_prefix(conds) if prec in (0, 1) else None  # the cached conditioning prefix of this voice: prefill the text positions only
+        if pre is not None:
+            ce = None
+        elif isinstance(conds, dict):
             ce = [self.cond_embeds(conds)] * B
         else:
             ce = [self.cond_embeds(c) for c in conds]
@@ -752,31 +807,46 @@ class T3Engine:
             st["uniforms"].copy_(torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)[:, :max_new_tokens])
 
         # ---- prefill embeddings (prepare_input_embeds + second BOS, t3.py:102-130,305-313)
-        x = torch.zeros(rows, S, self.D, device=dev)
+        P0 = 34 if pre is not None else 0  # prompt positions that are NOT computed in this call
+        Sx = S - P0
+        x = torch.zeros(rows, Sx, self.D, device=dev)
         bos = torch.full((2,), START_SPEECH, dtype=torch.int64, device=dev)
         zero2 = torch.zeros(2, dtype=torch.int32, device=dev)
         for b in range(B):
             ids = text_tokens[b].to(dev).long().view(-1)
             pos = torch.arange(tl[b], dtype=torch.int32, device=dev)
             for r, scale in ((b, 1.0), (B + b, 0.0)):
-                x[r, :34] = ce[b]
-                ops.embed(ids, self.text_emb, x[r, 34:34 + tl[b]], table2=self.text_pos, ids2=pos, scale=scale)
-                ops.embed(bos, self.speech_emb, x[r, 34 + tl[b]:s0[b]], table2=self.speech_pos, ids2=zero2)
-        xf = x.view(rows * S, self.D)
-        pws = dict(h=torch.empty(rows * S, self.D, device=dev), qkv=torch.empty(rows * S, 3 * self.D, device=dev),
-                   att=torch.empty(rows * S, self.D, device=dev), g=torch.empty(rows * S, self.F, device=dev))
-        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(rows)
-        crow = torch.arange(rows, dtype=torch.int32, device=dev).repeat_interleave(S)
+                if pre is None:
+                    x[r, :34] = ce[b]
+                ops.embed(ids, self.text_emb, x[r, 34 - P0:34 - P0 + tl[b]], table2=self.text_pos, ids2=pos, scale=scale)
+                ops.embed(bos, self.speech_emb, x[r, 34 - P0 + tl[b]:s0[b] - P0], table2=self.speech_pos, ids2=zero2)
+        xf = x.view(rows * Sx, self.D)
+        pws = dict(h=torch.empty(rows * Sx, self.D, device=dev), qkv=torch.empty(rows * Sx, 3 * self.D, device=dev),
+                   att=torch.empty(rows * Sx, self.D, device=dev), g=torch.empty(rows * Sx, self.F, device=dev))
+        pos = torch.arange(P0, S, dtype=torch.int32, device=dev).repeat(rows)
+        crow = torch.arange(rows, dtype=torch.int32, device=dev).repeat_interleave(Sx)
         # prefill_prec (tune / CBX_T3_TUNE="prefill_prec=6", opt-in, untimed): the prefill's plain projections (q/k/v, o, down) and its attention
         # on the bf16x6 split kernels (24 significand bits, fp32 range, accumulation error below the exact MFMA's own: DESIGN.md section 1)
         # instead of the exact fp32 MFMA; gate|up (SwiGLU epilogue) and every decode step stay exact
-        if self.c_step and not ops.TIMER:  # the same launches through the stage-level C entry point cbx_t3_prefill (one ctypes call instead of 9 per layer)
+        if pre is not None:
+            if pre["ev"] is not None:  # the entry may have been written on another stream (two decode chains of the throughput schedule)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(pre["ev"])
+                pre["k"].record_stream(cur), pre["v"].record_stream(cur)
+            st["kc"][:, :rows, :, :34].copy_(pre["k"][:, None])
+            st["vc"][:, :rows, :, :34].copy_(pre["v"][:, None])
+            with ops.gemm_precision(prec):
+                for i, lw in enumerate(self.layers):
+                    self._layer_prefill_text(lw, xf, pws, Sx, S, rows, st["kc"][i], st["vc"][i], pos, crow)
+        elif self.c_step and not ops.TIMER:  # the same launches through the stage-level C entry point cbx_t3_prefill (one ctypes call instead of 9 per layer)
             self._prefill_c(xf, pws, S, rows, st, pos, crow)
         else:
-            with ops.gemm_precision(self.tune.get("prefill_prec") or 0):
+            with ops.gemm_precision(prec):
                 for i, lw in enumerate(self.layers):
                     self._layer_prefill(lw, xf, pws, S, rows, st["kc"][i], st["vc"][i], pos, crow)
-        last = torch.tensor([r * S + s0[r % B] - 1 for r in range(rows)], device=dev)
+        if pre is None and prec in (0, 1):
+            self._keep_voice_prefix(conds, st)
+        last = torch.tensor([r * Sx + s0[r % B] - P0 - 1 for r in range(rows)], device=dev)
         hl = xf.index_select(0, last).contiguous()
         ops.layernorm(hl, self.norm, None, st["dws"]["h"], 1e-5, rms=True)
         ops.linear(st["dws"]["h"], self.head, st["logits"])

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 14 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 15 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
@@ -30,7 +30,8 @@ extern "C" {
                               13: per-call launch geometry of the plane-format kernels (cbx_gemm_pl_t.tile, cbx_flash_attn_planes_v, cbx_cfm_t.gemm_tile /
                                   attn_version: no process-wide state on the flow path either) incl. the CO-RESIDENT forms of the throughput schedule
                                   (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW;
-                              14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts; the token loop in C: cbx_t3_loop_* */
+                              14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts; the token loop in C: cbx_t3_loop_*;
+                              15: cbx_flash_attn_kv_f32 (K / V head strides: attention over the KV cache in the prefill) */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -266,6 +267,13 @@ int cbx_layernorm_f32(const float* x, float* y, const float* w, const float* b, 
 int cbx_flash_attn_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens,
                        int nz1, int n_heads, int Tq, int Tk, long q_sb, long q_st, long k_sb, long k_st,
                        long v_sb, long v_st, long o_sb, long o_st, float scale, int causal, void* stream);
+/* ABI v15: the same with HEAD strides for K and V (k_sh / v_sh floats between the heads of one token; cbx_flash_attn_f32 = 64): keys and values read where
+ * DynamicCache keeps them -- T3's KV cache [row][head][max_ctx][64] has k_st = 64, k_sh = max_ctx * 64.  Serves the prefill of the TEXT positions of T3.inference
+ * when the 34 conditioning positions of a voice are already cached (t3.py:303-335: the prompt [cond | text | BOS BOS]; HF sdpa is_causal with Tq < Tk: query i sees
+ * keys j <= i + (Tk - Tq)). */
+int cbx_flash_attn_kv_f32(const float* q, const float* k, const float* v, float* o, const int* key_lens, int nz1, int n_heads, int Tq, int Tk,
+                          long q_sb, long q_st, long k_sb, long k_st, long k_sh, long v_sb, long v_st, long v_sh, long o_sb, long o_st, float scale,
+                          int causal, void* stream);
 /* Same contract on the bf16 / fp16 matrix cores with split fp32 operands: precision 3 ("bf16x3", rel. error ~4e-6 per
  * contraction), 6 ("bf16x6", fp32-level) or 16 ("f16x3", fp32-level, fp16 operand range), see cbx_gemm_t.precision.
  * 5.3x / 2.7x / 5.3x fewer matrix-core cycles. */

@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 14
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):

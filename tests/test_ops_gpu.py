@@ -179,6 +179,26 @@ def test_flash_attn(dev, Tq, Tk, causal):
     _close(out, ref.transpose(1, 2), 2e-5, "flash_attn")
 
 
+def test_flash_attn_keys_from_the_kv_cache(dev):
+    """cbx_flash_attn_kv_f32 (ABI v15): K / V with their own head strides -- views of a [row][head][max_ctx][64] cache -- and causal attention with fewer queries than
+    keys (the queries are the LAST Tq positions: the prefill of T3's text positions behind a cached conditioning prefix).  Bit-identical to the same attention over the
+    token-major copy of the keys (cbx_flash_attn_f32) restricted to those queries, and close to torch's SDPA."""
+    from chatterbox_amd import ops
+    Z, H, Tk, Tq, ctx = 3, 4, 103, 69, 128
+    qkv = _r((Z, Tk, 3, H, 64), 1)
+    d = qkv.to(dev)
+    kc, vc = torch.zeros(Z, H, ctx, 64, device=dev), torch.zeros(Z, H, ctx, 64, device=dev)
+    kc[:, :, :Tk], vc[:, :, :Tk] = d[:, :, 1].transpose(1, 2), d[:, :, 2].transpose(1, 2)
+    full = torch.empty(Z, Tk, H, 64, device=dev)
+    ops.flash_attn(d[:, :, 0], d[:, :, 1], d[:, :, 2], full, 0.125, causal=True)
+    out = torch.empty(Z, Tq, H, 64, device=dev)
+    ops.flash_attn(d[:, Tk - Tq:, 0], kc[:, :, :Tk].permute(0, 2, 1, 3), vc[:, :, :Tk].permute(0, 2, 1, 3), out, 0.125, causal=True)
+    assert torch.equal(out, full[:, Tk - Tq:]), "queries behind a prefix, keys from the cache == the same rows of the full causal attention"
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    _close(out, ref.transpose(1, 2)[:, Tk - Tq:], 2e-5, "flash_attn over the KV cache")
+
+
 # ---- split-bf16 modes (cbx_gemm_t.precision 3 / 6, cbx_flash_attn_split_f32): fp32 operands rebuilt from bf16 planes on
 # the 16x faster bf16 matrix cores.  Stated tolerances: precision 6 = the fp32 tolerances above; precision 3 = 1e-4.
 _SPLIT_TOL = {6: 3e-5, 16: 3e-5, 3: 1e-4}  # 16 = f16x3 (two fp16 planes, second one scaled): fp32-level like 6

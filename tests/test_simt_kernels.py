@@ -45,7 +45,7 @@ _OPS = [
     ("test_conv_transpose", (32, 16, 11, 5, 3)),
     ("test_bmm", ()),
     ("test_layernorm_rmsnorm", ()),
-    ("test_flash_attn", (103, 103, True)), ("test_flash_attn", (130, 130, False)),
+    ("test_flash_attn", (103, 103, True)), ("test_flash_attn", (130, 130, False)), ("test_flash_attn_keys_from_the_kv_cache", ()),
     ("test_split_flash_attn", (130, 130, False, 3)), ("test_split_flash_attn", (103, 103, True, 6)), ("test_split_flash_attn", (130, 130, False, 16)),
     ("test_decode_attn", ()),
     ("test_softmax_relpos", ()),

@@ -442,6 +442,37 @@ def test_t3_prefill_through_the_c_entry_point_equals_the_python_sequence(dev, la
         assert torch.equal(a, b), f"cbx_t3_prefill vs the Python launch sequence: {what}: {_first_diff(a, b)}"
 
 
+def test_t3_cached_voice_prefix_prefill_equals_the_full_prefill(dev, layers=2, steps=6):
+    """Round 6: after the first prefill with a voice the K / V of its 34 conditioning positions are kept; the next prefills with the same conditioning tensors run over
+    the text positions only and read the prefix keys from the KV cache (cbx_flash_attn_kv_f32).  The prompt is causal, so nothing may change: KV cache, prefill logits
+    and tokens of the second / third call (another batch shape) are bit-identical to an engine that never shares; an in-place edit of a conditioning tensor is a miss."""
+    from chatterbox_amd import synth
+    from chatterbox_amd.t3 import T3Engine
+    sd = synth.t3_state_dict(layers, 0)
+    cond = synth.t3_cond()
+    a, b = T3Engine(sd, dev), T3Engine(sd, dev)
+    b.share_prefix = False
+    for lens in ((12, 20, 7), (12, 20, 7), (31, 5)):
+        tt = [synth.text_tokens(n, seed=i + 1) for i, n in enumerate(lens)]
+        u = synth.rand((len(lens), steps), seed=3)
+        kw = dict(max_new_tokens=steps, uniforms=u, ban_eos=True, return_prefill_logits=True, **SAMP)
+        hit = a._voice_prefix(cond) is not None
+        res = []
+        for eng in (a, b):
+            toks, logits = eng.generate(cond, tt, **kw)
+            st = eng._state[next(k for k in eng._state if k[0] == len(lens))]
+            S = 34 + max(lens) + 2
+            res.append(([t.tolist() for t in toks], logits.cpu(), st["kc"][:, :, :, :S].cpu().clone(), st["vc"][:, :, :, :S].cpu().clone()))
+        assert res[0][0] == res[1][0], f"tokens, lens {lens} (prefix cached: {hit})"
+        for x, y, what in zip(res[0][1:], res[1][1:], ("prefill logits", "k cache", "v cache")):
+            assert torch.equal(x, y), f"text-only prefill behind the cached prefix vs the full prefill: {what}, lens {lens}: {_first_diff(x, y)}"
+    assert len(a._prefix_cache) == 1 and not b._prefix_cache and a._voice_prefix(cond) is not None
+    assert a._voice_prefix(dict(cond)) is not None, "a new dict over the same tensors is the same voice"
+    cond["speaker_emb"].mul_(1.0)  # in-place write: the version counter moves
+    assert a._voice_prefix(cond) is None, "an edited conditioning tensor must not hit"
+    assert a._voice_prefix(synth.t3_cond()) is None, "equal content in other tensors is a miss (identity, not a device-side compare: no sync in generate())"
+
+
 def test_two_engines_with_different_geometries_in_one_process(dev):
     """ABI v10: the decode geometry travels per call (cbx_decode_attn_t, cbx_gemv_t.flags, cbx_t3_step_t.da_* / gemv_flags) -- nothing is
     process-wide.  Two T3Engines with different geometries, their decode graphs captured one after the other and replayed INTERLEAVED, each

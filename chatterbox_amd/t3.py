@@ -453,17 +453,28 @@ class T3Engine:
     # themselves, so their K / V at every layer depend on the voice alone -- not on the text, the row (the CFG copy keeps cond_emb, t3.py:102-130) or the batch.
     # After the first (full) prefill with a voice they are copied out of KV-cache row 0; later prefills with the SAME conditioning tensors run over the text
     # positions only (a third fewer rows in every prefill GEMM at 64 text tokens) and read the prefix keys from the cache (cbx_flash_attn_kv_f32).  The entry keeps
-    # the conditioning tensors alive and is matched by identity + version counter: a hit means the very tensors the prefix was computed from, unmodified.
+    # the conditioning tensors alive and is matched by identity + version counter (+ content for host tensors; a device tensor made under inference_mode has no
+    # counter: identity alone): a hit means the very tensors the prefix was computed from.
     _PREFIX_KEEP = 4
+
+    @staticmethod
+    def _tver(t):
+        try:
+            return t._version
+        except RuntimeError:  # "Inference tensors do not track version counter"
+            return -1
 
     def _voice_prefix(self, conds):
         if not (self.share_prefix and isinstance(conds, dict)):
             return None
         for ent in self._prefix_cache:
             ok = ent["keys"] == sorted(conds)
-            for k, v, ver in ent["items"] if ok else ():
+            for k, v, ver, snap in ent["items"] if ok else ():
                 c = conds[k]
-                ok = (c is v and c._version == ver) if torch.is_tensor(v) else (not torch.is_tensor(c) and c == v)
+                if not torch.is_tensor(v):
+                    ok = not torch.is_tensor(c) and c == v
+                else:  # the very tensor, unmodified: version counter where the tensor has one (inference tensors do not), content for host tensors (a few KB)
+                    ok = c is v and self._tver(c) == ver and (snap is None or torch.equal(c, snap))
                 if not ok:
                     break
             if ok:
@@ -474,7 +485,8 @@ class T3Engine:
         """After a full prefill: K / V of positions 0 .. 33 of cache row 0 (L, H, 34, 64)."""
         if not (self.share_prefix and isinstance(conds, dict)) or self._voice_prefix(conds) is not None:
             return
-        items = [(k, v, v._version if torch.is_tensor(v) else None) for k, v in sorted(conds.items())]
+        items = [(k, v, self._tver(v) if torch.is_tensor(v) else None, v.clone() if torch.is_tensor(v) and v.device.type == "cpu" else None)
+                 for k, v in sorted(conds.items())]
         ent = dict(keys=sorted(conds), items=items, k=st["kc"][:, 0, :, :34].clone(), v=st["vc"][:, 0, :, :34].clone(), ev=None)
         if self.dev.type == "cuda":
             ent["ev"] = torch.cuda.Event()

@@ -471,6 +471,12 @@ def test_t3_cached_voice_prefix_prefill_equals_the_full_prefill(dev, layers=2, s
     cond["speaker_emb"].mul_(1.0)  # in-place write: the version counter moves
     assert a._voice_prefix(cond) is None, "an edited conditioning tensor must not hit"
     assert a._voice_prefix(synth.t3_cond()) is None, "equal content in other tensors is a miss (identity, not a device-side compare: no sync in generate())"
+    with torch.inference_mode():  # conditioning tensors made under inference_mode (the API layer) carry no version counter: identity + host content
+        ci = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in synth.t3_cond().items()}
+    t1 = a.generate(ci, tt, **kw)[0]
+    assert a._voice_prefix(ci) is not None
+    t2 = a.generate(ci, tt, **kw)[0]
+    assert [t.tolist() for t in t1] == [t.tolist() for t in t2]
 
 
 def test_two_engines_with_different_geometries_in_one_process(dev):

@@ -51,7 +51,62 @@ class _LoopHandle:
             pass
 
 
-class T3Engine:
+class VoicePrefixCache:
+    """K / V of a voice's conditioning positions at every layer, kept after the first prefill with that voice (round 6; T3Engine: 34 positions, the GPT-2 backbones:
+    1 + the prompt tokens).  The prompt of T3.inference / inference_turbo is [conditioning | text | BOS] under a causal mask (t3.py:303-335, 407-423): the conditioning
+    positions see only themselves, so their K / V depend on the voice alone.  An entry keeps the conditioning tensors alive and is matched by identity + version
+    counter (+ content for host tensors; a device tensor made under inference_mode has no counter: identity alone): a hit means the very tensors the prefix was
+    computed from.  No device-side compare: generate() must not synchronise (the throughput schedule enqueues ahead)."""
+    _PREFIX_KEEP = 4
+
+    @staticmethod
+    def _tver(t):
+        try:
+            return t._version
+        except RuntimeError:  # "Inference tensors do not track version counter"
+            return -1
+
+    def _voice_prefix(self, conds):
+        if not (self.share_prefix and isinstance(conds, dict)):
+            return None
+        for ent in self._prefix_cache:
+            ok = ent["keys"] == sorted(conds)
+            for k, v, ver, snap in ent["items"] if ok else ():
+                c = conds[k]
+                if not torch.is_tensor(v):
+                    ok = not torch.is_tensor(c) and c == v
+                else:  # the very tensor, unmodified: version counter where the tensor has one (inference tensors do not), content for host tensors (a few KB)
+                    ok = c is v and self._tver(c) == ver and (snap is None or torch.equal(c, snap))
+                if not ok:
+                    break
+            if ok:
+                return ent
+        return None
+
+    def _keep_voice_prefix(self, conds, st, P=34):
+        """After a full prefill: K / V of positions 0 .. P - 1 of cache row 0 (L, H, P, 64)."""
+        if not (self.share_prefix and isinstance(conds, dict)) or self._voice_prefix(conds) is not None:
+            return
+        items = [(k, v, self._tver(v) if torch.is_tensor(v) else None, v.clone() if torch.is_tensor(v) and v.device.type == "cpu" else None)
+                 for k, v in sorted(conds.items())]
+        ent = dict(keys=sorted(conds), items=items, P=P, k=st["kc"][:, 0, :, :P].clone(), v=st["vc"][:, 0, :, :P].clone(), ev=None)
+        if self.dev.type == "cuda":
+            ent["ev"] = torch.cuda.Event()
+            ent["ev"].record()
+        self._prefix_cache.insert(0, ent)
+        del self._prefix_cache[self._PREFIX_KEEP:]
+
+    def _paste_voice_prefix(self, pre, st, rows):
+        """The cached prefix into rows 0 .. rows - 1 of the KV cache (the entry may have been written on another stream: two decode chains of the throughput schedule)."""
+        if pre["ev"] is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pre["ev"])
+            pre["k"].record_stream(cur), pre["v"].record_stream(cur)
+        st["kc"][:, :rows, :, :pre["P"]].copy_(pre["k"][:, None])
+        st["vc"][:, :rows, :, :pre["P"]].copy_(pre["v"][:, None])
+
+
+class T3Engine(VoicePrefixCache):
     D, H, HD, F = 1024, 16, 64, 4096
     MAX_BATCH = 32  # utterances per device batch: 2 CFG rows each, decode GEMV serves M <= 64 rows
     # decode launch geometry: waves per 16-column tile (nw) / cross-workgroup K splits; *2 = the packed-operand (v2) path
@@ -448,52 +503,9 @@ class T3Engine:
         ops.axpby(self.emo_w.view(1, -1), out[33:34], a=emo, b=0.0)
         return out
 
-    # ------------------------------------------------------------------ the conditioning prefix of a voice (round 6)
-    # The prompt of T3.inference is [34 conditioning positions | text | BOS BOS] under a causal mask (t3.py:303-335): the conditioning positions see only
-    # themselves, so their K / V at every layer depend on the voice alone -- not on the text, the row (the CFG copy keeps cond_emb, t3.py:102-130) or the batch.
-    # After the first (full) prefill with a voice they are copied out of KV-cache row 0; later prefills with the SAME conditioning tensors run over the text
-    # positions only (a third fewer rows in every prefill GEMM at 64 text tokens) and read the prefix keys from the cache (cbx_flash_attn_kv_f32).  The entry keeps
-    # the conditioning tensors alive and is matched by identity + version counter (+ content for host tensors; a device tensor made under inference_mode has no
-    # counter: identity alone): a hit means the very tensors the prefix was computed from.
-    _PREFIX_KEEP = 4
-
-    @staticmethod
-    def _tver(t):
-        try:
-            return t._version
-        except RuntimeError:  # "Inference tensors do not track version counter"
-            return -1
-
-    def _voice_prefix(self, conds):
-        if not (self.share_prefix and isinstance(conds, dict)):
-            return None
-        for ent in self._prefix_cache:
-            ok = ent["keys"] == sorted(conds)
-            for k, v, ver, snap in ent["items"] if ok else ():
-                c = conds[k]
-                if not torch.is_tensor(v):
-                    ok = not torch.is_tensor(c) and c == v
-                else:  # the very tensor, unmodified: version counter where the tensor has one (inference tensors do not), content for host tensors (a few KB)
-                    ok = c is v and self._tver(c) == ver and (snap is None or torch.equal(c, snap))
-                if not ok:
-                    break
-            if ok:
-                return ent
-        return None
-
-    def _keep_voice_prefix(self, conds, st):
-        """After a full prefill: K / V of positions 0 .. 33 of cache row 0 (L, H, 34, 64)."""
-        if not (self.share_prefix and isinstance(conds, dict)) or self._voice_prefix(conds) is not None:
-            return
-        items = [(k, v, self._tver(v) if torch.is_tensor(v) else None, v.clone() if torch.is_tensor(v) and v.device.type == "cpu" else None)
-                 for k, v in sorted(conds.items())]
-        ent = dict(keys=sorted(conds), items=items, k=st["kc"][:, 0, :, :34].clone(), v=st["vc"][:, 0, :, :34].clone(), ev=None)
-        if self.dev.type == "cuda":
-            ent["ev"] = torch.cuda.Event()
-            ent["ev"].record()
-        self._prefix_cache.insert(0, ent)
-        del self._prefix_cache[self._PREFIX_KEEP:]
-
+    # ------------------------------------------------------------------ the conditioning prefix of a voice (round 6: VoicePrefixCache)
+    # Later prefills with the SAME conditioning tensors run over the text positions only (a third fewer rows in every prefill GEMM at 64 text tokens) and read the
+    # prefix keys from the cache (cbx_flash_attn_kv_f32).
     def _layer_prefill_text(self, lw, x, ws, St, S, rows, kc, vc, pos, crow):
         """_layer_prefill over the text positions alone: queries from the q | k | v workspace, keys / values [cached prefix | text] from the KV cache."""
         ops.layernorm(x, lw["ln1"], None, ws["h"], 1e-5, rms=True)
@@ -841,12 +853,7 @@ class T3Engine:
         # on the bf16x6 split kernels (24 significand bits, fp32 range, accumulation error below the exact MFMA's own: DESIGN.md section 1)
         # instead of the exact fp32 MFMA; gate|up (SwiGLU epilogue) and every decode step stay exact
         if pre is not None:
-            if pre["ev"] is not None:  # the entry may have been written on another stream (two decode chains of the throughput schedule)
-                cur = torch.cuda.current_stream()
-                cur.wait_event(pre["ev"])
-                pre["k"].record_stream(cur), pre["v"].record_stream(cur)
-            st["kc"][:, :rows, :, :34].copy_(pre["k"][:, None])
-            st["vc"][:, :rows, :, :34].copy_(pre["v"][:, None])
+            self._paste_voice_prefix(pre, st, rows)
             with ops.gemm_precision(prec):
                 for i, lw in enumerate(self.layers):
                     self._layer_prefill_text(lw, xf, pws, Sx, S, rows, st["kc"][i], st["vc"][i], pos, crow)

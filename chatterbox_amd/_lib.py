@@ -16,7 +16,7 @@ c_f = ctypes.c_void_p
 c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 
-ABI_VERSION = 15  # include/cbx.h CBX_ABI_VERSION
+ABI_VERSION = 16  # include/cbx.h CBX_ABI_VERSION
 
 
 class GemmParams(ctypes.Structure):
@@ -120,6 +120,16 @@ class T3Prefill(ctypes.Structure):  # cbx_t3_prefill_t
                 ("eps", c_float), ("attn_scale", c_float), ("layers", ctypes.POINTER(T3Layer)), ("x", c_f), ("h", c_f), ("qkv", c_f), ("att", c_f), ("g", c_f),
                 ("positions", c_f), ("cache_rows", c_f), ("cos_t", c_f), ("sin_t", c_f), ("kc", c_f), ("vc", c_f),
                 ("kv_layer_stride", c_long), ("kv_row_stride", c_long), ("kv_head_stride", c_long)]
+
+
+class Gpt2Layer(ctypes.Structure):  # cbx_gpt2_layer_t (ABI v16)
+    _fields_ = [(k, c_f) for k in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "wfc", "bfc", "wpr", "bpr")]
+
+
+class Gpt2Prefill(ctypes.Structure):  # cbx_gpt2_prefill_t (ABI v16)
+    _fields_ = [("n_layers", c_int), ("rows", c_int), ("S", c_int), ("prefix", c_int), ("dim", c_int), ("n_heads", c_int), ("eps", c_float), ("attn_scale", c_float),
+                ("layers", ctypes.POINTER(Gpt2Layer)), ("x", c_f), ("h", c_f), ("qkv", c_f), ("att", c_f), ("g", c_f), ("positions", c_f), ("cache_rows", c_f),
+                ("kc", c_f), ("vc", c_f), ("kv_layer_stride", c_long), ("kv_row_stride", c_long), ("kv_head_stride", c_long)]
 
 
 class PlanesRef(ctypes.Structure):  # cbx_planes_t (ABI v12)
@@ -231,6 +241,7 @@ _SIGS = {
     "cbx_fsq_index": ([c_f, c_f, c_long, c_long, c_f], c_int),
     "cbx_t3_decode_step": ([ctypes.POINTER(T3Step), c_f], c_int),
     "cbx_t3_prefill": ([ctypes.POINTER(T3Prefill), c_f], c_int),
+    "cbx_gpt2_prefill": ([ctypes.POINTER(Gpt2Prefill), c_f], c_int),
     "cbx_t3_loop_create": ([ctypes.POINTER(T3Step), c_f, ctypes.POINTER(c_f)], c_int),
     "cbx_t3_loop_run": ([c_f, c_int, c_int, c_f, ctypes.POINTER(c_int)], c_int),
     "cbx_t3_loop_destroy": ([c_f], c_int),

@@ -383,6 +383,11 @@ extern "C" int cbx_gemm_f32(const cbx_gemm_t* pp, void* stream) {
     // measured on the CFM / HiFT shapes (bench.py, MI355X): 64x64 tiles 492 ms per flow pass, 128x64 543, 64x128 536, 128x128 803 -- the
     // single-stage pipeline needs many co-resident waves to hide its load->LDS->barrier latency; 8 waves x (32x32): 81 TF/s on the bench mix
     // vs 77 for 64x64 (4 waves).  (Rounds 1-2 A/B'd six more tile forms through an environment knob; the losers are gone with it.)
+    // a handful of workgroups walking a long K (the prefill of the GPT-2 backbones at batch 1: 65 - 441 rows, N = 1024, K = 4096: 16 - 64 workgroups x 256 K tiles of 16)
+    // is bound by the latency of a K step, not by the matrix rate: 64-wide K tiles take a quarter of the steps.  Same k order per output element: bit-identical
+    // (round 6, profiles/r06_at_*.log)
+    const long wgs = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.nz1 * p.nz2;
+    if (wgs <= 128 && p.K >= 1024 && fast_loader_ok(p, 64)) return launch<128, 64, 4, 2, false, 64, 1>(p, st);
     if (fast_loader_ok(p, 16)) return launch<128, 64, 4, 2, false, 16, 1>(p, st);
     return launch<128, 64, 4, 2, false>(p, st);
 }

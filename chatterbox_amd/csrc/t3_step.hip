@@ -129,6 +129,48 @@ extern "C" int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream) {
     return 0;
 }
 
+// ---- The prefill of T3.inference_turbo (t3.py:392-468 -> HF GPT2Model over [speaker | prompt tokens | text | start-speech]) as ONE call (ABI v16): the launches
+// T3TurboEngine.generate issues per layer -- ln_1, c_attn (+ bias), K / V append, causal attention, attention c_proj (+ bias + residual), ln_2, c_fc (+ bias +
+// gelu_new), mlp c_proj (+ bias + residual) -- with the same arguments (bit-identical results).  At batch 1 the prompt's 441 rows keep the chip busy for ~0.1 ms
+// per layer while nine Python-issued launches cost ~0.4 ms of host time: the prefill was host-bound (profiles/r06_ao_*.log).  prefix > 0: the first `prefix`
+// positions of every row are already in the KV cache (VoicePrefixCache: speaker + prompt tokens of a voice, computed once); x holds the remaining S positions of
+// every row and the attention reads keys / values [prefix | S] from the cache (cbx_flash_attn_kv_f32).
+extern "C" int cbx_gpt2_prefill(const cbx_gpt2_prefill_t* d, void* stream) {
+    CBX_REQUIRE(d && d->layers && d->n_layers > 0 && d->x && d->h && d->qkv && d->att && d->g && d->positions && d->cache_rows && d->kc && d->vc,
+                "gpt2_prefill: null descriptor field");
+    CBX_REQUIRE(d->rows >= 1 && d->S >= 1 && d->prefix >= 0 && d->dim == d->n_heads * 64, "gpt2_prefill: bad shape (head_dim 64)");
+    const int D = d->dim, F = 4 * d->dim, H = d->n_heads;
+    const long M = (long)d->rows * d->S;
+    auto linear = [&](const float* A, const float* W, const float* bias, float* C, const float* R, int N, int K, int act) {
+        cbx_gemm_t g{};
+        g.A = A, g.W = W, g.C = C, g.R = R, g.bias = bias;
+        g.M = (int)M, g.N = N, g.K = K, g.Cin = K, g.taps = 1, g.dil = 1, g.stride = 1, g.up = 1, g.nz1 = 1, g.nz2 = 1, g.act1 = act;
+        g.alpha = 1.0f, g.lda = K, g.ldw = K, g.ldc = N, g.ldr = R ? D : 0, g.precision = 0;
+        return cbx_gemm_f32(&g, stream);
+    };
+    int rc = 0;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const cbx_gpt2_layer_t& L = d->layers[i];
+        float* kc = d->kc + (long)i * d->kv_layer_stride;
+        float* vc = d->vc + (long)i * d->kv_layer_stride;
+        if ((rc = cbx_layernorm_f32(d->x, d->h, L.ln1_w, L.ln1_b, nullptr, M, D, D, D, d->eps, 0, CBX_ACT_NONE, 1.0f, stream))) return rc;
+        if ((rc = linear(d->h, L.wqkv, L.bqkv, d->qkv, nullptr, 3 * D, D, CBX_ACT_NONE))) return rc;
+        if ((rc = cbx_rope_kv_f32(d->qkv, d->positions, nullptr, nullptr, kc, vc, d->cache_rows, M, H, 3 * D, d->kv_row_stride, d->kv_head_stride, stream))) return rc;
+        const long sb = (long)d->S * 3 * D, st = 3 * D;
+        if (d->prefix == 0)
+            rc = cbx_flash_attn_f32(d->qkv, d->qkv + D, d->qkv + 2 * D, d->att, nullptr, d->rows, H, d->S, d->S, sb, st, sb, st, sb, st, (long)d->S * D, D, d->attn_scale, 1, stream);
+        else
+            rc = cbx_flash_attn_kv_f32(d->qkv, kc, vc, d->att, nullptr, d->rows, H, d->S, d->prefix + d->S, sb, st, d->kv_row_stride, 64, d->kv_head_stride,
+                                       d->kv_row_stride, 64, d->kv_head_stride, (long)d->S * D, D, d->attn_scale, 1, stream);
+        if (rc) return rc;
+        if ((rc = linear(d->att, L.wo, L.bo, d->x, d->x, D, D, CBX_ACT_NONE))) return rc;
+        if ((rc = cbx_layernorm_f32(d->x, d->h, L.ln2_w, L.ln2_b, nullptr, M, D, D, D, d->eps, 0, CBX_ACT_NONE, 1.0f, stream))) return rc;
+        if ((rc = linear(d->h, L.wfc, L.bfc, d->g, nullptr, F, D, CBX_ACT_GELU_TANH))) return rc;
+        if ((rc = linear(d->g, L.wpr, L.bpr, d->x, d->x, D, F, CBX_ACT_NONE))) return rc;
+    }
+    return 0;
+}
+
 // ---- The token loop in C (include/cbx.h "handle-level entry points").  The graph is what chatterbox_amd/t3.py captures through torch.cuda.graph: one
 // cbx_t3_decode_step.  On the SIMT emulator (tests/simt: no graph API) the steps are issued one by one.
 #include <vector>

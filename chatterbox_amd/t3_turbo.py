@@ -10,11 +10,12 @@ import os
 import torch
 
 from . import ops
+from .t3 import VoicePrefixCache
 
 START_SPEECH, STOP_SPEECH = 6561, 6562
 
 
-class T3TurboEngine:
+class T3TurboEngine(VoicePrefixCache):
     MAX_BATCH = 64
     @ops.on_device
     def __init__(self, sd, device="cuda", n_layers=None):
@@ -83,6 +84,8 @@ class T3TurboEngine:
         self.ks_o = 4 if self.D % 512 == 0 else 2
         self.ks_p = 8
         self._state = {}
+        self.share_prefix, self._prefix_cache = os.environ.get("CBX_T3_SHARE_PREFIX", "1") == "1", []  # VoicePrefixCache: speaker + prompt tokens of a voice prefilled once
+        self.c_prefill = os.environ.get("CBX_T3_CSTEP", "1") == "1"  # the prefill through cbx_gpt2_prefill (one ctypes call instead of nine launches per layer)
         self.time_decode, self.decode_events = False, []  # (start, end, steps, prefill lengths, rows) per generate() when enabled (bench.py)
 
     def _forward_decode(self, st):
@@ -213,6 +216,22 @@ class T3TurboEngine:
         self._state[key] = st
         return st
 
+    def _prefill_c(self, xf, h, qkv, att, g, pos, crow, st, B, S, prefix):
+        """The prefill through cbx_gpt2_prefill (include/cbx.h, ABI v16): the nine launches per layer of generate()'s Python sequence, issued in C."""
+        import ctypes
+        from ._lib import Gpt2Layer, Gpt2Prefill, check, lib
+        p = lambda t: t.data_ptr()
+        arr = (Gpt2Layer * self.L)()  # built per call: a cached array would outlive a re-loaded weight tensor
+        for i, lw in enumerate(self.layers):
+            a = arr[i]
+            a.ln1_w, a.ln1_b, a.ln2_w, a.ln2_b = p(lw["ln1"][0]), p(lw["ln1"][1]), p(lw["ln2"][0]), p(lw["ln2"][1])
+            a.wqkv, a.bqkv, a.wo, a.bo, a.wfc, a.bfc, a.wpr, a.bpr = (p(lw[k]) for k in ("wqkv", "bqkv", "wo", "bo", "wfc", "bfc", "wpr", "bpr"))
+        d = Gpt2Prefill()
+        d.n_layers, d.rows, d.S, d.prefix, d.dim, d.n_heads, d.eps, d.attn_scale, d.layers = self.L, B, S, prefix, self.D, self.H, 1e-5, 0.125, arr
+        d.x, d.h, d.qkv, d.att, d.g, d.positions, d.cache_rows, d.kc, d.vc = p(xf), p(h), p(qkv), p(att), p(g), p(pos), p(crow), p(st["kc"]), p(st["vc"])
+        d.kv_layer_stride, d.kv_row_stride, d.kv_head_stride = st["kc"].stride(0), st["kc"].stride(1), st["kc"].stride(2)
+        check(lib.cbx_gpt2_prefill(ctypes.byref(d), ops._stream()), "cbx_gpt2_prefill")
+
     @ops.on_device
     @torch.inference_mode()
     def generate(self, conds, text_tokens, max_gen_len=1000, temperature=0.8, top_k=1000, top_p=0.95, repetition_penalty=1.2,
@@ -220,6 +239,7 @@ class T3TurboEngine:
         """conds: one cond dict (speaker_emb (1,256), cond_prompt_speech_tokens (1,375)) or a list of B; text_tokens: list of B
         1-D LongTensors (GPT-2 BPE ids, no SOT/EOT).  Returns a list of B 1-D LongTensors without the trailing EOS."""
         dev, B, D = self.dev, len(text_tokens), self.D
+        voice = conds if isinstance(conds, dict) else None  # one voice for the whole batch: its conditioning prefix may be cached
         conds = [conds] * B if isinstance(conds, dict) else conds
         assert B >= 1, "empty batch"
         if uniforms is not None:
@@ -258,32 +278,52 @@ class T3TurboEngine:
             st["uniforms"].copy_(torch.as_tensor(uniforms, dtype=torch.float32).view(B, -1)[:, :n_samples])
 
         # ---- prefill: [speaker | prompt-token embeddings | text | start-speech] + wpe (prepare_input_embeds, t3.py:102-130,407-423)
-        x = torch.zeros(B, S, D, device=dev)
+        # The 1 + n_prompt conditioning positions see only themselves (causal) and carry absolute positions: with their K / V cached (VoicePrefixCache) only the
+        # text positions and the start token are computed -- 65 of 441 positions at 64 text tokens -- against keys read from the KV cache.
+        exact = ops._prec() not in (3, 6, 16)
+        pre = self._voice_prefix(voice) if voice is not None and exact else None
+        if pre is not None and pre["P"] != 1 + n_prompt[0]:
+            pre = None
+        P0 = pre["P"] if pre is not None else 0
+        Sx = S - P0
+        x = torch.zeros(B, Sx, D, device=dev)
         for b in range(B):
             pos = torch.arange(s0[b], dtype=torch.int32, device=dev)
-            ops.linear(conds[b]["speaker_emb"].to(dev).float().view(1, 256), self.spkr_w, x[b, 0:1], bias=self.spkr_b)
-            ops.axpby(self.wpe[0:1], x[b, 0:1], 1.0, 1.0)
-            a, e = 1, 1 + n_prompt[b]
-            ops.embed(conds[b]["cond_prompt_speech_tokens"].to(dev).long().view(-1), self.speech_emb, x[b, a:e], table2=self.wpe, ids2=pos[a:e])
-            a, e = e, e + tl[b]
-            ops.embed(text_tokens[b].to(dev).long().view(-1), self.text_emb, x[b, a:e], table2=self.wpe, ids2=pos[a:e])
-            ops.embed(torch.full((1,), START_SPEECH, dtype=torch.int64, device=dev), self.speech_emb, x[b, e:e + 1], table2=self.wpe, ids2=pos[e:e + 1])
-        M = B * S
+            if pre is None:
+                ops.linear(conds[b]["speaker_emb"].to(dev).float().view(1, 256), self.spkr_w, x[b, 0:1], bias=self.spkr_b)
+                ops.axpby(self.wpe[0:1], x[b, 0:1], 1.0, 1.0)
+                a, e = 1, 1 + n_prompt[b]
+                ops.embed(conds[b]["cond_prompt_speech_tokens"].to(dev).long().view(-1), self.speech_emb, x[b, a:e], table2=self.wpe, ids2=pos[a:e])
+            a, e = 1 + n_prompt[b], 1 + n_prompt[b] + tl[b]
+            ops.embed(text_tokens[b].to(dev).long().view(-1), self.text_emb, x[b, a - P0:e - P0], table2=self.wpe, ids2=pos[a:e])
+            ops.embed(torch.full((1,), START_SPEECH, dtype=torch.int64, device=dev), self.speech_emb, x[b, e - P0:e - P0 + 1], table2=self.wpe, ids2=pos[e:e + 1])
+        M = B * Sx
         xf = x.view(M, D)
         h, qkv, att, g = (torch.empty(M, n, device=dev) for n in (D, 3 * D, D, 4 * D))
-        posr = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
-        crow = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(S)
-        for i, lw in enumerate(self.layers):
-            ops.layernorm(xf, lw["ln1"][0], lw["ln1"][1], h, 1e-5)
-            ops.linear(h, lw["wqkv"], qkv, bias=lw["bqkv"])
-            ops.rope_kv(qkv, posr, None, None, st["kc"][i], st["vc"][i], self.H, cache_rows=crow)
-            q4 = qkv.view(B, S, 3, self.H, 64)
-            ops.flash_attn(q4[:, :, 0], q4[:, :, 1], q4[:, :, 2], att.view(B, S, self.H, 64), 0.125, causal=True)
-            ops.linear(att, lw["wo"], xf, bias=lw["bo"], residual=xf)
-            ops.layernorm(xf, lw["ln2"][0], lw["ln2"][1], h, 1e-5)
-            ops.linear(h, lw["wfc"], g, bias=lw["bfc"], act=ops.GELU_TANH)
-            ops.linear(g, lw["wpr"], xf, bias=lw["bpr"], residual=xf)
-        last = torch.tensor([b * S + s0[b] - 1 for b in range(B)], device=dev)
+        posr = torch.arange(P0, S, dtype=torch.int32, device=dev).repeat(B)
+        crow = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(Sx)
+        if pre is not None:
+            self._paste_voice_prefix(pre, st, B)
+        if self.c_prefill and exact and not ops.TIMER:
+            self._prefill_c(xf, h, qkv, att, g, posr, crow, st, B, Sx, P0)
+        else:
+            for i, lw in enumerate(self.layers):
+                ops.layernorm(xf, lw["ln1"][0], lw["ln1"][1], h, 1e-5)
+                ops.linear(h, lw["wqkv"], qkv, bias=lw["bqkv"])
+                ops.rope_kv(qkv, posr, None, None, st["kc"][i], st["vc"][i], self.H, cache_rows=crow)
+                q4 = qkv.view(B, Sx, 3, self.H, 64)
+                if pre is None:
+                    ops.flash_attn(q4[:, :, 0], q4[:, :, 1], q4[:, :, 2], att.view(B, Sx, self.H, 64), 0.125, causal=True)
+                else:  # keys / values [cached prefix | text] where the cache keeps them (cbx_flash_attn_kv_f32)
+                    ops.flash_attn(q4[:, :, 0], st["kc"][i][:B, :, :S].permute(0, 2, 1, 3), st["vc"][i][:B, :, :S].permute(0, 2, 1, 3),
+                                   att.view(B, Sx, self.H, 64), 0.125, causal=True)
+                ops.linear(att, lw["wo"], xf, bias=lw["bo"], residual=xf)
+                ops.layernorm(xf, lw["ln2"][0], lw["ln2"][1], h, 1e-5)
+                ops.linear(h, lw["wfc"], g, bias=lw["bfc"], act=ops.GELU_TANH)
+                ops.linear(g, lw["wpr"], xf, bias=lw["bpr"], residual=xf)
+        if pre is None and voice is not None and exact:
+            self._keep_voice_prefix(voice, st, P=1 + n_prompt[0])
+        last = torch.tensor([b * Sx + s0[b] - P0 - 1 for b in range(B)], device=dev)
         hl = xf.index_select(0, last).contiguous()
         ops.layernorm(hl, self.lnf[0], self.lnf[1], st["dws"]["h"], 1e-5)
         ops.linear(st["dws"]["h"], self.head, st["logits"], bias=self.head_b)

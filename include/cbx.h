@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CBX_ABI_VERSION 15 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
+#define CBX_ABI_VERSION 16 /* 2: cbx_gemm_t.precision, cbx_flash_attn_split_f32; 4: packed decode GEMV operands, RMSNorm / residual folded into cbx_gemv_f32;
                               5: precision 16 (f16x3) + cbx_set_range_flag; 6: LayerNorm folded into the GEMM A operand (ln_stats / ln_w / ln_b, cbx_row_stats_f32);
                               7: plane-format operands (cbx_gemm_planes, cbx_split_planes_f32, cbx_layernorm_planes_f32, cbx_flash_attn_split_po),
                                  per-device range flag, cbx_gemm_ln_fusable; 8: cbx_gemm_pl_t.PT (transposed column range), cbx_set_decode_attn_workspace;
@@ -31,7 +31,8 @@ extern "C" {
                                   attn_version: no process-wide state on the flow path either) incl. the CO-RESIDENT forms of the throughput schedule
                                   (one workgroup per CU that leaves half of the register file and 64 KiB of LDS to another stream), CBX_GEMV_SHALLOW;
                               14: the batch-1 decode path of the GPT-2 backbones (Turbo / Nano): cbx_gemv_row_f32, cbx_decode_attn_parts; the token loop in C: cbx_t3_loop_*;
-                              15: cbx_flash_attn_kv_f32 (K / V head strides: attention over the KV cache in the prefill) */
+                              15: cbx_flash_attn_kv_f32 (K / V head strides: attention over the KV cache in the prefill);
+                              16: cbx_gpt2_prefill (the prefill of the GPT-2 backbones as one call, optionally behind a cached conditioning prefix) */
 #define CBX_EINVAL (-22)
 
 /* activations usable in GEMM / elementwise epilogues */
@@ -539,6 +540,29 @@ typedef struct cbx_t3_prefill_t {
     long kv_layer_stride, kv_row_stride, kv_head_stride;  /* floats */
 } cbx_t3_prefill_t;
 int cbx_t3_prefill(const cbx_t3_prefill_t* d, void* stream);
+
+/* ---- ABI v16: the PREFILL of T3.inference_turbo for every row (t3.py:392-468 -> HF GPT2Model over [speaker | prompt tokens | text | start-speech], absolute
+ * position embeddings already added to x; KV cache filled) ----
+ * x (rows * S, dim) in / out as cbx_t3_prefill_t; per layer ln_1 -> c_attn (+ bias) -> K / V append at positions[] of cache row cache_rows[] -> causal attention ->
+ * attention c_proj (+ bias + residual) -> ln_2 -> c_fc (+ bias + gelu_new) -> mlp c_proj (+ bias + residual); weights ROW-MAJOR (N, K) (the checkpoint's Conv1D
+ * weights transposed), ffn = 4 * dim.  prefix > 0: the first `prefix` positions of every row are ALREADY in the KV cache (the speaker + prompt-token positions of a
+ * voice see only themselves under the causal mask and carry absolute positions: computed once per voice); x then holds the remaining S positions of every row,
+ * positions[] start at `prefix`, and the attention reads keys / values [prefix | S] from the cache (cbx_flash_attn_kv_f32).  Sequences kernel-level entry points
+ * only (exact fp32): no allocation, no synchronisation; results bit-identical to issuing the same launches one by one. */
+typedef struct cbx_gpt2_layer_t {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *wqkv, *bqkv, *wo, *bo, *wfc, *bfc, *wpr, *bpr;
+} cbx_gpt2_layer_t;
+typedef struct cbx_gpt2_prefill_t {
+    int n_layers, rows, S, prefix, dim, n_heads;
+    float eps, attn_scale;
+    const cbx_gpt2_layer_t* layers;       /* HOST array [n_layers] */
+    float* x;                             /* [rows * S][dim] in / out */
+    float *h, *qkv, *att, *g;             /* workspaces: [rows * S][dim], [..][3 * dim], [..][dim], [..][4 * dim] */
+    const int *positions, *cache_rows;    /* [rows * S] */
+    float *kc, *vc;                       /* KV cache [n_layers][rows][n_heads][max_ctx][64] */
+    long kv_layer_stride, kv_row_stride, kv_head_stride;  /* floats */
+} cbx_gpt2_prefill_t;
+int cbx_gpt2_prefill(const cbx_gpt2_prefill_t* d, void* stream);
 
 /* ---- stage-level entry points of the S3Gen flow decoder and of the HiFT vocoder (ABI v12) ----
  * A plane-format operand (see PLANE-FORMAT operands above) as the stage descriptors carry it: base of the h plane with any column offset applied, row

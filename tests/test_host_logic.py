@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libcbx_hip.so does not export {n}"
     from chatterbox_amd import _lib  # binding table covers the same set
     assert names == set(_lib._SIGS), names ^ set(_lib._SIGS)
-    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 15
+    assert _lib.lib.cbx_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -36,7 +36,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     structs = {"cbx_gemm_t": _lib.GemmParams, "cbx_gemm_pl_t": _lib.GemmPlParams, "cbx_gemv_t": _lib.GemvParams, "cbx_t3_layer_t": _lib.T3Layer, "cbx_t3_step_t": _lib.T3Step,
-               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill,
+               "cbx_sampler_t": _lib.SamplerParams, "cbx_decode_attn_t": _lib.DecodeAttnParams, "cbx_t3_prefill_t": _lib.T3Prefill, "cbx_gpt2_layer_t": _lib.Gpt2Layer, "cbx_gpt2_prefill_t": _lib.Gpt2Prefill,
                "cbx_planes_t": _lib.PlanesRef, "cbx_cfm_tblock_t": _lib.CfmTBlock, "cbx_cfm_stage_t": _lib.CfmStage, "cbx_cfm_t": _lib.CfmSolve,
                "cbx_hift_resblock_t": _lib.HiftResblock, "cbx_hift_t": _lib.HiftDecode,
                "cbx_conformer_t": _lib.Conformer, "cbx_s3enc_t": _lib.S3Encode, "cbx_hift_f0_t": _lib.HiftF0,

@@ -35,6 +35,18 @@ def test_linear(dev, M, N, K):
         _close(out, fn(F.linear(x, w, b)) + r, 3e-5 * max(1.0, math.sqrt(K / 256)), f"linear act={act}")
 
 
+def test_linear_small_grid_form_is_bit_identical(dev):
+    """Round 6: a handful of workgroups walking a long K take 64-wide K tiles (cbx_gemm_f32's dispatcher, 128 workgroups or fewer, K >= 1024).  The k order per output
+    element does not change: the rows of a 65-row call are bit-identical to the same rows inside a 1200-row call (a grid that stays on the 16-wide K tiles)."""
+    from chatterbox_amd import ops
+    for N, K in ((1024, 4096), (3072, 1024)):
+        x, w, b, r = _r((1200, K), 1).to(dev), _r((N, K), 2, 1 / math.sqrt(K)).to(dev), _r((N,), 3).to(dev), _r((1200, N), 4).to(dev)
+        big, small = torch.empty(1200, N, device=dev), torch.empty(65, N, device=dev)
+        ops.linear(x, w, big, bias=b, act=ops.GELU_TANH, residual=r)
+        ops.linear(x[:65], w, small, bias=b, act=ops.GELU_TANH, residual=r[:65])
+        assert torch.equal(small, big[:65]), f"N {N} K {K}: {(small - big[:65]).abs().max().item():.3e}"
+
+
 def test_gelu_erf_accuracy(dev):
     """The branch-free erf of the GELU epilogue (cbx_common.h: cbx_gelu_erf) against fp64 on a dense grid over [-8, 8], the branch
     seam |x| / sqrt 2 = 1, the clamp at 4 and denormal-small inputs: |error| <= 1.5e-7 max(1, |gelu|), i.e. the rounding level of F.gelu in fp32."""

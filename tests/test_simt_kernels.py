@@ -37,7 +37,7 @@ CPU = torch.device("cpu")
 
 # (module, test function, arguments after `dev`)
 _OPS = [
-    ("test_linear", (1, 8, 16)), ("test_linear", (37, 80, 192)),
+    ("test_linear", (1, 8, 16)), ("test_linear", (37, 80, 192)), ("test_linear", (40, 128, 1024)),
     ("test_linear_strided_accumulate_and_second_output", ()),
     ("test_swiglu", ()),
     ("test_conv1d", (32, 48, 3, 1, 1, 1, 77)), ("test_conv1d", (64, 64, 11, 5, 1, 25, 300)),

@@ -592,8 +592,8 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
         k_new[lane] = kn;
         v_new[lane] = vn0;
         if (sp == S - 1) {  // one workgroup appends the new token to the cache
-            kb[(long)pos * 64 + lane] = kn;
-            vb[(long)pos * 64 + lane] = vn0;
+            cbx_store_out(kb + (long)pos * 64 + lane, kn);
+            cbx_store_out(vb + (long)pos * 64 + lane, vn0);
         }
     }
     __syncthreads();
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const float* __re
             const int n = head * 64 + tid;
             oi = (((long)(row >> 4) * (n_heads * 2) + (n >> 5)) * 2 + ((n >> 2) & 1)) * 256 + ((((n >> 3) & 3) << 4) + (row & 15)) * 4 + (n & 3);
         }
-        o[oi] = num / den;
+        cbx_store_out(o + oi, num / den);
     }
 #ifdef CBX_TRACE
     CBX_TRC_STAMP(3);

@@ -7,6 +7,39 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Stores of the decode step's outputs (activation images, split-K partial images, the KV append).  A dependent launch starts only after its predecessor's end-of-kernel
+// release has written the dirty lines of every XCD's L2 back; a line stored write-through has left the L2 by then (MI355X_MICROARCH.md "publish-large": 64 KB per
+// workgroup, plain stores + release 8.2 us against sc1 stores 3.0).  Same values at the same addresses: results are unchanged bit for bit.
+// CBX_WT: 1 sc1 (agent-scope write-through; the default), 0 plain stores, 2 sc0 sc1 (system scope), 3 nt -- side builds: scripts/wt_build.sh.  Measured on one box, interleaved
+// processes (profiles/r06_az_decode_store_policy_ab.log): the B = 8 token step 1.1285 ms plain, 1.1050 sc1, 1.1043 sc0 sc1, 1.1398 nt; identical logits.  The flow's kernels
+// (16 MB outputs per launch: plane GEMM epilogues, plane attention, narrow LayerNorm) LOSE 3.3 % with write-through stores (profiles/r06_ba_flow_store_policy_ab.log) and keep
+// plain stores.
+#ifndef CBX_WT
+#define CBX_WT 1
+#endif
+__device__ __forceinline__ void cbx_store_out(float* p, float v) {
+#if CBX_WT == 1
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif CBX_WT == 2
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif CBX_WT == 3
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void cbx_store_out4(float* p, f32x4 v) {
+#if CBX_WT == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");  // the nop: a VALU write of the data registers of a > 64-bit store needs wait states the compiler does not insert after inline asm
+#elif CBX_WT == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif CBX_WT == 3
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 #define CBX_F16_LO_SCALE 2048.0f  /* scale of the second fp16 plane of the f16x3 forms (gemm_split.hip) */
 int* cbx_range_flag();            /* gemm_split.hip: device word of cbx_set_range_flag, or NULL */
 #ifdef __HIPCC__

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
 #pragma unroll
                         for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
                         if (p.x_out && blockIdx.x == 0 && on[d] && xok[0])  // the reduced residual stream, same packed address as x (pad rows stay as allocated: zero)
-                            *reinterpret_cast<f32x4*>(p.x_out + (xp[0] - p.x) + (it0 + d) * 512 + h * 256) = xq;
+                            cbx_store_out4(p.x_out + (xp[0] - p.x) + (it0 + d) * 512 + h * 256, xq);
                     }
                     xq = (on[d] && xok[t]) ? xq : zero4;
                     if constexpr (RMS) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const cbx_gemv_t p) {
             if (p.act) v = cbx_act(v, p.act, 0.f, 0.f);  // only meaningful with ksplit == 1
         }
         if (p.res) v += PRE ? e_res[j] : p.res[e_o[j]];  // residual stream in the same layout as out (in place is fine: one thread per element, read before written)
-        p.out[e_o[j]] = v;
+        cbx_store_out(p.out + e_o[j], v);
     }
 #ifdef CBX_TRACE
     CBX_TRC_STAMP(5);  // epilogue stores issued
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
 #pragma unroll
                     for (int j = 0; j < NP; ++j) xq += pv[d][j][h];
                     if (p.x_out && blockIdx.x == 0 && on[d] && xok)  // the reduced residual stream (this wave's K slice), same packed address as x; pad rows stay zero
-                        *reinterpret_cast<f32x4*>(p.x_out + xo + (it0 + d) * 512 + h * 256) = xq;
+                        cbx_store_out4(p.x_out + xo + (it0 + d) * 512 + h * 256, xq);
                 }
                 xq = (on[d] && xok) ? xq : zero4;
                 ss += (xq[0] * xq[0] + xq[1] * xq[1]) + (xq[2] * xq[2] + xq[3] * xq[3]);
@@ -474,9 +474,9 @@ __global__ __launch_bounds__(512) void gemv_ct_kernel(const cbx_gemv_t p) {
         } else if (p.ksplit == 1) {
             v *= rsqrtf(sq / (float)p.K + p.eps);
         } else if (blockIdx.x == 0 && c == 0 && col == 0) {
-            p.ssq_out[ks * 16 + row] = sq;  // this K slice's sum of squares of row `row` (identical in every column group: group 0 writes it)
+            cbx_store_out(p.ssq_out + ks * 16 + row, sq);  // this K slice's sum of squares of row `row` (identical in every column group: group 0 writes it)
         }
-        p.out[(long)ks * p.part_stride + (long)row * p.ldo + n] = v;
+        cbx_store_out(p.out + (long)ks * p.part_stride + (long)row * p.ldo + n, v);
     }
 #ifdef CBX_TRACE
     CBX_TRC_STAMP(5);

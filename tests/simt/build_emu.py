@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE.  The product library is chatterbox_amd/libcbx_hip.so (hipcc
 
 The sources are used as they are, except for two mechanical rewrites done on a COPY (tests/simt/_gen/):
   * inline asm: `s_waitcnt` / `s_nop` / empty optimisation barriers are dropped; `v_max3_f32 d, |a|, |b|, d` and the
-    `v_fma_mix{lo,hi}_f16` pairs become calls of the equivalent C functions of simt_emu.h; any OTHER asm statement is an error;
+    `v_fma_mix{lo,hi}_f16` pairs become calls of the equivalent C functions of simt_emu.h; `global_store_dword{,x2,x4} … sc1` (the write-through
+    stores of cbx_common.h) become plain stores; any OTHER asm statement is an error;
   * `extern __shared__ T name[];` becomes a pointer to the launch's dynamic LDS block.
 
     python tests/simt/build_emu.py [--force]
@@ -115,6 +116,9 @@ def _rewrite_asm(body, where):
         else:
             s, t = ins[1], ins[2]
         return f"({outs[0]} = simt_fma_mix_f16({outs[0] if hi else '0u'}, {h}, {s}, {t}, {hi}))"
+    if first in ("global_store_dword", "global_store_dwordx2", "global_store_dwordx4"):  # write-through stores (cbx_common.h cbx_store_out*): plain stores here
+        assert re.match(r"global_store_dword(x2|x4)? %0, %1, off( sc0)?( sc1)?(\\n\\ts_nop \d)?\s*$", tmpl.strip()) and len(ins) == 2 and not outs, (where, tmpl)
+        return f"simt_store_wt((void*)({ins[0]}), {ins[1]})"
     raise ValueError(f"{where}: asm statement without an emulation: {tmpl!r}")
 
 

@@ -502,6 +502,9 @@ template <class G, class L> static inline void simt_global_load_lds(G src, L lds
 // ---------------------------------------------------------------------------------------------------------------- rewritten inline asm
 // (tests/simt/build_emu.py maps the sources' asm statements onto these)
 static inline float simt_max3_abs(float acc, float a, float b) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), acc); }
+// global_store_dword{,x2,x4} ... sc1: a write-through store is a store (the cache policy has no meaning here)
+template <class V>
+static inline void simt_store_wt(void* p, V v) { memcpy(p, &v, sizeof(V)); }
 // v_fma_mix{lo,hi}_f16 with an fp16 first operand (low / high half of h2), fp32 second and third operands: one rounding, to fp16
 static inline unsigned simt_fma_mix_f16(unsigned dst, unsigned h2, float s, float t, int hi) {
     _Float16 h;

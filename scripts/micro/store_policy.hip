@@ -41,8 +41,37 @@ __global__ __launch_bounds__(512) void step_kernel(const f32x4* __restrict__ w, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) a2[u] += v[u];
     }
+    for (; i < n4_per_wg; i += 512) a2[0] += __builtin_nontemporal_load(p + i);
     acc = (acc + a2[0] + a2[1] + a2[2] + a2[3]) * 1e-9f;
     const long per_wg = out4_total / gridDim.x;  // 16-byte pieces per workgroup (>= 1)
+    float* o = out + (long)blockIdx.x * per_wg * 4;
+    for (long j = threadIdx.x; j < per_wg; j += 512) store16<POLICY>(o + j * 4, acc);
+}
+
+// The hand-off as a tuned kernel would do it: the whole 64 KB image (8 loads of 16 bytes per thread) is REQUESTED before the weight stream and consumed after it.
+template <int POLICY, int NX>
+__global__ __launch_bounds__(512) void hidden_kernel(const f32x4* __restrict__ w, long n4_per_wg, const float* __restrict__ in, float* __restrict__ out, long out4_total) {
+    const f32x4* i4 = reinterpret_cast<const f32x4*>(in);
+    f32x4 xv[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) xv[u] = i4[threadIdx.x + u * 512];
+    const f32x4* p = w + (long)blockIdx.x * n4_per_wg;
+    f32x4 a2[4] = {};
+    long i = threadIdx.x;
+    for (; i + 3 * 512 < n4_per_wg; i += 4 * 512) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 512);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a2[u] += v[u];
+    }
+    for (; i < n4_per_wg; i += 512) a2[0] += __builtin_nontemporal_load(p + i);
+    f32x4 acc = a2[0] + a2[1] + a2[2] + a2[3];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) acc += xv[u];
+    if (NX == 0) acc.x += in[threadIdx.x & 63];
+    acc *= 1e-9f;
+    const long per_wg = out4_total / gridDim.x;
     float* o = out + (long)blockIdx.x * per_wg * 4;
     for (long j = threadIdx.x; j < per_wg; j += 512) store16<POLICY>(o + j * 4, acc);
 }
@@ -54,16 +83,45 @@ static const char* PN[4] = {"plain", "sc1", "sc0 sc1", "nt"};
 
 int main(int argc, char** argv) {
     const int N = 150, REPLAYS = argc > 1 ? atoi(argv[1]) : 20;
-    const long WBYTES = 8 << 20, OUTMAX = 4 << 20;
+    const long WBYTES = 8 << 20, OUTMAX = 4 << 20, WMAX = argc > 2 ? (32 << 20) : WBYTES;
     hipStream_t s0;
     CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
     std::vector<float*> w(N);
-    for (int j = 0; j < N; ++j) { CK(hipMalloc(&w[j], WBYTES)); CK(hipMemsetAsync(w[j], 0, WBYTES, s0)); }
+    for (int j = 0; j < N; ++j) { CK(hipMalloc(&w[j], WMAX)); CK(hipMemsetAsync(w[j], 0, WMAX, s0)); }
     float* act[2];
     for (int k = 0; k < 2; ++k) { CK(hipMalloc(&act[k], OUTMAX)); CK(hipMemsetAsync(act[k], 0, OUTMAX, s0)); }
     CK(hipStreamSynchronize(s0));
     hipEvent_t t0, t1;
     CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    if (argc > 2) {  // hand-off mode: a 64 KB image written by every launch (sc1) and read WHOLE by every workgroup of the next one, requested before the weight stream
+        const long wb[] = {4 << 20, 12 << 20, 16 << 20, 32 << 20};  // the decode projections: o, q | k | v, down, gate|up
+        for (int round = 0; round < 2; ++round)
+            for (long wbytes : wb) {
+                double us[3];
+                for (int m = 0; m < 3; ++m) {  // 0: no hand-off (256 B read), 1: 64 KB requested up front, 2: 64 KB read in a serial loop first
+                    kern_t k = m == 0 ? (kern_t)hidden_kernel<1, 0> : m == 1 ? (kern_t)hidden_kernel<1, 8> : (kern_t)step_kernel<1, true>;
+                    hipGraph_t g; hipGraphExec_t ge;
+                    CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+                    for (int j = 0; j < N; ++j)
+                        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, s0, reinterpret_cast<const f32x4*>(w[j]), wbytes / 16 / 256, act[j & 1], act[(j + 1) & 1], (long)(64 << 10) / 16);
+                    CK(hipStreamEndCapture(s0, &g));
+                    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                    for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, s0));
+                    CK(hipStreamSynchronize(s0));
+                    CK(hipEventRecord(t0, s0));
+                    for (int r = 0; r < REPLAYS; ++r) CK(hipGraphLaunch(ge, s0));
+                    CK(hipEventRecord(t1, s0));
+                    CK(hipStreamSynchronize(s0));
+                    float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+                    us[m] = ms * 1e3 / REPLAYS / N;
+                    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+                }
+                printf("weights %2ld MB per launch, 64 KB image out (sc1): no hand-off %.2f us | image requested before the stream %.2f us | image read first, serially %.2f us\n",
+                       wbytes >> 20, us[0], us[1], us[2]);
+                fflush(stdout);
+            }
+        return 0;
+    }
     const long outs[] = {4 << 10, 64 << 10, 256 << 10, 512 << 10, 2 << 20};
     for (int round = 0; round < 2; ++round)
         for (int rd = 0; rd < 2; ++rd)
